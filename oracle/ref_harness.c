@@ -1,0 +1,179 @@
+/*
+ * ref_harness.c -- thin exported wrappers around the REFERENCE's own header-only
+ * colour math, compiled from where it lies (-I/root/reference/Renderer).
+ * TEST INFRASTRUCTURE ONLY.  Output goes to oracle/_ref/ (git-ignored).
+ *
+ * Nothing of the reference is copied here: this file only #includes
+ * Renderer/BT709.h (which includes Renderer/sRGB.h) and forwards to its
+ * `static inline` functions so that Python (ctypes) can call them.
+ *
+ * The one thing the headers need that plain C lacks is the Objective-C BOOL /
+ * TRUE / FALSE spelling of int/1/0 (BT709.h:1051, 1180 -- debug flags only);
+ * oracle/Makefile passes them as -D macros.  DEBUG is left undefined so the
+ * headers' range asserts stay off, as in the reference's Release build.
+ *
+ * Must be compiled as C (not C++): the headers rely on pow(double,double).
+ */
+#include <assert.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <unistd.h>
+#include <fcntl.h>
+
+#include "BT709.h"
+
+/* gamma ids shared with bt709_oracle.h: 0 Apple, 1 sRGB, 2 Linear, 3 ITU709 */
+
+void ref_decode_pixel(int gamma, int Y, int Cb, int Cr, int rgb[3]) {
+  int R = -1, G = -1, B = -1;
+  if (gamma == 0) {
+    Apple196_to_sRGB_convertYCbCrToRGB(Y, Cb, Cr, &R, &G, &B, 1);
+  } else if (gamma == 1) {
+    sRGB_to_sRGB_convertYCbCrToRGB(Y, Cb, Cr, &R, &G, &B, 1);
+  } else if (gamma == 2) {
+    float Rn, Gn, Bn;
+    BT709_convertYCbCrToNonLinearRGB(Y, Cb, Cr, &Rn, &Gn, &Bn);
+    R = BT709_from_linear(Rn, BT709GammaSrgb);
+    G = BT709_from_linear(Gn, BT709GammaSrgb);
+    B = BT709_from_linear(Bn, BT709GammaSrgb);
+  } else {
+    BT709_to_sRGB_convertYCbCrToRGB(Y, Cb, Cr, &R, &G, &B, 1);
+  }
+  rgb[0] = R;
+  rgb[1] = G;
+  rgb[2] = B;
+}
+
+void ref_encode_pixel(int gamma, int R, int G, int B, int ycbcr[3]) {
+  int Y = -1, Cb = -1, Cr = -1;
+  if (gamma == 0) {
+    Apple196_from_sRGB_convertRGBToYCbCr(R, G, B, &Y, &Cb, &Cr);
+  } else if (gamma == 1) {
+    sRGB_from_sRGB_convertRGBToYCbCr(R, G, B, &Y, &Cb, &Cr);
+  } else if (gamma == 2) {
+    float Rn = sRGB_nonLinearNormToLinear(byteNorm(R));
+    float Gn = sRGB_nonLinearNormToLinear(byteNorm(G));
+    float Bn = sRGB_nonLinearNormToLinear(byteNorm(B));
+    BT709_convertNonLinearRGBToYCbCr(Rn, Gn, Bn, &Y, &Cb, &Cr);
+  } else {
+    BT709_from_sRGB_convertRGBToYCbCr(R, G, B, &Y, &Cb, &Cr, 1);
+  }
+  ycbcr[0] = Y;
+  ycbcr[1] = Cb;
+  ycbcr[2] = Cr;
+}
+
+void ref_ycbcr_to_rgbn(int Y, int Cb, int Cr, float rgbn[3]) {
+  BT709_convertYCbCrToNonLinearRGB(Y, Cb, Cr, &rgbn[0], &rgbn[1], &rgbn[2]);
+}
+
+int ref_decode_alpha(int A) {
+  float Rn, Gn, Bn;
+  BT709_convertYCbCrToNonLinearRGB(A, 128, 128, &Rn, &Gn, &Bn);
+  return (int)round(Rn * 255.0f);
+}
+
+/* composite per-channel map applied after matrix+saturate, built only from
+ * reference functions */
+int ref_transfer_to_byte(int gamma, float v) {
+  if (gamma == 0) v = sRGB_linearNormToNonLinear(Apple196_nonLinearNormToLinear(v));
+  else if (gamma == 2) v = sRGB_linearNormToNonLinear(v);
+  else if (gamma == 3) v = sRGB_linearNormToNonLinear(BT709_nonLinearNormToLinear(v));
+  return (int)round(v * 255.0f);
+}
+
+float ref_srgb_to_linear(float v) { return sRGB_nonLinearNormToLinear(v); }
+float ref_linear_to_srgb(float v) { return sRGB_linearNormToNonLinear(v); }
+float ref_itu709_to_linear(float v) { return BT709_nonLinearNormToLinear(v); }
+float ref_linear_to_itu709(float v) { return BT709_linearNormToNonLinear(v); }
+float ref_apple196_to_linear(float v) { return Apple196_nonLinearNormToLinear(v); }
+float ref_linear_to_apple196(float v) { return Apple196_linearNormToNonLinear(v); }
+
+/* index (Y<<16)+(Cb<<8)+Cr, 3 bytes R,G,B per entry; rows [y0,y1) of Y */
+void ref_decode_table(int gamma, uint8_t *table, int y0, int y1) {
+  for (int Y = y0; Y < y1; Y++)
+    for (int Cb = 0; Cb < 256; Cb++)
+      for (int Cr = 0; Cr < 256; Cr++) {
+        int rgb[3];
+        ref_decode_pixel(gamma, Y, Cb, Cr, rgb);
+        size_t i = ((size_t)Y << 16) + ((size_t)Cb << 8) + (size_t)Cr;
+        table[3 * i + 0] = (uint8_t)rgb[0];
+        table[3 * i + 1] = (uint8_t)rgb[1];
+        table[3 * i + 2] = (uint8_t)rgb[2];
+      }
+}
+
+/* worst-channel round-trip error histogram over R in [r0,r1) */
+void ref_roundtrip_histogram(int gamma, uint64_t hist[11], int r0, int r1) {
+  for (int d = 0; d < 11; d++) hist[d] = 0;
+  for (int R = r0; R < r1; R++)
+    for (int G = 0; G < 256; G++)
+      for (int B = 0; B < 256; B++) {
+        int v[3], o[3];
+        ref_encode_pixel(gamma, R, G, B, v);
+        ref_decode_pixel(gamma, v[0], v[1], v[2], o);
+        int e = abs(o[0] - R);
+        if (abs(o[1] - G) > e) e = abs(o[1] - G);
+        if (abs(o[2] - B) > e) e = abs(o[2] - B);
+        hist[e > 10 ? 10 : e]++;
+      }
+}
+
+static int to_ref_gamma(int g) {
+  return g == 0 ? BT709GammaApple : (g == 1 ? BT709GammaSrgb : BT709GammaLinear);
+}
+
+/* BT709_average_pixel_values has `debug = 1` left on (BT709.h:1373) and prints
+ * several lines per call; park stdout on /dev/null while a batch runs. */
+static int saved_stdout = -1;
+void ref_quiet_begin(void) {
+  fflush(stdout);
+  saved_stdout = dup(1);
+  int nul = open("/dev/null", O_WRONLY);
+  dup2(nul, 1);
+  close(nul);
+}
+void ref_quiet_end(void) {
+  fflush(stdout);
+  if (saved_stdout >= 0) {
+    dup2(saved_stdout, 1);
+    close(saved_stdout);
+    saved_stdout = -1;
+  }
+}
+
+/* rgb = {R1,G1,B1,...,R4,G4,B4}; out = {Y1,Y2,Y3,Y4,Cb,Cr} */
+void ref_subsample_block(const int rgb[12], int in_gamma, int out_gamma, int out[6]) {
+  BT709_average_pixel_values(rgb[0], rgb[1], rgb[2], rgb[3], rgb[4], rgb[5],
+                             rgb[6], rgb[7], rgb[8], rgb[9], rgb[10], rgb[11],
+                             &out[0], &out[1], &out[2], &out[3], &out[4], &out[5],
+                             to_ref_gamma(in_gamma), to_ref_gamma(out_gamma));
+}
+
+/* BGRA words -> tight NV12 via repeated BT709_average_pixel_values, walking
+ * blocks the way cvpbu_ycbcr_subsample does (that function itself needs
+ * CoreVideo and cannot be built here). */
+void ref_encode_nv12(const uint32_t *bgra, int width, int height, int in_gamma,
+                     int out_gamma, uint8_t *y, uint8_t *uv) {
+  ref_quiet_begin();
+  for (int row = 0; row < height; row += 2)
+    for (int col = 0; col < width; col += 2) {
+      int rgb[12], out[6];
+      const uint32_t p[4] = {bgra[row * width + col], bgra[row * width + col + 1],
+                             bgra[(row + 1) * width + col], bgra[(row + 1) * width + col + 1]};
+      for (int i = 0; i < 4; i++) {
+        rgb[3 * i] = (p[i] >> 16) & 0xFF;
+        rgb[3 * i + 1] = (p[i] >> 8) & 0xFF;
+        rgb[3 * i + 2] = p[i] & 0xFF;
+      }
+      ref_subsample_block(rgb, in_gamma, out_gamma, out);
+      y[row * width + col] = (uint8_t)out[0];
+      y[row * width + col + 1] = (uint8_t)out[1];
+      y[(row + 1) * width + col] = (uint8_t)out[2];
+      y[(row + 1) * width + col + 1] = (uint8_t)out[3];
+      uv[(row / 2) * width + col] = (uint8_t)out[4];
+      uv[(row / 2) * width + col + 1] = (uint8_t)out[5];
+    }
+  ref_quiet_end();
+}
