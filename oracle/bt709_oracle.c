@@ -186,6 +186,22 @@ void bt709o_encode_pixel(int gamma, int R, int G, int B, int ycbcr[3]) {
   rgbn_to_ycbcr(n[0], n[1], n[2], ycbcr);
 }
 
+void bt709o_encode_linear_pixel(int apply_curve, int R, int G, int B, int ycbcr[3]) {
+  float n[3] = {byte_norm(R), byte_norm(G), byte_norm(B)}; /* BT709.h:336-338 */
+  if (apply_curve) /* BT709.h:300-315 */
+    for (int c = 0; c < 3; c++) n[c] = bt709o_linear_to_itu709(n[c]);
+  rgbn_to_ycbcr(n[0], n[1], n[2], ycbcr);
+}
+
+void bt709o_decode_to_linear_pixel(int apply_curve, int Y, int Cb, int Cr, int rgb[3]) {
+  float n[3];
+  bt709o_ycbcr_to_rgbn(Y, Cb, Cr, n);
+  for (int c = 0; c < 3; c++) {
+    if (apply_curve) n[c] = bt709o_itu709_to_linear(n[c]); /* BT709.h:536-546 */
+    rgb[c] = bt709o_quantize(n[c]);                        /* BT709.h:577-579 */
+  }
+}
+
 /* ------------------------------------------------------------------ frames */
 
 /* The per-channel byte map depends only on the saturated pre-gamma float, and

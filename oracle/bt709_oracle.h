@@ -87,6 +87,14 @@ int bt709o_decode_alpha(int A);
  * LINEAR = sRGB -> linear -> matrix (no video curve). */
 void bt709o_encode_pixel(int gamma, int R, int G, int B, int ycbcr[3]);
 
+/* BT709_convertRGBToYCbCr / BT709_convertYCbCrToRGB (BT709.h:327-341, 558-605):
+ * bytes are treated as LINEAR light; apply_curve selects the ITU curve on the
+ * way in / out.  Off the decoder's path; kept because the reference's direct
+ * C tests (CoreImageMetalFilterTests.m:94-357) pin the ITU transfer pair
+ * through them. */
+void bt709o_encode_linear_pixel(int apply_curve, int R, int G, int B, int ycbcr[3]);
+void bt709o_decode_to_linear_pixel(int apply_curve, int Y, int Cb, int Cr, int rgb[3]);
+
 /* ---- frames */
 /* NV12 (+ optional linear alpha plane) -> BGRA8.  Chroma is replicated
  * (row/2, col/2: BGRAToBT709Converter.m:267-277).  Output word is

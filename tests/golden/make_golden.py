@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json|*.npz from the reference tree.  CONTAINER ONLY.
+
+Needs /root/reference (read-only) and oracle/_ref/libbt709ref.so (built by
+`make -C oracle` from the reference headers where they lie).  Everything written
+here is DATA -- numbers asserted by the reference's XCTest files, outputs of the
+reference's own header functions, and small crops of images the reference
+bundles, passed through the reference's encode functions -- never source text.
+
+    python tests/golden/make_golden.py
+
+Outputs (all committed):
+  vectors.json      test-suite vectors parsed from EmptyiOSTests/*.m (file:line kept)
+  reference.json    table hashes, histograms, threshold tables, alpha map, produced by
+                    running the reference headers (oracle/_ref)
+  patterns.npz      crops of the bundled test images as NV12 (reference encoder) with the
+                    reference decode of each crop in every gamma mode
+"""
+import hashlib
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle_lib import Reference  # noqa: E402
+
+REF = "/root/reference"
+TESTS = os.path.join(REF, "EmptyiOSTests")
+
+
+# ----------------------------------------------------------------- XCTest parsing
+
+def strip_comments(src):
+    src = re.sub(r"/\*.*?\*/", lambda m: "\n" * m.group(0).count("\n"), src, flags=re.S)
+    return re.sub(r"//[^\n]*", "", src)
+
+
+def methods(path):
+    """Yield (name, first_line, body) for every `- (void)testXxx {` method."""
+    src = strip_comments(open(path, encoding="utf-8", errors="replace").read())
+    heads = [(m.start(), m.group(1)) for m in re.finditer(r"^- \(void\)\s*(test\w+)\s*\{", src, flags=re.M)]
+    for i, (pos, name) in enumerate(heads):
+        end = heads[i + 1][0] if i + 1 < len(heads) else len(src)
+        yield name, src.count("\n", 0, pos) + 1, src[pos:end]
+
+
+ASSIGN = re.compile(r"\b(?:int|uint32_t)?\s*\b(Rin|Gin|Bin)\s*=\s*([^;]+);")
+EXPECT = re.compile(r"int\s+v\s*=\s*(\w+)\s*;\s*int\s+expectedVal\s*=\s*([^;]+);", re.S)
+TYPE = re.compile(r"BGRAToBT709ConverterTypeEnum\s+(\w+)\s*=\s*BGRAToBT709Converter(\w+)\s*;")
+CALL = re.compile(r"\b((?:BT709|Apple196|sRGB)_\w*convert\w+)\s*\(")
+GAMMAFLAG = re.compile(r"\bapplyGammaMap\s*=\s*(\d)\s*;")
+
+
+def parse_method(body):
+    env = {}
+    for m in ASSIGN.finditer(body):
+        try:
+            env[m.group(1)] = int(eval(m.group(2), {}, dict(env)))
+        except Exception:
+            pass
+    expects = []
+    for m in EXPECT.finditer(body):
+        try:
+            expects.append((m.group(1), int(eval(m.group(2), {}, dict(env)))))
+        except Exception:
+            expects.append((m.group(1), None))
+    types = {m.group(1): m.group(2) for m in TYPE.finditer(body)}
+    calls = []
+    for m in CALL.finditer(body):
+        if m.group(1) not in calls:
+            calls.append(m.group(1))
+    flag = GAMMAFLAG.search(body)
+    return env, expects, types, calls, (int(flag.group(1)) if flag else None)
+
+
+def triple(expects, names):
+    d = {}
+    for k, v in expects:
+        if k in names and k not in d:
+            d[k] = v
+    if all(n in d and d[n] is not None for n in names):
+        return [d[n] for n in names]
+    return None
+
+
+def collect_vectors():
+    out = {"metal_decode": [], "converter": [], "direct_c": []}
+
+    # 1. Metal decode tests: sRGB -> (Y,Cb,Cr) -> Metal decode, default Apple gamma
+    f = os.path.join(TESTS, "MetalBT709DecoderTests.m")
+    for name, line, body in methods(f):
+        env, expects, types, _, _ = parse_method(body)
+        ycc = triple(expects, ["Y", "Cb", "Cr"])
+        rgb = triple(expects, ["Rout", "Gout", "Bout"])
+        if ycc and rgb and all(k in env for k in ("Rin", "Gin", "Bin")):
+            out["metal_decode"].append({
+                "test": name, "src": "EmptyiOSTests/MetalBT709DecoderTests.m:%d" % line,
+                "rgb_in": [env["Rin"], env["Gin"], env["Bin"]], "ycbcr": ycc, "rgb_out": rgb,
+                "encode_type": types.get("type", types.get("encodeType")),
+                "decode_type": types.get("decodeType")})
+
+    # 2. converter tests (software / vImage / metal decode of greys)
+    f = os.path.join(TESTS, "AppleEncodeDecodeBT709Tests.m")
+    for name, line, body in methods(f):
+        env, expects, types, _, _ = parse_method(body)
+        ycc = triple(expects, ["Y", "Cb", "Cr"])
+        rgb = triple(expects, ["Rout", "Gout", "Bout"])
+        if ycc and rgb and all(k in env for k in ("Rin", "Gin", "Bin")):
+            out["converter"].append({
+                "test": name, "src": "EmptyiOSTests/AppleEncodeDecodeBT709Tests.m:%d" % line,
+                "rgb_in": [env["Rin"], env["Gin"], env["Bin"]], "ycbcr": ycc, "rgb_out": rgb,
+                "encode_type": types.get("encodeType", types.get("type")),
+                "decode_type": types.get("decodeType")})
+
+    # 3. direct calls into BT709.h
+    f = os.path.join(TESTS, "CoreImageMetalFilterTests.m")
+    for name, line, body in methods(f):
+        env, expects, _, calls, flag = parse_method(body)
+        ycc = triple(expects, ["Y", "Cb", "Cr"])
+        rgb = triple(expects, ["R", "G", "B"])
+        if ycc and all(k in env for k in ("Rin", "Gin", "Bin")) and len(calls) <= 2:
+            out["direct_c"].append({
+                "test": name, "src": "EmptyiOSTests/CoreImageMetalFilterTests.m:%d" % line,
+                "rgb_in": [env["Rin"], env["Gin"], env["Bin"]], "ycbcr": ycc, "rgb_out": rgb,
+                "calls": calls, "applyGammaMap": flag})
+    return out
+
+
+def collect_histograms():
+    """`XCTAssert([mDict[@"exact"] intValue] == N` plus the result comment block."""
+    f = os.path.join(TESTS, "CoreImageMetalFilterTests.m")
+    raw = open(f, encoding="utf-8", errors="replace").read()
+    res = {}
+    wanted = {"testConvertsRGBTo709_RoundTripAll_WithGamma": "itu709",
+              "testConvertsRGBToApple196_RoundTripAll_WithGamma": "apple",
+              "testConvertSRGBToSRGB_RoundTripAll_WithGamma": "srgb"}
+    for name, key in wanted.items():
+        pos = raw.index("(void)" + name)
+        line = raw.count("\n", 0, pos) + 1
+        tail = raw[pos:]
+        exact = int(re.search(r'mDict\[@"exact"\] intValue\] == (\d+)', tail).group(1))
+        block = re.search(r"/\*(.*?)\*/", tail, flags=re.S).group(1)
+        hist = {}
+        for m in re.finditer(r"(exact|off\d|offMore9)\s*=\s*(\d+)", block):
+            hist[m.group(1)] = int(m.group(2))
+        res[key] = {"src": "EmptyiOSTests/CoreImageMetalFilterTests.m:%d" % line,
+                    "asserted_exact": exact, "comment_block": hist}
+    return res
+
+
+# ----------------------------------------------------------------- reference runs
+
+def run_reference(ref):
+    out = {"note": "produced by oracle/_ref/libbt709ref.so = /root/reference/Renderer/BT709.h + sRGB.h "
+                   "compiled in place (gcc -O2 -ffp-contract=off, DEBUG undefined)"}
+    out["table_sha256"] = {}
+    out["histograms"] = {}
+    out["thresholds_hex"] = {}
+    names = {0: "apple", 1: "srgb", 2: "linear", 3: "itu709"}
+    for g, n in names.items():
+        t = ref.decode_table(g)
+        out["table_sha256"][n] = hashlib.sha256(t.tobytes()).hexdigest()
+        print("table", n, out["table_sha256"][n], flush=True)
+        thr = ref.thresholds(g)
+        out["thresholds_hex"][n] = ["%08x" % v for v in thr.view(np.uint32)]
+        if g != 2:
+            out["histograms"][n] = ref.roundtrip_histogram(g)
+            print("hist", n, out["histograms"][n], flush=True)
+    out["alpha_map"] = [ref.decode_alpha(a) for a in range(256)]
+    # sampled subsample-block vectors (encode side; BT709_average_pixel_values)
+    rng = np.random.default_rng(709)
+    blocks = []
+    for _ in range(64):
+        rgb = [int(v) for v in rng.integers(0, 256, 12)]
+        for ig, og in ((1, 0), (1, 1), (0, 0)):
+            blocks.append({"rgb": rgb, "in": ig, "out": og, "y4cbcr": list(ref.subsample_block(rgb, ig, og))})
+    out["subsample_blocks"] = blocks
+    return out
+
+
+# ----------------------------------------------------------------- bundled images
+
+def load_bgra(path):
+    from PIL import Image
+    im = Image.open(path).convert("RGB")
+    a = np.asarray(im, dtype=np.uint32)
+    return (a[..., 0] << 16) | (a[..., 1] << 8) | a[..., 2]
+
+
+def decode_ref(ref, gamma, y, uv):
+    """Reference per-pixel decode over a tight NV12 crop via its full table."""
+    tbl = decode_ref.tables.get(gamma)
+    if tbl is None:
+        tbl = decode_ref.tables[gamma] = ref.decode_table(gamma).reshape(-1, 3)
+    h, w = y.shape
+    cb = np.repeat(np.repeat(uv[:, 0::2], 2, axis=0), 2, axis=1).astype(np.uint32)
+    cr = np.repeat(np.repeat(uv[:, 1::2], 2, axis=0), 2, axis=1).astype(np.uint32)
+    idx = (y.astype(np.uint32) << 16) | (cb << 8) | cr
+    rgb = tbl[idx.reshape(-1)].reshape(h, w, 3)
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    out[..., 0] = rgb[..., 2]
+    out[..., 1] = rgb[..., 1]
+    out[..., 2] = rgb[..., 0]
+    out[..., 3] = 0xFF
+    return out
+
+
+decode_ref.tables = {}
+
+
+def collect_patterns(ref):
+    imgs = [
+        ("qt_hd", "Renderer/QuickTime_Test_Pattern_HD_sRGB.png",
+         [(0, 0, 256, 128), (832, 476, 256, 128), (1664, 952, 256, 128), (448, 64, 128, 256)]),
+        ("clouds", "Renderer/clouds_reflecting_off_the_beach-wallpaper-2048x1536.jpg",
+         [(0, 0, 128, 128), (960, 704, 128, 128), (1920, 1408, 128, 128)]),
+    ]
+    arrays, meta = {}, []
+    for key, rel, crops in imgs:
+        bgra = load_bgra(os.path.join(REF, rel))
+        H, W = bgra.shape
+        for (x, y0, w, h) in crops:
+            tile = np.ascontiguousarray(bgra[y0:y0 + h, x:x + w])
+            # reference encoder: sRGB in -> Apple 1.96 video gamma out (the app's default clip type)
+            yp, uv = ref.encode_nv12(tile.reshape(-1), w, h, 1, 0)
+            tag = "%s_%d_%d_%dx%d" % (key, x, y0, w, h)
+            arrays[tag + "_y"] = yp
+            arrays[tag + "_uv"] = uv
+            rec = {"tag": tag, "image": rel, "image_size": [W, H], "crop": [x, y0, w, h], "bgra_sha256": {}}
+            for g, n in ((0, "apple"), (1, "srgb"), (2, "linear"), (3, "itu709")):
+                out = decode_ref(ref, g, yp, uv)
+                rec["bgra_sha256"][n] = hashlib.sha256(out.tobytes()).hexdigest()
+                if g == 0:
+                    arrays[tag + "_bgra_apple"] = out.reshape(h, w * 4)
+            meta.append(rec)
+            print("pattern", tag, flush=True)
+    return arrays, meta
+
+
+def main():
+    ref = Reference()
+    vec = collect_vectors()
+    vec["histograms"] = collect_histograms()
+    print({k: len(v) for k, v in vec.items()})
+    json.dump(vec, open(os.path.join(HERE, "vectors.json"), "w"), indent=1)
+
+    r = run_reference(ref)
+    arrays, meta = collect_patterns(ref)
+    r["patterns"] = meta
+    json.dump(r, open(os.path.join(HERE, "reference.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(HERE, "patterns.npz"), **arrays)
+    print("patterns.npz", os.path.getsize(os.path.join(HERE, "patterns.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,8 @@ class Oracle:
         L.bt709o_decode_pixel.argtypes = [C.c_int] * 4 + [_i32p]
         L.bt709o_decode_alpha.restype, L.bt709o_decode_alpha.argtypes = C.c_int, [C.c_int]
         L.bt709o_encode_pixel.argtypes = [C.c_int] * 4 + [_i32p]
+        L.bt709o_encode_linear_pixel.argtypes = [C.c_int] * 4 + [_i32p]
+        L.bt709o_decode_to_linear_pixel.argtypes = [C.c_int] * 4 + [_i32p]
         L.bt709o_decode_nv12_rows.restype = C.c_int
         L.bt709o_decode_nv12_rows.argtypes = [
             C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, _u8p, C.c_size_t,
@@ -95,6 +97,16 @@ class Oracle:
 
     def decode_alpha(self, A):
         return self.lib.bt709o_decode_alpha(A)
+
+    def encode_linear_pixel(self, apply_curve, R, G, B):
+        out = (C.c_int * 3)()
+        self.lib.bt709o_encode_linear_pixel(apply_curve, R, G, B, out)
+        return tuple(out)
+
+    def decode_to_linear_pixel(self, apply_curve, Y, Cb, Cr):
+        out = (C.c_int * 3)()
+        self.lib.bt709o_decode_to_linear_pixel(apply_curve, Y, Cb, Cr, out)
+        return tuple(out)
 
     def ycbcr_to_rgbn(self, Y, Cb, Cr):
         out = (C.c_float * 3)()
