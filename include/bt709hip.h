@@ -1,0 +1,235 @@
+/*
+ * bt709hip.h -- C ABI of the MI355X (gfx950) BT.709 NV12 -> sRGB BGRA decode path.
+ *
+ * This is the drop-in boundary for the reference's decode operator
+ * (paths relative to the reference repository, mdejong/MetalBT709Decoder):
+ *
+ *   Renderer/MetalRenderContext.h:17-105   device / queue holder, texture alloc,
+ *                                          upload and read-back helpers
+ *                                          -> bt709hip_context_*, bt709hip_malloc/free,
+ *                                             bt709hip_upload/download, bt709hip_stream_*
+ *   Renderer/MetalBT709Decoder.h:15-19     MetalBT709Gamma            -> bt709hip_gamma
+ *   Renderer/MetalBT709Decoder.h:27-48     gamma / hasAlphaChannel /
+ *                                          useComputeRenderer props   -> bt709hip_decoder_create
+ *   Renderer/MetalBT709Decoder.h:56        -setupMetal                -> bt709hip_decoder_setup
+ *   Renderer/MetalBT709Decoder.h:65-72     -decodeBT709:alphaPixelBuffer:bgraSRGBTexture:
+ *                                           commandBuffer:renderPassDescriptor:renderWidth:
+ *                                           renderHeight:waitUntilCompleted:
+ *                                                                     -> bt709hip_decode
+ *   Renderer/MetalScaleRenderContext.h:34-40  -renderScaled:... (pass 2), fused with pass 1
+ *                                          for the exact 2:1 case     -> bt709hip_decode_half
+ *
+ * Plain C types only: pointers are DEVICE pointers unless a parameter says
+ * "host"; a stream is an opaque hipStream_t passed as void*; sizes are bytes.
+ * Every function returns a bt709hip_status (0 = success) unless noted.  The
+ * reference's BOOL convention is one comparison away: ok = (status == 0).
+ *
+ * Ownership (differs from the reference on purpose): the caller
+ * owns every buffer and stream; a decoder holds only its lookup table, keeps no
+ * per-frame state, and may be used from several streams at once.  Buffers must
+ * stay alive until the stream has passed the decode.
+ */
+#ifndef BT709HIP_H
+#define BT709HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BT709HIP_VERSION 100
+
+typedef struct bt709hip_context bt709hip_context; /* ~ MetalRenderContext */
+typedef struct bt709hip_decoder bt709hip_decoder; /* ~ MetalBT709Decoder  */
+
+typedef enum {
+  BT709HIP_OK = 0,
+  BT709HIP_ERR_INVALID_ARG = -1,    /* NULL pointer, unknown enum, negative size */
+  BT709HIP_ERR_NOT_SETUP = -2,      /* decoder has no context (setupMetal would return FALSE, .m:48-54) */
+  BT709HIP_ERR_SIZE_MISMATCH = -3,  /* out != in, render != in, alpha != in (.m:272-306) */
+  BT709HIP_ERR_ODD_DIMENSIONS = -4, /* 4:2:0 needs even W,H (BGRAToBT709Converter.m:69-74) */
+  BT709HIP_ERR_MATRIX = -5,         /* YCbCr matrix tag is not ITU_R_709_2 (.m:311-318) */
+  BT709HIP_ERR_TRANSFER = -6,       /* transfer tag does not match the decoder's gamma (.m:320-353) */
+  BT709HIP_ERR_ALPHA_TRANSFER = -7, /* alpha buffer is not tagged linear (.m:357-368) */
+  BT709HIP_ERR_STRIDE = -8,         /* stride smaller than a row / misaligned output */
+  BT709HIP_ERR_HIP = -9,            /* a HIP call failed: see bt709hip_last_hip_error */
+  BT709HIP_ERR_NO_DEVICE = -10,     /* no such GPU */
+  BT709HIP_ERR_UNSUPPORTED = -11    /* e.g. batch larger than BT709HIP_MAX_BATCH */
+} bt709hip_status;
+
+/* MetalBT709Gamma (MetalBT709Decoder.h:15-19).  ITU709 is an extension: the true
+ * ITU curve the reference keeps as a dead branch (BGRAToBT709Converter.m:175-183). */
+typedef enum {
+  BT709HIP_GAMMA_APPLE = 0, /* default */
+  BT709HIP_GAMMA_SRGB = 1,
+  BT709HIP_GAMMA_LINEAR = 2,
+  BT709HIP_GAMMA_ITU709 = 3
+} bt709hip_gamma;
+
+/* kCVImageBufferYCbCrMatrixKey values the reference looks at (.m:311-318) */
+typedef enum {
+  BT709HIP_MATRIX_UNSPECIFIED = 0,
+  BT709HIP_MATRIX_ITU_R_709_2 = 1,
+  BT709HIP_MATRIX_ITU_R_601_4 = 2,
+  BT709HIP_MATRIX_SMPTE_240M = 3
+} bt709hip_matrix_tag;
+
+/* kCVImageBufferTransferFunctionKey values the reference looks at (.m:320-353) */
+typedef enum {
+  BT709HIP_TRANSFER_UNSPECIFIED = 0,
+  BT709HIP_TRANSFER_ITU_R_709_2 = 1, /* required by GAMMA_APPLE and GAMMA_ITU709 */
+  BT709HIP_TRANSFER_SRGB = 2,        /* required by GAMMA_SRGB */
+  BT709HIP_TRANSFER_LINEAR = 3       /* required by GAMMA_LINEAR and by every alpha buffer */
+} bt709hip_transfer_tag;
+
+/* One 4:2:0 biplanar video-range frame ("420v", what createCoreVideoYCbCrBuffer
+ * makes: BGRAToBT709Converter.m:471-494) plus the two colour attachments the
+ * decoder validates.  Replaces CVPixelBufferRef.  For an alpha frame only the
+ * y plane is read (cvpbu_wrap_y_plane_as_metal_texture, CVPixelBufferUtils.h:82-116);
+ * cbcr may be NULL there. */
+typedef struct {
+  const void *y;      /* W x H bytes, row pitch y_stride               */
+  size_t y_stride;
+  const void *cbcr;   /* (W/2) x (H/2) byte pairs Cb,Cr; pitch cbcr_stride */
+  size_t cbcr_stride;
+  int32_t width;      /* luma width, even  */
+  int32_t height;     /* luma height, even */
+  int32_t matrix;     /* bt709hip_matrix_tag   */
+  int32_t transfer;   /* bt709hip_transfer_tag */
+} bt709hip_frame;
+
+/* 8-bit BGRA sRGB render target; replaces id<MTLTexture> BGRA8Unorm_sRGB.
+ * Memory order B,G,R,A i.e. little-endian word (A<<24)|(R<<16)|(G<<8)|B
+ * (MetalBT709DecoderTests.m:47-52).  bgra must be 4-byte aligned, stride a
+ * multiple of 4 (16-byte alignment of both enables the wide-store kernel). */
+typedef struct {
+  void *bgra;
+  size_t stride;
+  int32_t width;
+  int32_t height;
+} bt709hip_surface;
+
+typedef struct {
+  int32_t device_ordinal;
+  int32_t compute_units;
+  int32_t wavefront_size;
+  int32_t lds_bytes_per_block;
+  int32_t memory_clock_khz;
+  int32_t memory_bus_width_bits;
+  int32_t l2_bytes;
+  int32_t clock_khz;
+  uint64_t total_memory_bytes;
+  char name[128];
+  char arch[64];
+} bt709hip_device_info;
+
+#define BT709HIP_MAX_BATCH 32
+
+/* ------------------------------------------------------------------ context */
+/* MetalRenderContext -setupMetal (MetalRenderContext.m:36-74): bind a device,
+ * create the default stream.  device_ordinal is the HIP device index. */
+int bt709hip_context_create(int device_ordinal, bt709hip_context **out);
+int bt709hip_context_destroy(bt709hip_context *ctx);
+int bt709hip_context_info(const bt709hip_context *ctx, bt709hip_device_info *info);
+/* Number of visible GPUs; does not initialise any of them.  Returns count or <0. */
+int bt709hip_device_count(void);
+
+/* Streams ~ MTLCommandQueue/-commandBuffer (MetalRenderContext.h:20): one per
+ * in-flight frame.  `stream == NULL` anywhere below means the context's default. */
+int bt709hip_stream_create(bt709hip_context *ctx, void **stream);
+int bt709hip_stream_destroy(bt709hip_context *ctx, void *stream);
+int bt709hip_stream_synchronize(bt709hip_context *ctx, void *stream);
+
+/* Events (timing only; no reference twin). elapsed: milliseconds start->stop. */
+int bt709hip_event_create(bt709hip_context *ctx, void **event);
+int bt709hip_event_destroy(bt709hip_context *ctx, void *event);
+int bt709hip_event_record(bt709hip_context *ctx, void *event, void *stream);
+int bt709hip_event_synchronize(bt709hip_context *ctx, void *event);
+int bt709hip_event_elapsed_ms(bt709hip_context *ctx, void *start, void *stop, float *ms);
+
+/* Device memory ~ make*Texture / fill* / get*TexturePixels
+ * (MetalRenderContext.h:62-105).  upload/download are asynchronous on `stream`
+ * (hipMemcpy2DAsync); host memory should be pinned for true overlap
+ * (bt709hip_host_alloc).  Pitches are bytes; `row_bytes` x `rows` is copied. */
+int bt709hip_malloc(bt709hip_context *ctx, size_t bytes, void **dptr);
+int bt709hip_free(bt709hip_context *ctx, void *dptr);
+int bt709hip_host_alloc(bt709hip_context *ctx, size_t bytes, void **hptr);
+int bt709hip_host_free(bt709hip_context *ctx, void *hptr);
+int bt709hip_memset(bt709hip_context *ctx, void *dptr, int value, size_t bytes, void *stream);
+int bt709hip_upload(bt709hip_context *ctx, void *dst_dev, size_t dst_pitch,
+                    const void *src_host, size_t src_pitch,
+                    size_t row_bytes, size_t rows, void *stream);
+int bt709hip_download(bt709hip_context *ctx, void *dst_host, size_t dst_pitch,
+                      const void *src_dev, size_t src_pitch,
+                      size_t row_bytes, size_t rows, void *stream);
+
+/* ------------------------------------------------------------------ decoder */
+/* alloc/init + property assignment.  has_alpha != 0 forces gamma to SRGB exactly
+ * as -setupMetalRenderPipeline does (MetalBT709Decoder.m:165-169).  ctx may be
+ * NULL (a decoder without a render context): setup/decode then fail with
+ * ERR_NOT_SETUP, mirroring .m:48-54; attach one with bt709hip_decoder_set_context. */
+int bt709hip_decoder_create(bt709hip_context *ctx, int gamma, int has_alpha,
+                            bt709hip_decoder **out);
+int bt709hip_decoder_destroy(bt709hip_decoder *dec);
+int bt709hip_decoder_set_context(bt709hip_decoder *dec, bt709hip_context *ctx);
+/* Alpha byte written when the decoder has no alpha channel.  Default 0xFF (Metal
+ * opaque path, AAPLShaders.metal:243); 0x00 reproduces unconvertSoftware's words
+ * (BGRAToBT709Converter.m:187-193). */
+int bt709hip_decoder_set_alpha_fill(bt709hip_decoder *dec, int alpha_byte);
+int bt709hip_decoder_get_gamma(const bt709hip_decoder *dec);
+/* -setupMetal: builds the exact transfer table for the decoder's gamma and puts
+ * it in device memory.  Idempotent (MetalBT709Decoder.m:66-70); implied by decode. */
+int bt709hip_decoder_setup(bt709hip_decoder *dec);
+
+/* -decodeBT709:... (MetalBT709Decoder.h:65-72).  Enqueues ONE fused kernel
+ * (chroma replicate + YCbCr->RGB matrix + exact transfer + 8-bit pack) on
+ * `stream`.  `alpha` may be NULL.  render_width/height must equal the frame size
+ * (pass 1 never scales: .m:284-290).  wait_until_completed != 0 synchronises the
+ * stream before returning (.m:486-489). */
+int bt709hip_decode(bt709hip_decoder *dec,
+                    const bt709hip_frame *frame, const bt709hip_frame *alpha,
+                    const bt709hip_surface *out,
+                    int render_width, int render_height,
+                    void *stream, int wait_until_completed);
+
+/* The same operator over `count` <= BT709HIP_MAX_BATCH independent frames of one
+ * geometry (same width/height/strides/tags) in ONE launch: grid.y = frame.  This
+ * is how a stream of small frames stays off the launch-latency floor.  alphas may
+ * be NULL. */
+int bt709hip_decode_batch(bt709hip_decoder *dec, int count,
+                          const bt709hip_frame *frames, const bt709hip_frame *alphas,
+                          const bt709hip_surface *outs,
+                          void *stream, int wait_until_completed);
+
+/* Pass 1 + pass 2 (MetalScaleRenderContext -renderScaled:, bilinear) fused for the
+ * exact 2:1 ratio: out is (W/2) x (H/2).  Frame W,H must be multiples of 4.
+ * Two-pass-equivalent arithmetic: each output channel is the linear-light mean of
+ * the four decoded 8-bit sRGB values, re-encoded to sRGB ("rescale"). */
+int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame,
+                         const bt709hip_surface *out,
+                         void *stream, int wait_until_completed);
+int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count,
+                               const bt709hip_frame *frames, const bt709hip_surface *outs,
+                               void *stream, int wait_until_completed);
+
+/* -------------------------------------------------------------- diagnostics */
+const char *bt709hip_strerror(int status);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none). */
+int bt709hip_last_hip_error(void);
+const char *bt709hip_last_hip_error_string(void);
+
+/* Introspection used by the parity tests (host memory out).
+ * thresholds: 255 floats, t[k-1] = smallest x in [0,1] whose output byte is >= k.
+ * constants:  8 floats {1/255, M_y, M_cr_r, M_cb_g, M_cr_g, M_cb_b, 16, 128}
+ *             (matrix built as BT709.h:386-397). */
+int bt709hip_gamma_thresholds(int gamma, float thresholds[255]);
+int bt709hip_matrix_constants(float constants[8]);
+/* Name of the kernel the last decode on this thread launched (for profiling). */
+const char *bt709hip_last_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BT709HIP_H */

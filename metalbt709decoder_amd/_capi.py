@@ -1,0 +1,135 @@
+"""ctypes binding of the C ABI declared in include/bt709hip.h.
+
+Loading never falls back to anything: if libbt709hip.so is missing and cannot be
+built, importing the product raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+class Frame(C.Structure):  # bt709hip_frame
+    _fields_ = [("y", C.c_void_p), ("y_stride", C.c_size_t),
+                ("cbcr", C.c_void_p), ("cbcr_stride", C.c_size_t),
+                ("width", C.c_int32), ("height", C.c_int32),
+                ("matrix", C.c_int32), ("transfer", C.c_int32)]
+
+
+class Surface(C.Structure):  # bt709hip_surface
+    _fields_ = [("bgra", C.c_void_p), ("stride", C.c_size_t),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class DeviceInfo(C.Structure):  # bt709hip_device_info
+    _fields_ = [("device_ordinal", C.c_int32), ("compute_units", C.c_int32),
+                ("wavefront_size", C.c_int32), ("lds_bytes_per_block", C.c_int32),
+                ("memory_clock_khz", C.c_int32), ("memory_bus_width_bits", C.c_int32),
+                ("l2_bytes", C.c_int32), ("clock_khz", C.c_int32),
+                ("total_memory_bytes", C.c_uint64),
+                ("name", C.c_char * 128), ("arch", C.c_char * 64)]
+
+
+# status codes (bt709hip_status)
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_NOT_SETUP = -2
+ERR_SIZE_MISMATCH = -3
+ERR_ODD_DIMENSIONS = -4
+ERR_MATRIX = -5
+ERR_TRANSFER = -6
+ERR_ALPHA_TRANSFER = -7
+ERR_STRIDE = -8
+ERR_HIP = -9
+ERR_NO_DEVICE = -10
+ERR_UNSUPPORTED = -11
+
+MAX_BATCH = 32
+
+# every symbol include/bt709hip.h declares: name -> (restype, argtypes)
+_P, _I, _Z = C.c_void_p, C.c_int, C.c_size_t
+_FP, _SP = C.POINTER(Frame), C.POINTER(Surface)
+SYMBOLS = {
+    "bt709hip_device_count": (_I, []),
+    "bt709hip_context_create": (_I, [_I, c_void_pp]),
+    "bt709hip_context_destroy": (_I, [_P]),
+    "bt709hip_context_info": (_I, [_P, C.POINTER(DeviceInfo)]),
+    "bt709hip_stream_create": (_I, [_P, c_void_pp]),
+    "bt709hip_stream_destroy": (_I, [_P, _P]),
+    "bt709hip_stream_synchronize": (_I, [_P, _P]),
+    "bt709hip_event_create": (_I, [_P, c_void_pp]),
+    "bt709hip_event_destroy": (_I, [_P, _P]),
+    "bt709hip_event_record": (_I, [_P, _P, _P]),
+    "bt709hip_event_synchronize": (_I, [_P, _P]),
+    "bt709hip_event_elapsed_ms": (_I, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "bt709hip_malloc": (_I, [_P, _Z, c_void_pp]),
+    "bt709hip_free": (_I, [_P, _P]),
+    "bt709hip_host_alloc": (_I, [_P, _Z, c_void_pp]),
+    "bt709hip_host_free": (_I, [_P, _P]),
+    "bt709hip_memset": (_I, [_P, _P, _I, _Z, _P]),
+    "bt709hip_upload": (_I, [_P, _P, _Z, _P, _Z, _Z, _Z, _P]),
+    "bt709hip_download": (_I, [_P, _P, _Z, _P, _Z, _Z, _Z, _P]),
+    "bt709hip_decoder_create": (_I, [_P, _I, _I, c_void_pp]),
+    "bt709hip_decoder_destroy": (_I, [_P]),
+    "bt709hip_decoder_set_context": (_I, [_P, _P]),
+    "bt709hip_decoder_set_alpha_fill": (_I, [_P, _I]),
+    "bt709hip_decoder_get_gamma": (_I, [_P]),
+    "bt709hip_decoder_setup": (_I, [_P]),
+    "bt709hip_decode": (_I, [_P, _FP, _FP, _SP, _I, _I, _P, _I]),
+    "bt709hip_decode_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
+    "bt709hip_decode_half": (_I, [_P, _FP, _SP, _P, _I]),
+    "bt709hip_decode_half_batch": (_I, [_P, _I, _FP, _SP, _P, _I]),
+    "bt709hip_strerror": (C.c_char_p, [_I]),
+    "bt709hip_last_hip_error": (_I, []),
+    "bt709hip_last_hip_error_string": (C.c_char_p, []),
+    "bt709hip_gamma_thresholds": (_I, [_I, C.POINTER(C.c_float)]),
+    "bt709hip_matrix_constants": (_I, [C.POINTER(C.c_float)]),
+    "bt709hip_last_kernel_name": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Return the loaded C-ABI library, building it in-tree first if it is stale and a
+    compiler is present.  Raises (never falls back) when the library is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.is_stale():
+        try:
+            _build.build()
+        except Exception as exc:  # no hipcc here: accept a prebuilt library if one shipped
+            if not os.path.exists(path):
+                raise ImportError("libbt709hip.so is missing and could not be built: %s" % exc)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def strerror(status):
+    return load().bt709hip_strerror(int(status)).decode()
+
+
+class Bt709Error(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = int(status)
+        msg = "%s: %s" % (what, strerror(status)) if what else strerror(status)
+        if self.status == ERR_HIP:
+            msg += " (%s)" % load().bt709hip_last_hip_error_string().decode()
+        super().__init__(msg)
+
+
+def check(status, what=""):
+    if status != OK:
+        raise Bt709Error(status, what)

@@ -1,0 +1,555 @@
+// C-ABI shim (include/bt709hip.h): the thin layer that replaces MetalRenderContext /
+// MetalBT709Decoder's CoreVideo + Metal plumbing with hipMalloc / hipMemcpy2DAsync /
+// HIP streams, and validates a decode call the way -processBT709ToSRGB: does
+// (Renderer/MetalBT709Decoder.m:252-492) before launching the fused kernel.
+//
+// There is no CPU fallback anywhere in this file: without a HIP device every entry
+// point that needs one fails with BT709HIP_ERR_NO_DEVICE / BT709HIP_ERR_HIP.
+#include "../../include/bt709hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "bt709_constants.h"
+#include "bt709_kernels.h"
+#include "transfer_tables.h"
+
+using namespace bt709;
+
+struct bt709hip_context {
+  int device = 0;
+  hipDeviceProp_t props;
+  hipStream_t default_stream = nullptr;
+  int grid_blocks = 0;  // workgroups a launch aims for (all frames together)
+};
+
+struct bt709hip_decoder {
+  bt709hip_context *ctx = nullptr;
+  int gamma = BT709HIP_GAMMA_APPLE;
+  int has_alpha = 0;
+  uint32_t alpha_fill = 0xFF;
+  bool nontemporal = true;
+  std::mutex setup_mutex;
+  bool ready = false;
+  // device copies
+  void *d_table = nullptr;         // TransferBucket[n+1(+pad)]
+  uint32_t table_bytes = 0;
+  uint32_t table_n = 0;
+  void *d_table_linear = nullptr;  // TransferBucketLinear[n+1] (half-scale decode side)
+  uint32_t table_linear_bytes = 0;
+  void *d_encode = nullptr;        // LINEAR-mode TransferBucket[] (half-scale encode side)
+  uint32_t encode_bytes = 0;
+  uint32_t encode_n = 0;
+};
+
+namespace {
+
+thread_local hipError_t tl_hip_error = hipSuccess;
+thread_local const char *tl_kernel_name = "";
+
+int hip_fail(hipError_t e) {
+  tl_hip_error = e;
+  return BT709HIP_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                          \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) return hip_fail(_e); \
+  } while (0)
+
+int bind(const bt709hip_context *ctx) {
+  if (ctx == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return BT709HIP_OK;
+}
+
+hipStream_t pick(const bt709hip_context *ctx, void *stream) {
+  return stream ? static_cast<hipStream_t>(stream) : ctx->default_stream;
+}
+
+bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+int env_int(const char *name, int fallback) {
+  const char *v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : fallback;
+}
+
+// transfer tag the configured gamma insists on (MetalBT709Decoder.m:335-353)
+int required_transfer(int gamma) {
+  switch (gamma) {
+    case BT709HIP_GAMMA_SRGB: return BT709HIP_TRANSFER_SRGB;
+    case BT709HIP_GAMMA_LINEAR: return BT709HIP_TRANSFER_LINEAR;
+    default: return BT709HIP_TRANSFER_ITU_R_709_2;  // APPLE and the ITU709 extension
+  }
+}
+
+// Validation of one frame/alpha/surface triple in the reference's order
+// (MetalBT709Decoder.m:265-368), then the checks the texture wrappers imply.
+int validate(const bt709hip_decoder *dec, const bt709hip_frame *f, const bt709hip_frame *a,
+             const bt709hip_surface *o, int out_w, int out_h, int render_w, int render_h) {
+  if (f == nullptr || o == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (f->width < 0 || f->height < 0) return BT709HIP_ERR_INVALID_ARG;
+  if (o->width != out_w || o->height != out_h) return BT709HIP_ERR_SIZE_MISMATCH;          // .m:272-282
+  if (render_w != out_w || render_h != out_h) return BT709HIP_ERR_SIZE_MISMATCH;            // .m:284-290
+  if (a != nullptr && (a->width != f->width || a->height != f->height)) return BT709HIP_ERR_SIZE_MISMATCH;  // .m:294-306
+  if (f->matrix != BT709HIP_MATRIX_ITU_R_709_2) return BT709HIP_ERR_MATRIX;                // .m:311-318
+  if (f->transfer != required_transfer(dec->gamma)) return BT709HIP_ERR_TRANSFER;          // .m:320-353
+  if (a != nullptr && a->transfer != BT709HIP_TRANSFER_LINEAR) return BT709HIP_ERR_ALPHA_TRANSFER;  // .m:357-368
+  if ((f->width & 1) || (f->height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;
+  if (dec->has_alpha && a == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (f->width == 0 || f->height == 0) return BT709HIP_OK;
+  if (f->y == nullptr || f->cbcr == nullptr || o->bgra == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (dec->has_alpha && a->y == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (f->y_stride < static_cast<size_t>(f->width) || f->cbcr_stride < static_cast<size_t>(f->width))
+    return BT709HIP_ERR_STRIDE;
+  if (dec->has_alpha && a->y_stride < static_cast<size_t>(a->width)) return BT709HIP_ERR_STRIDE;
+  if (o->stride < static_cast<size_t>(out_w) * 4 || (o->stride & 3) || !aligned(o->bgra, 4))
+    return BT709HIP_ERR_STRIDE;
+  if (f->y_stride > 0xffffffffu || f->cbcr_stride > 0xffffffffu || o->stride > 0xffffffffu)
+    return BT709HIP_ERR_STRIDE;
+  return BT709HIP_OK;
+}
+
+int upload_table(const void *src, size_t bytes, void **dst) {
+  HIP_TRY(hipMalloc(dst, bytes));
+  HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return BT709HIP_OK;
+}
+
+uint32_t grid_x_for(const bt709hip_context *ctx, uint32_t rows, int frames) {
+  uint32_t per_frame = static_cast<uint32_t>(ctx->grid_blocks / (frames > 0 ? frames : 1));
+  if (per_frame < 1) per_frame = 1;
+  return rows < per_frame ? rows : per_frame;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ context
+
+int bt709hip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    tl_hip_error = e;
+    return e == hipErrorNoDevice ? 0 : BT709HIP_ERR_HIP;
+  }
+  return n;
+}
+
+int bt709hip_context_create(int device_ordinal, bt709hip_context **out) {
+  if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    tl_hip_error = e;
+    return BT709HIP_ERR_NO_DEVICE;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n) return BT709HIP_ERR_NO_DEVICE;
+  bt709hip_context *ctx = new (std::nothrow) bt709hip_context();
+  if (ctx == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  ctx->device = device_ordinal;
+  e = hipSetDevice(device_ordinal);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->props, device_ordinal);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->default_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = prepare_kernels();
+  if (e != hipSuccess) {
+    delete ctx;
+    return hip_fail(e);
+  }
+  // Workgroups per launch: enough to fill every CU at 8 resident blocks, times a
+  // small factor so the tail is short; row pairs are grid-strided beyond that.
+  ctx->grid_blocks = ctx->props.multiProcessorCount * 8 * env_int("BT709HIP_GRID_MULT", 2);
+  *out = ctx;
+  return BT709HIP_OK;
+}
+
+int bt709hip_context_destroy(bt709hip_context *ctx) {
+  if (ctx == nullptr) return BT709HIP_OK;
+  if (hipSetDevice(ctx->device) == hipSuccess && ctx->default_stream) {
+    (void)hipStreamSynchronize(ctx->default_stream);
+    (void)hipStreamDestroy(ctx->default_stream);
+  }
+  delete ctx;
+  return BT709HIP_OK;
+}
+
+int bt709hip_context_info(const bt709hip_context *ctx, bt709hip_device_info *info) {
+  if (ctx == nullptr || info == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  std::memset(info, 0, sizeof *info);
+  info->device_ordinal = ctx->device;
+  info->compute_units = ctx->props.multiProcessorCount;
+  info->wavefront_size = ctx->props.warpSize;
+  info->lds_bytes_per_block = static_cast<int32_t>(ctx->props.sharedMemPerBlock);
+  info->memory_clock_khz = ctx->props.memoryClockRate;
+  info->memory_bus_width_bits = ctx->props.memoryBusWidth;
+  info->l2_bytes = ctx->props.l2CacheSize;
+  info->clock_khz = ctx->props.clockRate;
+  info->total_memory_bytes = ctx->props.totalGlobalMem;
+  std::snprintf(info->name, sizeof info->name, "%s", ctx->props.name);
+  std::snprintf(info->arch, sizeof info->arch, "%s", ctx->props.gcnArchName);
+  return BT709HIP_OK;
+}
+
+int bt709hip_stream_create(bt709hip_context *ctx, void **stream) {
+  if (stream == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return BT709HIP_OK;
+}
+
+int bt709hip_stream_destroy(bt709hip_context *ctx, void *stream) {
+  if (stream == nullptr) return BT709HIP_OK;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_stream_synchronize(bt709hip_context *ctx, void *stream) {
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipStreamSynchronize(pick(ctx, stream)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_event_create(bt709hip_context *ctx, void **event) {
+  if (event == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  hipEvent_t ev = nullptr;
+  HIP_TRY(hipEventCreate(&ev));
+  *event = ev;
+  return BT709HIP_OK;
+}
+
+int bt709hip_event_destroy(bt709hip_context *ctx, void *event) {
+  if (event == nullptr) return BT709HIP_OK;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_event_record(bt709hip_context *ctx, void *event, void *stream) {
+  if (event == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), pick(ctx, stream)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_event_synchronize(bt709hip_context *ctx, void *event) {
+  if (event == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_event_elapsed_ms(bt709hip_context *ctx, void *start, void *stop, float *ms) {
+  if (start == nullptr || stop == nullptr || ms == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_malloc(bt709hip_context *ctx, size_t bytes, void **dptr) {
+  if (dptr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *dptr = nullptr;
+  if (int rc = bind(ctx)) return rc;
+  if (bytes == 0) return BT709HIP_OK;
+  HIP_TRY(hipMalloc(dptr, bytes));
+  return BT709HIP_OK;
+}
+
+int bt709hip_free(bt709hip_context *ctx, void *dptr) {
+  if (dptr == nullptr) return BT709HIP_OK;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipFree(dptr));
+  return BT709HIP_OK;
+}
+
+int bt709hip_host_alloc(bt709hip_context *ctx, size_t bytes, void **hptr) {
+  if (hptr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *hptr = nullptr;
+  if (int rc = bind(ctx)) return rc;
+  if (bytes == 0) return BT709HIP_OK;
+  HIP_TRY(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+  return BT709HIP_OK;
+}
+
+int bt709hip_host_free(bt709hip_context *ctx, void *hptr) {
+  if (hptr == nullptr) return BT709HIP_OK;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipHostFree(hptr));
+  return BT709HIP_OK;
+}
+
+int bt709hip_memset(bt709hip_context *ctx, void *dptr, int value, size_t bytes, void *stream) {
+  if (int rc = bind(ctx)) return rc;
+  if (bytes == 0) return BT709HIP_OK;
+  if (dptr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  HIP_TRY(hipMemsetAsync(dptr, value, bytes, pick(ctx, stream)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_upload(bt709hip_context *ctx, void *dst_dev, size_t dst_pitch, const void *src_host,
+                    size_t src_pitch, size_t row_bytes, size_t rows, void *stream) {
+  if (int rc = bind(ctx)) return rc;
+  if (row_bytes == 0 || rows == 0) return BT709HIP_OK;
+  if (dst_dev == nullptr || src_host == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (dst_pitch < row_bytes || src_pitch < row_bytes) return BT709HIP_ERR_STRIDE;
+  HIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_host, src_pitch, row_bytes, rows, hipMemcpyHostToDevice,
+                           pick(ctx, stream)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_download(bt709hip_context *ctx, void *dst_host, size_t dst_pitch, const void *src_dev,
+                      size_t src_pitch, size_t row_bytes, size_t rows, void *stream) {
+  if (int rc = bind(ctx)) return rc;
+  if (row_bytes == 0 || rows == 0) return BT709HIP_OK;
+  if (dst_host == nullptr || src_dev == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (dst_pitch < row_bytes || src_pitch < row_bytes) return BT709HIP_ERR_STRIDE;
+  HIP_TRY(hipMemcpy2DAsync(dst_host, dst_pitch, src_dev, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost,
+                           pick(ctx, stream)));
+  return BT709HIP_OK;
+}
+
+// ------------------------------------------------------------------ decoder
+
+int bt709hip_decoder_create(bt709hip_context *ctx, int gamma, int has_alpha, bt709hip_decoder **out) {
+  if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (gamma < 0 || gamma >= kGammaCount) return BT709HIP_ERR_INVALID_ARG;
+  bt709hip_decoder *dec = new (std::nothrow) bt709hip_decoder();
+  if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  dec->ctx = ctx;
+  dec->has_alpha = has_alpha ? 1 : 0;
+  // RGBA render supports only the sRGB gamma function (MetalBT709Decoder.m:165-169)
+  dec->gamma = has_alpha ? BT709HIP_GAMMA_SRGB : gamma;
+  dec->nontemporal = env_int("BT709HIP_NONTEMPORAL", 1) != 0;
+  *out = dec;
+  return BT709HIP_OK;
+}
+
+int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
+  if (dec == nullptr) return BT709HIP_OK;
+  if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) {
+    if (dec->d_table) (void)hipFree(dec->d_table);
+    if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
+    if (dec->d_encode) (void)hipFree(dec->d_encode);
+  }
+  delete dec;
+  return BT709HIP_OK;
+}
+
+int bt709hip_decoder_set_context(bt709hip_decoder *dec, bt709hip_context *ctx) {
+  if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(dec->setup_mutex);
+  if (dec->ready) return dec->ctx == ctx ? BT709HIP_OK : BT709HIP_ERR_INVALID_ARG;
+  dec->ctx = ctx;
+  return BT709HIP_OK;
+}
+
+int bt709hip_decoder_set_alpha_fill(bt709hip_decoder *dec, int alpha_byte) {
+  if (dec == nullptr || alpha_byte < 0 || alpha_byte > 255) return BT709HIP_ERR_INVALID_ARG;
+  dec->alpha_fill = static_cast<uint32_t>(alpha_byte);
+  return BT709HIP_OK;
+}
+
+int bt709hip_decoder_get_gamma(const bt709hip_decoder *dec) {
+  return dec ? dec->gamma : BT709HIP_ERR_INVALID_ARG;
+}
+
+int bt709hip_decoder_setup(bt709hip_decoder *dec) {
+  if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(dec->setup_mutex);
+  if (dec->ctx == nullptr) return BT709HIP_ERR_NOT_SETUP;  // MetalBT709Decoder.m:48-54
+  if (dec->ready) return BT709HIP_OK;                      // second call is a nop (.m:66-70)
+  if (int rc = bind(dec->ctx)) return rc;
+
+  TransferTable t, enc;
+  if (!build_transfer_table(dec->gamma, &t) || !build_transfer_table(kGammaLinear, &enc))
+    return BT709HIP_ERR_UNSUPPORTED;
+  dec->table_n = t.n;
+  dec->table_bytes = static_cast<uint32_t>(t.buckets.size() * sizeof(TransferBucket));
+  dec->table_linear_bytes = static_cast<uint32_t>(t.buckets_linear.size() * sizeof(TransferBucketLinear));
+  dec->encode_n = enc.n;
+  dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
+  if (int rc = upload_table(t.buckets.data(), dec->table_bytes, &dec->d_table)) return rc;
+  if (int rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &dec->d_table_linear)) return rc;
+  if (int rc = upload_table(enc.buckets.data(), dec->encode_bytes, &dec->d_encode)) return rc;
+  dec->ready = true;
+  return BT709HIP_OK;
+}
+
+int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
+                          const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
+                          int wait_until_completed) {
+  if (dec == nullptr || frames == nullptr || outs == nullptr || count < 0) return BT709HIP_ERR_INVALID_ARG;
+  if (count > kMaxBatch) return BT709HIP_ERR_UNSUPPORTED;
+  if (int rc = bt709hip_decoder_setup(dec)) return rc;  // -decodeBT709 calls -setupMetal first (.m:228-231)
+  if (count == 0) return BT709HIP_OK;
+  if (int rc = bind(dec->ctx)) return rc;
+
+  const bt709hip_frame &f0 = frames[0];
+  const bt709hip_surface &o0 = outs[0];
+  DecodeParams p;
+  std::memset(&p, 0, sizeof p);
+  bool fast = (f0.width % 4) == 0 && (f0.y_stride % 4) == 0 && (f0.cbcr_stride % 4) == 0 && (o0.stride % 16) == 0;
+  for (int i = 0; i < count; ++i) {
+    const bt709hip_frame *a = alphas ? &alphas[i] : nullptr;
+    if (int rc = validate(dec, &frames[i], a, &outs[i], frames[i].width, frames[i].height, outs[i].width,
+                          outs[i].height))
+      return rc;
+    if (frames[i].width != f0.width || frames[i].height != f0.height || frames[i].y_stride != f0.y_stride ||
+        frames[i].cbcr_stride != f0.cbcr_stride || outs[i].stride != o0.stride)
+      return BT709HIP_ERR_SIZE_MISMATCH;
+    if (dec->has_alpha && a->y_stride != alphas[0].y_stride) return BT709HIP_ERR_SIZE_MISMATCH;
+    p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
+    p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
+    p.frames[i].alpha = dec->has_alpha ? static_cast<const uint8_t *>(a->y) : nullptr;
+    p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
+    fast = fast && aligned(frames[i].y, 4) && aligned(frames[i].cbcr, 4) && aligned(outs[i].bgra, 16);
+    if (dec->has_alpha) fast = fast && aligned(a->y, 4) && (a->y_stride % 4) == 0;
+  }
+  if (f0.width == 0 || f0.height == 0) return BT709HIP_OK;
+
+  p.table = dec->d_table;
+  p.table_bytes = dec->table_bytes;
+  p.table_scale = static_cast<float>(dec->table_n);
+  p.width = static_cast<uint32_t>(f0.width);
+  p.height = static_cast<uint32_t>(f0.height);
+  p.y_stride = static_cast<uint32_t>(f0.y_stride);
+  p.cbcr_stride = static_cast<uint32_t>(f0.cbcr_stride);
+  p.alpha_stride = dec->has_alpha ? static_cast<uint32_t>(alphas[0].y_stride) : 0;
+  p.out_stride = static_cast<uint32_t>(o0.stride);
+  p.alpha_word = dec->alpha_fill << 24;
+
+  hipStream_t s = pick(dec->ctx, stream);
+  const uint32_t gx = grid_x_for(dec->ctx, p.height / 2, count);
+  tl_kernel_name = launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
+                                 dec->nontemporal, gx, s);
+  HIP_TRY(hipGetLastError());
+  if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));  // .m:486-489
+  return BT709HIP_OK;
+}
+
+int bt709hip_decode(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_frame *alpha,
+                    const bt709hip_surface *out, int render_width, int render_height, void *stream,
+                    int wait_until_completed) {
+  if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bt709hip_decoder_setup(dec)) return rc;
+  // render size is a property of this call only; check it here, the rest in the batch path
+  if (int rc = validate(dec, frame, alpha, out, frame ? frame->width : 0, frame ? frame->height : 0, render_width,
+                        render_height))
+    return rc;
+  return bt709hip_decode_batch(dec, 1, frame, alpha, out, stream, wait_until_completed);
+}
+
+int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
+                               const bt709hip_surface *outs, void *stream, int wait_until_completed) {
+  if (dec == nullptr || frames == nullptr || outs == nullptr || count < 0) return BT709HIP_ERR_INVALID_ARG;
+  if (count > kMaxBatch) return BT709HIP_ERR_UNSUPPORTED;
+  if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;
+  if (int rc = bt709hip_decoder_setup(dec)) return rc;
+  if (count == 0) return BT709HIP_OK;
+  if (int rc = bind(dec->ctx)) return rc;
+
+  const bt709hip_frame &f0 = frames[0];
+  const bt709hip_surface &o0 = outs[0];
+  DecodeParams p;
+  std::memset(&p, 0, sizeof p);
+  bool wide = (f0.width % 8) == 0 && (f0.y_stride % 8) == 0 && (f0.cbcr_stride % 8) == 0 && (o0.stride % 16) == 0;
+  for (int i = 0; i < count; ++i) {
+    if ((frames[i].width & 3) || (frames[i].height & 3)) return BT709HIP_ERR_ODD_DIMENSIONS;
+    if (int rc = validate(dec, &frames[i], nullptr, &outs[i], frames[i].width / 2, frames[i].height / 2,
+                          outs[i].width, outs[i].height))
+      return rc;
+    if (frames[i].width != f0.width || frames[i].height != f0.height || frames[i].y_stride != f0.y_stride ||
+        frames[i].cbcr_stride != f0.cbcr_stride || outs[i].stride != o0.stride)
+      return BT709HIP_ERR_SIZE_MISMATCH;
+    p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
+    p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
+    p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
+    wide = wide && aligned(frames[i].y, 8) && aligned(frames[i].cbcr, 8) && aligned(outs[i].bgra, 16);
+  }
+  if (f0.width == 0 || f0.height == 0) return BT709HIP_OK;
+
+  p.table = dec->d_table_linear;
+  p.table_bytes = dec->table_linear_bytes;
+  p.table_scale = static_cast<float>(dec->table_n);
+  p.table2 = dec->d_encode;
+  p.table2_bytes = dec->encode_bytes;
+  p.table2_scale = static_cast<float>(dec->encode_n);
+  p.width = static_cast<uint32_t>(f0.width);
+  p.height = static_cast<uint32_t>(f0.height);
+  p.y_stride = static_cast<uint32_t>(f0.y_stride);
+  p.cbcr_stride = static_cast<uint32_t>(f0.cbcr_stride);
+  p.out_stride = static_cast<uint32_t>(o0.stride);
+  p.alpha_word = dec->alpha_fill << 24;
+
+  hipStream_t s = pick(dec->ctx, stream);
+  const uint32_t gx = grid_x_for(dec->ctx, p.height / 2, count);
+  tl_kernel_name = launch_decode_half(p, count, wide, dec->nontemporal, gx, s);
+  HIP_TRY(hipGetLastError());
+  if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
+  return BT709HIP_OK;
+}
+
+int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
+                         void *stream, int wait_until_completed) {
+  return bt709hip_decode_half_batch(dec, 1, frame, out, stream, wait_until_completed);
+}
+
+// -------------------------------------------------------------- diagnostics
+
+const char *bt709hip_strerror(int status) {
+  switch (status) {
+    case BT709HIP_OK: return "ok";
+    case BT709HIP_ERR_INVALID_ARG: return "invalid argument";
+    case BT709HIP_ERR_NOT_SETUP: return "decoder has no render context (setup failed)";
+    case BT709HIP_ERR_SIZE_MISMATCH: return "size mismatch between BT709 input, output surface, render size or alpha";
+    case BT709HIP_ERR_ODD_DIMENSIONS: return "width and height must be even (multiples of 4 for half-scale)";
+    case BT709HIP_ERR_MATRIX: return "unsupported YCbCrMatrix, only BT.709 matrix is supported";
+    case BT709HIP_ERR_TRANSFER: return "TransferFunction tag does not match the decoder's gamma";
+    case BT709HIP_ERR_ALPHA_TRANSFER: return "alpha pixel buffer TransferFunction must be linear";
+    case BT709HIP_ERR_STRIDE: return "stride smaller than a row or misaligned output";
+    case BT709HIP_ERR_HIP: return "HIP runtime error";
+    case BT709HIP_ERR_NO_DEVICE: return "no such HIP device";
+    case BT709HIP_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}
+
+int bt709hip_last_hip_error(void) { return static_cast<int>(tl_hip_error); }
+const char *bt709hip_last_hip_error_string(void) { return hipGetErrorString(tl_hip_error); }
+const char *bt709hip_last_kernel_name(void) { return tl_kernel_name; }
+
+int bt709hip_gamma_thresholds(int gamma, float thresholds[255]) {
+  if (thresholds == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  TransferTable t;
+  if (!build_transfer_table(gamma, &t)) return BT709HIP_ERR_INVALID_ARG;
+  std::memcpy(thresholds, t.thresholds, sizeof t.thresholds);
+  return BT709HIP_OK;
+}
+
+int bt709hip_matrix_constants(float c[8]) {
+  if (c == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  c[0] = kInv255;
+  c[1] = kMY;
+  c[2] = kMCrR;
+  c[3] = kMCbG;
+  c[4] = kMCrG;
+  c[5] = kMCbB;
+  c[6] = 16.0f;
+  c[7] = 128.0f;
+  return BT709HIP_OK;
+}
+
+}  // extern "C"

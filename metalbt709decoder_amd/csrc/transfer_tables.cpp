@@ -1,0 +1,135 @@
+// See transfer_tables.h.  Host code; runs once per decoder in -setupMetal's place.
+//
+// C++ note: every pow() below is called on explicit doubles.  The reference is C,
+// where pow(float,float) IS the double function (sRGB.h:54,70; BT709.h:77,133);
+// in C++ the same spelling would pick the float overload and change results.
+#include "transfer_tables.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace bt709 {
+
+float srgb_to_linear(float v) {
+  if (v <= 0.04045f) return v * (1.0f / 12.92f);
+  const float a = 0.055f;
+  const float gamma = 2.4f;
+  const float base = (v + a) * (1.0f / (1.0f + a));
+  return static_cast<float>(std::pow(static_cast<double>(base), static_cast<double>(gamma)));
+}
+
+float linear_to_srgb(float v) {
+  if (v <= 0.0031308f) return v * 12.92f;
+  const float a = 0.055f;
+  const float gamma = 1.0f / 2.4f;
+  // whole expression in double, narrowed once (sRGB.h:70)
+  const double r = static_cast<double>(1.0f + a) *
+                       std::pow(static_cast<double>(v), static_cast<double>(gamma)) -
+                   static_cast<double>(a);
+  return static_cast<float>(r);
+}
+
+float itu709_to_linear(float v) {
+  if (v < 0.081f) return v * (1.0f / 4.5f);
+  const float a = 0.099f;
+  const float gamma = 1.0f / 0.45f;
+  const float base = (v + a) * (1.0f / (1.0f + a));
+  return static_cast<float>(std::pow(static_cast<double>(base), static_cast<double>(gamma)));
+}
+
+float apple196_to_linear(float v) {
+  const float x_intercept = 0.05583828f;
+  if (v < x_intercept) return v * (1.0f / 16.0f);
+  const float gamma = 1.960938f;  // APPLE_GAMMA_196, BT709.h:122
+  return static_cast<float>(std::pow(static_cast<double>(v), static_cast<double>(gamma)));
+}
+
+int quantize_byte(float v) {
+  const float scaled = v * 255.0f;  // float multiply first
+  return static_cast<int>(std::round(static_cast<double>(scaled)));
+}
+
+int transfer_to_byte(int gamma, float v) {
+  switch (gamma) {
+    case kGammaApple:
+      return quantize_byte(linear_to_srgb(apple196_to_linear(v)));
+    case kGammaSRGB:  // sRGB_to_sRGB_convertYCbCrToRGB applies no curve (BT709.h:977-983)
+      return quantize_byte(v);
+    case kGammaLinear:  // BT709_from_linear(v, Srgb), BT709.h:1156-1166
+      return quantize_byte(linear_to_srgb(v));
+    case kGammaITU709:
+      return quantize_byte(linear_to_srgb(itu709_to_linear(v)));
+    default:
+      return -1;
+  }
+}
+
+namespace {
+
+float from_bits(uint32_t u) {
+  float f;
+  std::memcpy(&f, &u, sizeof f);
+  return f;
+}
+
+// smallest float in [0,1] mapped to >= k; monotonicity makes bisection on the bit
+// pattern valid (non-negative floats order like their bit patterns)
+float find_threshold(int gamma, int k) {
+  uint32_t lo = 0, hi = 0x3f800000u;
+  if (transfer_to_byte(gamma, from_bits(hi)) < k) return std::numeric_limits<float>::infinity();
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (transfer_to_byte(gamma, from_bits(mid)) >= k) hi = mid;
+    else lo = mid + 1;
+  }
+  return from_bits(lo);
+}
+
+}  // namespace
+
+bool build_transfer_table(int gamma, TransferTable *out) {
+  if (gamma < 0 || gamma >= kGammaCount || out == nullptr) return false;
+  out->gamma = gamma;
+  for (int k = 1; k <= 255; ++k) out->thresholds[k - 1] = find_threshold(gamma, k);
+
+  float lin_of_byte[257];
+  for (int b = 0; b < 256; ++b) lin_of_byte[b] = srgb_to_linear(b * (1.0f / 255.0f));
+  lin_of_byte[256] = lin_of_byte[255];
+
+  const float inf = std::numeric_limits<float>::infinity();
+  for (uint32_t n = 256; n <= 65536; n *= 2) {
+    std::vector<TransferBucket> b(n + 1);
+    bool ok = true;
+    int k = 0;  // thresholds <= current bucket start
+    for (uint32_t q = 0; q <= n && ok; ++q) {
+      const float lo = static_cast<float>(q) / static_cast<float>(n);  // exact
+      const float hi = static_cast<float>(q + 1) / static_cast<float>(n);
+      while (k < 255 && out->thresholds[k] <= lo) ++k;
+      b[q].base = static_cast<uint32_t>(k);
+      b[q].edge = inf;
+      if (k < 255 && out->thresholds[k] < hi) {
+        b[q].edge = out->thresholds[k];
+        // a second threshold inside the same bucket would be lost
+        if (k + 1 < 255 && out->thresholds[k + 1] < hi) ok = false;
+      }
+    }
+    if (!ok) continue;
+    out->n = n;
+    // pad so the device copy can be moved with 16-byte loads
+    while ((b.size() * sizeof(TransferBucket)) % 16 != 0) b.push_back(TransferBucket{inf, 255u});
+    out->buckets = b;
+    out->buckets_linear.resize(n + 1);
+    for (uint32_t q = 0; q <= n; ++q) {
+      TransferBucketLinear &e = out->buckets_linear[q];
+      e.edge = b[q].edge;
+      e.base = b[q].base;
+      e.lin_below = lin_of_byte[b[q].base];
+      e.lin_above = lin_of_byte[b[q].base + 1];
+    }
+    return true;
+  }
+  return false;
+}
+
+}  // namespace bt709

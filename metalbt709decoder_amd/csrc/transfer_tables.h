@@ -1,0 +1,63 @@
+// Host-side builder of the exact per-gamma transfer tables the kernels look up.
+//
+// The reference applies, per channel, after matrix+saturate:
+//     video curve -> linear      (float in, libm double pow inside)
+//     linear      -> sRGB        (same)
+//     (int)round(v * 255.0f)
+// (Renderer/BT709.h:856-883 for the default Apple mode).  No GPU pow reproduces
+// libm's correctly rounded double pow bit for bit, and none is needed: each such
+// composite is a monotone step function of the float in [0,1] (checked for all
+// 1 065 353 217 inputs by tests/test_oracle_golden.py), so it is fully described
+// by 255 thresholds.  The kernel wants O(1) lookup, so the thresholds are laid
+// out in N uniform buckets, N a power of two chosen so no bucket holds two
+// thresholds:
+//     byte(x) = bucket[q].base + (x >= bucket[q].edge),   q = (uint)(x * N)
+// x*N is exact (power of two), so q is exact.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace bt709 {
+
+enum Gamma : int { kGammaApple = 0, kGammaSRGB = 1, kGammaLinear = 2, kGammaITU709 = 3, kGammaCount = 4 };
+
+// One bucket.  `edge` is the single threshold strictly inside the bucket or +inf.
+struct alignas(8) TransferBucket {
+  float edge;
+  uint32_t base;
+};
+
+// Bucket for the fused 2:1 rescale: the decoded byte is never materialised, the
+// lookup returns it already linearised (sampler-side sRGB decode of an sRGB8 texel:
+// sRGB_nonLinearNormToLinear(byteNorm(b)), Renderer/sRGB.h:32-57).
+struct alignas(16) TransferBucketLinear {
+  float edge;
+  float lin_below;  // linear value of byte `base`
+  float lin_above;  // linear value of byte `base + 1`
+  uint32_t base;
+};
+
+struct TransferTable {
+  int gamma = 0;
+  uint32_t n = 0;                        // bucket count N (power of two); table has N + 1 entries
+  float thresholds[255];                 // t[k-1] = min { x in [0,1] : byte(x) >= k }
+  std::vector<TransferBucket> buckets;   // N + 1 (+ padding to a 16-byte multiple)
+  std::vector<TransferBucketLinear> buckets_linear;  // same buckets, linearised outputs
+};
+
+// Scalar transfer functions, float in / float out, C semantics of the reference.
+float srgb_to_linear(float v);      // Renderer/sRGB.h:43-57
+float linear_to_srgb(float v);      // Renderer/sRGB.h:62-74
+float itu709_to_linear(float v);    // Renderer/BT709.h:68-81
+float apple196_to_linear(float v);  // Renderer/BT709.h:125-137
+int quantize_byte(float v);         // (int)round(v * 255.0f), Renderer/BT709.h:881-883
+
+// Per-channel composite of one gamma mode.
+int transfer_to_byte(int gamma, float v);
+
+// Builds thresholds + buckets.  Returns false if gamma is unknown or the
+// single-threshold-per-bucket property cannot be met with N <= 65536.
+bool build_transfer_table(int gamma, TransferTable *out);
+
+}  // namespace bt709

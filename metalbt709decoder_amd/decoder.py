@@ -1,0 +1,368 @@
+"""Host-side mirror of the reference's decode operator, over the C ABI.
+
+The reference's host side is Objective-C (no ObjC runtime, Foundation, CoreVideo or
+Metal exists on this platform), so the classes below keep the reference's names,
+property names, argument meaning and BOOL/nil error behaviour in Python so that the
+parity tests read like EmptyiOSTests/MetalBT709DecoderTests.m:189-277:
+
+    MetalRenderContext   Renderer/MetalRenderContext.h:17-105
+    MetalBT709Decoder    Renderer/MetalBT709Decoder.h:15-72
+    CVPixelBuffer        the 420v buffer + colour attachments the decoder reads
+                         (BGRAToBT709Converter.m:412-494)
+    BGRAToBT709Converter only its buffer helpers: createCoreVideoYCbCrBuffer,
+                         setBT709Attributes, copyBT709ToCoreVideo (plumbing; the
+                         colour math of that class is CPU code and is NOT here)
+
+Everything that touches pixels runs on the GPU through libbt709hip.so; there is no
+CPU implementation of the decode in this package.
+"""
+import ctypes as C
+import logging
+
+import numpy as np
+
+from . import _capi
+from ._capi import Frame, Surface
+
+log = logging.getLogger("metalbt709decoder_amd")
+
+# MetalBT709Gamma (MetalBT709Decoder.h:15-19) + the ITU extension
+MetalBT709GammaApple = 0
+MetalBT709GammaSRGB = 1
+MetalBT709GammaLinear = 2
+MetalBT709GammaITU709 = 3
+
+# kCVImageBufferYCbCrMatrixKey / kCVImageBufferTransferFunctionKey values
+kCVImageBufferYCbCrMatrix_ITU_R_709_2 = 1
+kCVImageBufferYCbCrMatrix_ITU_R_601_4 = 2
+kCVImageBufferYCbCrMatrix_SMPTE_240M_1995 = 3
+kCVImageBufferTransferFunction_ITU_R_709_2 = 1
+kCVImageBufferTransferFunction_sRGB = 2
+kCVImageBufferTransferFunction_Linear = 3
+
+MTLPixelFormatBGRA8Unorm_sRGB = 81  # the only render target format the HIP path writes
+
+
+def _align_up(v, a):
+    return (v + a - 1) // a * a
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes owned through the context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        _capi.check(ctx.lib.bt709hip_malloc(ctx.handle, self.nbytes, C.byref(p)), "bt709hip_malloc")
+        self.ptr = p.value or 0
+
+    def free(self):
+        if self.ptr and self.ctx.handle:
+            self.ctx.lib.bt709hip_free(self.ctx.handle, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CommandBuffer:
+    """One in-flight unit of work = one HIP stream (MTLCommandBuffer's role)."""
+
+    def __init__(self, ctx, stream=None, owned=False):
+        self.ctx, self.stream, self.owned = ctx, stream, owned
+        self.label = ""
+
+    def commit(self):  # work is enqueued eagerly; nothing to flush
+        return None
+
+    def waitUntilCompleted(self):
+        _capi.check(self.ctx.lib.bt709hip_stream_synchronize(self.ctx.handle, self.stream), "stream sync")
+
+    def release(self):
+        if self.owned and self.stream:
+            self.ctx.lib.bt709hip_stream_destroy(self.ctx.handle, self.stream)
+            self.stream = None
+
+
+class CommandQueue:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def commandBuffer(self, new_stream=False):
+        """Default: the context's stream.  new_stream=True gives the frame a stream of
+        its own (north-star: one HIP stream per in-flight frame)."""
+        if not new_stream:
+            return CommandBuffer(self.ctx, None)
+        s = C.c_void_p()
+        _capi.check(self.ctx.lib.bt709hip_stream_create(self.ctx.handle, C.byref(s)), "stream create")
+        return CommandBuffer(self.ctx, s.value, owned=True)
+
+
+class BGRATexture:
+    """8-bit BGRA sRGB render target in device memory (id<MTLTexture> BGRA8Unorm_sRGB)."""
+
+    def __init__(self, ctx, width, height, stride=None, ptr=None):
+        self.ctx, self.width, self.height = ctx, int(width), int(height)
+        self.stride = int(stride) if stride else _align_up(self.width * 4, 16)
+        self._buf = None
+        if ptr is None:
+            self._buf = DeviceBuffer(ctx, max(self.stride * self.height, 16))
+            ptr = self._buf.ptr
+        self.ptr = ptr
+
+    def surface(self):
+        return Surface(self.ptr, self.stride, self.width, self.height)
+
+
+class CVPixelBuffer:
+    """kCVPixelFormatType_420YpCbCr8BiPlanarVideoRange buffer in device memory plus the
+    attachments -processBT709ToSRGB: validates (MetalBT709Decoder.m:311-368)."""
+
+    def __init__(self, ctx, width, height, y_stride=None, cbcr_stride=None, planes=None):
+        self.ctx, self.width, self.height = ctx, int(width), int(height)
+        self.y_stride = int(y_stride) if y_stride else _align_up(self.width, 16)
+        self.cbcr_stride = int(cbcr_stride) if cbcr_stride else _align_up(self.width, 16)
+        self.attachments = {}
+        self._buf = None
+        if planes is None:
+            ysz = _align_up(self.y_stride * self.height, 256)
+            csz = self.cbcr_stride * (self.height // 2)
+            self._buf = DeviceBuffer(ctx, max(ysz + csz, 16))
+            self.y_ptr, self.cbcr_ptr = self._buf.ptr, self._buf.ptr + ysz
+        else:
+            self.y_ptr, self.cbcr_ptr = planes
+
+    # CVBufferGetAttachment / CVBufferSetAttachment
+    def setAttachment(self, key, value):
+        self.attachments[key] = value
+
+    def getAttachment(self, key):
+        return self.attachments.get(key, 0)
+
+    def frame(self):
+        return Frame(self.y_ptr, self.y_stride, self.cbcr_ptr, self.cbcr_stride, self.width, self.height,
+                     self.getAttachment("YCbCrMatrix"), self.getAttachment("TransferFunction"))
+
+    # plane upload/download (CVPixelBufferLockBaseAddress + memcpy in the reference)
+    def upload_planes(self, y, cbcr, commandBuffer=None):
+        y = np.ascontiguousarray(y, dtype=np.uint8)
+        cbcr = np.ascontiguousarray(cbcr, dtype=np.uint8)
+        assert y.shape == (self.height, self.width) and cbcr.shape == (self.height // 2, self.width)
+        self.ctx._upload(self.y_ptr, self.y_stride, y, commandBuffer)
+        self.ctx._upload(self.cbcr_ptr, self.cbcr_stride, cbcr, commandBuffer)
+        self.ctx._sync(commandBuffer)
+
+
+class MetalRenderContext:
+    """Device + queue holder (Renderer/MetalRenderContext.h:17-43)."""
+
+    def __init__(self, device=0):
+        self.device = device  # HIP device ordinal; MTLCreateSystemDefaultDevice() ~ 0
+        self.handle = None
+        self.lib = None
+        self.commandQueue = None
+
+    def setupMetal(self):
+        """Idempotent (MetalRenderContext.m:36-74).  Returns False when there is no GPU."""
+        if self.handle:
+            return True
+        self.lib = _capi.load()
+        h = C.c_void_p()
+        rc = self.lib.bt709hip_context_create(int(self.device), C.byref(h))
+        if rc != _capi.OK:
+            log.error("bt709hip_context_create(%d): %s", self.device, _capi.strerror(rc))
+            return False
+        self.handle = h.value
+        self.commandQueue = CommandQueue(self)
+        return True
+
+    def info(self):
+        info = _capi.DeviceInfo()
+        _capi.check(self.lib.bt709hip_context_info(self.handle, C.byref(info)))
+        return info
+
+    def release(self):
+        if self.handle:
+            self.lib.bt709hip_context_destroy(self.handle)
+            self.handle = None
+
+    # -- texture helpers (MetalRenderContext.h:62-105)
+    def makeBGRATexture(self, size, pixels=None, stride=None):
+        w, h = size
+        tex = BGRATexture(self, w, h, stride)
+        if pixels is not None:
+            self.fillBGRATexture(tex, pixels)
+        else:
+            _capi.check(self.lib.bt709hip_memset(self.handle, tex.ptr, 0, tex.stride * tex.height, None))
+            self._sync(None)
+        return tex
+
+    def fillBGRATexture(self, tex, pixels):
+        a = np.ascontiguousarray(pixels).view(np.uint8).reshape(tex.height, tex.width * 4)
+        self._upload(tex.ptr, tex.stride, a, None)
+        self._sync(None)
+
+    def getBGRATexturePixels(self, tex, commandBuffer=None):
+        """Read-back as an (H, W) uint32 array of (A<<24)|(R<<16)|(G<<8)|B words."""
+        out = np.empty((tex.height, tex.width * 4), dtype=np.uint8)
+        if tex.height and tex.width:
+            stream = commandBuffer.stream if commandBuffer else None
+            _capi.check(self.lib.bt709hip_download(self.handle, out.ctypes.data, out.shape[1], tex.ptr, tex.stride,
+                                                   out.shape[1], tex.height, stream), "download")
+            self._sync(commandBuffer)
+        return out.view(np.uint32).reshape(tex.height, tex.width)
+
+    # -- internals
+    def _upload(self, dptr, dpitch, arr, commandBuffer):
+        if arr.size == 0:
+            return
+        stream = commandBuffer.stream if commandBuffer else None
+        _capi.check(self.lib.bt709hip_upload(self.handle, dptr, dpitch, arr.ctypes.data, arr.shape[1],
+                                             arr.shape[1], arr.shape[0], stream), "upload")
+
+    def _sync(self, commandBuffer):
+        stream = commandBuffer.stream if commandBuffer else None
+        _capi.check(self.lib.bt709hip_stream_synchronize(self.handle, stream), "stream sync")
+
+
+class BGRAToBT709Converter:
+    """Buffer helpers of Renderer/BGRAToBT709Converter.{h,m} that the decode tests use."""
+
+    @staticmethod
+    def createCoreVideoYCbCrBuffer(ctx, size, y_stride=None, cbcr_stride=None):
+        w, h = size  # BGRAToBT709Converter.m:471-494
+        return CVPixelBuffer(ctx, w, h, y_stride, cbcr_stride)
+
+    @staticmethod
+    def setBT709Attributes(buf):
+        buf.setAttachment("YCbCrMatrix", kCVImageBufferYCbCrMatrix_ITU_R_709_2)  # .m:412-451
+        buf.setAttachment("TransferFunction", kCVImageBufferTransferFunction_ITU_R_709_2)
+        return True
+
+    @staticmethod
+    def copyBT709ToCoreVideo(inBT709Pixels, cvPixelBuffer):
+        """Packed (Cr<<16)|(Cb<<8)|Y words -> NV12 planes (BGRAToBT709Converter.m:1042-1099):
+        Y of every pixel; CbCr of every even column, every row writing into row/2, so the
+        odd row's pair is what remains."""
+        w, h = cvPixelBuffer.width, cvPixelBuffer.height
+        p = np.ascontiguousarray(inBT709Pixels, dtype=np.uint32).reshape(h, w)
+        y = (p & 0xFF).astype(np.uint8)
+        cbcr = np.empty((h // 2, w), dtype=np.uint8)
+        src = p[1::2, 0::2]
+        cbcr[:, 0::2] = (src >> 8) & 0xFF
+        cbcr[:, 1::2] = (src >> 16) & 0xFF
+        cvPixelBuffer.upload_planes(y, cbcr)
+        return True
+
+
+class MetalBT709Decoder:
+    """Renderer/MetalBT709Decoder.h:21-72 over the HIP kernel."""
+
+    def __init__(self):
+        self.metalRenderContext = None
+        self.colorPixelFormat = MTLPixelFormatBGRA8Unorm_sRGB
+        self.gamma = MetalBT709GammaApple  # "Defaults to apple gamma"
+        self.useComputeRenderer = True     # there is only a compute path here
+        self.hasAlphaChannel = False
+        self.alphaFill = 0xFF
+        self.lastStatus = _capi.OK
+        self._handle = None
+
+    def _fail(self, rc, what):
+        self.lastStatus = rc
+        log.error("%s: %s", what, _capi.strerror(rc))  # NSLog in the reference
+        return False
+
+    def setupMetal(self):
+        if self.metalRenderContext is None:  # MetalBT709Decoder.m:48-54
+            self.lastStatus = _capi.ERR_NOT_SETUP
+            return False
+        ctx = self.metalRenderContext
+        if not ctx.setupMetal():
+            self.lastStatus = _capi.ERR_NO_DEVICE
+            return False
+        if self._handle:  # second call is a nop (.m:66-70)
+            return True
+        h = C.c_void_p()
+        rc = ctx.lib.bt709hip_decoder_create(ctx.handle, int(self.gamma), int(bool(self.hasAlphaChannel)),
+                                             C.byref(h))
+        if rc != _capi.OK:
+            return self._fail(rc, "decoder create")
+        self._handle = h.value
+        ctx.lib.bt709hip_decoder_set_alpha_fill(self._handle, int(self.alphaFill))
+        rc = ctx.lib.bt709hip_decoder_setup(self._handle)
+        if rc != _capi.OK:
+            return self._fail(rc, "decoder setup")
+        # hasAlphaChannel forces the sRGB function (.m:165-169)
+        self.gamma = ctx.lib.bt709hip_decoder_get_gamma(self._handle)
+        self.lastStatus = _capi.OK
+        return True
+
+    def decodeBT709(self, yCbCrInputTexture, alphaPixelBuffer=None, bgraSRGBTexture=None, commandBuffer=None,
+                    renderPassDescriptor=None, renderWidth=0, renderHeight=0, waitUntilCompleted=False):
+        """Returns True on success, False on any validation or launch failure
+        (MetalBT709Decoder.h:65-72).  renderPassDescriptor has no HIP meaning: a view
+        drawable is just another BGRATexture, pass it as bgraSRGBTexture."""
+        if not self.setupMetal():
+            return False
+        if yCbCrInputTexture is None or bgraSRGBTexture is None:
+            return self._fail(_capi.ERR_INVALID_ARG, "decodeBT709")
+        lib = self.metalRenderContext.lib
+        frame = yCbCrInputTexture.frame()
+        alpha = alphaPixelBuffer.frame() if alphaPixelBuffer is not None else None
+        surf = bgraSRGBTexture.surface()
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = lib.bt709hip_decode(self._handle, C.byref(frame), C.byref(alpha) if alpha is not None else None,
+                                 C.byref(surf), int(renderWidth), int(renderHeight), stream,
+                                 int(bool(waitUntilCompleted)))
+        if rc != _capi.OK:
+            return self._fail(rc, "decodeBT709")
+        self.lastStatus = _capi.OK
+        return True
+
+    def decodeBT709Batch(self, pixelBuffers, textures, alphaPixelBuffers=None, commandBuffer=None,
+                         waitUntilCompleted=False):
+        """`count` independent same-geometry frames in one launch (no reference twin: the
+        reference decodes one frame per command buffer)."""
+        if not self.setupMetal():
+            return False
+        n = len(pixelBuffers)
+        frames = (Frame * n)(*[b.frame() for b in pixelBuffers])
+        surfs = (Surface * n)(*[t.surface() for t in textures])
+        alphas = (Frame * n)(*[b.frame() for b in alphaPixelBuffers]) if alphaPixelBuffers else None
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = self.metalRenderContext.lib.bt709hip_decode_batch(self._handle, n, frames, alphas, surfs, stream,
+                                                               int(bool(waitUntilCompleted)))
+        if rc != _capi.OK:
+            return self._fail(rc, "decodeBT709Batch")
+        self.lastStatus = _capi.OK
+        return True
+
+    def decodeBT709Scaled(self, yCbCrInputTexture, bgraSRGBTexture, commandBuffer=None, waitUntilCompleted=False):
+        """-decodeBT709 into an intermediate + MetalScaleRenderContext -renderScaled:
+        (AAPLRenderer.m:940-977), fused, for the exact 2:1 ratio."""
+        if not self.setupMetal():
+            return False
+        frame, surf = yCbCrInputTexture.frame(), bgraSRGBTexture.surface()
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = self.metalRenderContext.lib.bt709hip_decode_half(self._handle, C.byref(frame), C.byref(surf), stream,
+                                                              int(bool(waitUntilCompleted)))
+        if rc != _capi.OK:
+            return self._fail(rc, "decodeBT709Scaled")
+        self.lastStatus = _capi.OK
+        return True
+
+    def release(self):
+        ctx = self.metalRenderContext
+        if self._handle and ctx is not None and ctx.handle:  # a destroyed context took the device with it
+            ctx.lib.bt709hip_decoder_destroy(self._handle)
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

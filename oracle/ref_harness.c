@@ -177,3 +177,21 @@ void ref_encode_nv12(const uint32_t *bgra, int width, int height, int in_gamma,
     }
   ref_quiet_end();
 }
+
+/* NV12 rows [row0,row1) through the reference's per-pixel function, walking pixels
+ * the way unconvertSoftware does (BGRAToBT709Converter.m:146-198) with chroma taken
+ * at row/2, col/2 (.m:267-277).  Used as the "reference" CPU baseline by bench.py. */
+void ref_decode_nv12_rows(int gamma, const uint8_t *y, size_t y_stride, const uint8_t *uv,
+                          size_t uv_stride, int width, int row0, int row1, uint8_t *bgra,
+                          size_t bgra_stride, int alpha_fill) {
+  for (int row = row0; row < row1; row++) {
+    const uint8_t *yr = y + (size_t)row * y_stride;
+    const uint8_t *cr = uv + (size_t)(row / 2) * uv_stride;
+    uint32_t *o = (uint32_t *)(bgra + (size_t)row * bgra_stride);
+    for (int col = 0; col < width; col++) {
+      int rgb[3];
+      ref_decode_pixel(gamma, yr[col], cr[2 * (col / 2)], cr[2 * (col / 2) + 1], rgb);
+      o[col] = ((uint32_t)alpha_fill << 24) | ((uint32_t)rgb[0] << 16) | ((uint32_t)rgb[1] << 8) | (uint32_t)rgb[2];
+    }
+  }
+}

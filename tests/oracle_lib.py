@@ -248,6 +248,20 @@ class Reference:
         L.ref_roundtrip_histogram.argtypes = [C.c_int, _u64p, C.c_int, C.c_int]
         L.ref_subsample_block.argtypes = [_i32p, C.c_int, C.c_int, _i32p]
         L.ref_encode_nv12.argtypes = [_u32p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p]
+        L.ref_decode_nv12_rows.argtypes = [C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int,
+                                           C.c_int, C.c_int, _u8p, C.c_size_t, C.c_int]
+
+    def decode_nv12(self, gamma, y, uv, alpha_fill=0xFF, rows=None, out=None):
+        """Frame loop over the reference's per-pixel function (cpu_baseline "reference")."""
+        y, width = _plane(y)
+        uv, _ = _plane(uv)
+        height = y.shape[0]
+        if out is None:
+            out = np.zeros((height, width * 4), dtype=np.uint8)
+        r0, r1 = rows if rows is not None else (0, height)
+        self.lib.ref_decode_nv12_rows(gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1],
+                                      width, r0, r1, _ptr(out, _u8p), out.shape[1], alpha_fill)
+        return out
 
     def decode_pixel(self, gamma, Y, Cb, Cr):
         out = (C.c_int * 3)()

@@ -1,0 +1,327 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI via the host
+mirror, against the CPU oracle and the committed golden fixtures.  Bar: bit-exact
+B,G,R,A bytes -- this is integer/byte output, there is no tolerance anywhere below.
+
+Reads like EmptyiOSTests/MetalBT709DecoderTests.m:189-277: make a 420v buffer, tag it
+BT.709, copy packed pixels in, -decodeBT709:... waitUntilCompleted, read the texture.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import metalbt709decoder_amd as mb
+from metalbt709decoder_amd import _capi
+from oracle_lib import GAMMA_NAMES
+
+pytestmark = pytest.mark.gpu
+
+GAMMAS = [mb.MetalBT709GammaApple, mb.MetalBT709GammaSRGB, mb.MetalBT709GammaLinear, mb.MetalBT709GammaITU709]
+
+
+@pytest.fixture(scope="module")
+def gh():
+    import gpu_helpers
+    gpu_helpers.context()
+    return gpu_helpers
+
+
+def test_native_library_is_loaded(gh):
+    """The HIP extension is in-tree and actually the thing that runs."""
+    import os
+    lib = mb.load_library()
+    assert os.path.samefile(lib._name, os.path.join(os.path.dirname(mb.__file__), "libbt709hip.so"))
+    info = gh.context().info()
+    assert info.arch.decode().startswith("gfx950"), info.arch
+    assert info.wavefront_size == 64
+
+
+# ------------------------------------------------------------------ reference vectors
+
+def test_metal_decode_vectors(gh, vectors):
+    """The reference's 28 Metal decode expectations, through the reference's own test
+    flow (MetalBT709DecoderTests.m:189-277), default Apple gamma."""
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    for r in vectors["metal_decode"]:
+        Y, Cb, Cr = r["ycbcr"]
+        outBT709 = np.full(4, (Cr << 16) | (Cb << 8) | Y, dtype=np.uint32)
+        bgraSRGBTexture = ctx.makeBGRATexture((2, 2))
+        yCbCrBuffer = mb.BGRAToBT709Converter.createCoreVideoYCbCrBuffer(ctx, (2, 2))
+        mb.BGRAToBT709Converter.setBT709Attributes(yCbCrBuffer)
+        mb.BGRAToBT709Converter.copyBT709ToCoreVideo(outBT709, yCbCrBuffer)
+        commandBuffer = ctx.commandQueue.commandBuffer()
+        worked = dec.decodeBT709(yCbCrBuffer, None, bgraSRGBTexture, commandBuffer, None, 2, 2, True)
+        assert worked, r["test"]
+        px = ctx.getBGRATexturePixels(bgraSRGBTexture)
+        for word in px.reshape(-1):
+            got = [(int(word) >> 16) & 0xFF, (int(word) >> 8) & 0xFF, int(word) & 0xFF]
+            assert got == r["rgb_out"], (r["test"], r["src"], got)
+            assert int(word) >> 24 == 0xFF
+
+
+def test_converter_software_vectors(gh, vectors):
+    """unconvertSoftware semantics: alpha_fill 0 reproduces its output words exactly."""
+    dec = gh.make_decoder(mb.MetalBT709GammaApple, alpha_fill=0x00)
+    for r in vectors["converter"]:
+        if r["decode_type"] not in ("Software", "Metal"):
+            continue
+        Y, Cb, Cr = r["ycbcr"]
+        y = np.full((2, 2), Y, np.uint8)
+        c = np.array([[Cb, Cr]], np.uint8)
+        out = gh.gpu_decode(y, c, decoder=dec).view(np.uint32)
+        R, G, B = r["rgb_out"]
+        assert (out == ((R << 16) | (G << 8) | B)).all(), r["test"]
+
+
+# ------------------------------------------------------------------ exhaustive sweep
+
+@pytest.mark.parametrize("gamma", GAMMAS)
+def test_exhaustive_2_24_sweep(gh, oracle, refdata, gamma):
+    """Every (Y,Cb,Cr) triple once: the GPU output, reordered into table layout, must
+    hash to the value the REFERENCE HEADERS produced (tests/golden/reference.json) and
+    equal the oracle's table byte for byte."""
+    y, c = gh.exhaustive_frame()
+    out = gh.gpu_decode(y, c, gamma)
+    assert out is not None
+    table = gh.exhaustive_to_table(out, y, c)
+    assert hashlib.sha256(table.tobytes()).hexdigest() == refdata["table_sha256"][GAMMA_NAMES[gamma]]
+    assert np.array_equal(table, oracle.decode_table(gamma))
+    assert (out.reshape(-1, 4)[:, 3] == 0xFF).all()
+
+
+# ------------------------------------------------------------------ frames vs oracle
+
+@pytest.mark.parametrize("gamma", GAMMAS)
+@pytest.mark.parametrize("size", [(2, 2), (4, 2), (2, 4), (6, 6), (18, 10), (64, 64), (250, 30), (1028, 6),
+                                  (1920, 1080)])
+def test_random_frames(gh, oracle, gamma, size):
+    w, h = size
+    y, c = gh.random_nv12(w, h, seed=w * 131 + h + gamma)
+    out = gh.gpu_decode(y, c, gamma)
+    assert np.array_equal(out, oracle.decode_nv12(gamma, y, c))
+
+
+@pytest.mark.parametrize("strides", [(1936, 1936, None), (1923, 1925, None), (1920, 2048, 7684), (1921, 1920, 7680 + 64)])
+def test_ragged_strides_and_fallback_kernel(gh, oracle, strides):
+    """CoreVideo planes have bytesPerRow >= width (CVPixelBufferUtils.h:82-155).  Odd
+    strides force the general kernel; the result must not change."""
+    ys, cs, os_ = strides
+    y, c = gh.random_nv12(1920, 54, seed=5)
+    out = gh.gpu_decode(y, c, mb.MetalBT709GammaApple, y_stride=ys, cbcr_stride=cs, out_stride=os_)
+    assert np.array_equal(out, oracle.decode_nv12(mb.MetalBT709GammaApple, y, c))
+    name = mb.load_library().bt709hip_last_kernel_name().decode()
+    if ys % 4 or cs % 4:
+        assert "blocks" in name
+    else:
+        assert "quads" in name
+
+
+def test_video_legal_range(gh, oracle):
+    y, c = gh.random_nv12(640, 360, seed=9, legal=True)
+    for gamma in GAMMAS:
+        assert np.array_equal(gh.gpu_decode(y, c, gamma), oracle.decode_nv12(gamma, y, c))
+
+
+def test_bundled_pattern_crops(gh, refdata, patterns):
+    """Crops of the reference's bundled images: GPU bytes == reference-header bytes."""
+    for rec in refdata["patterns"]:
+        y, c = patterns[rec["tag"] + "_y"], patterns[rec["tag"] + "_uv"]
+        for gamma in GAMMAS:
+            out = gh.gpu_decode(y, c, gamma)
+            assert hashlib.sha256(out.tobytes()).hexdigest() == rec["bgra_sha256"][GAMMA_NAMES[gamma]], rec["tag"]
+        assert np.array_equal(gh.gpu_decode(y, c, mb.MetalBT709GammaApple), patterns[rec["tag"] + "_bgra_apple"])
+
+
+def test_4k_full_size(gh, oracle):
+    """BASELINE config 3 geometry, full size, against the oracle (threads split rows)."""
+    from concurrent.futures import ThreadPoolExecutor
+    w, h = 3840, 2160
+    y, c = gh.random_nv12(w, h, seed=4)
+    out = gh.gpu_decode(y, c, mb.MetalBT709GammaApple)
+    want = np.zeros((h, w * 4), np.uint8)
+    bands = [(r, min(r + 270, h)) for r in range(0, h, 270)]
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(lambda b: oracle.decode_nv12(0, y, c, rows=b, out=want), bands))
+    assert np.array_equal(out, want)
+
+
+def test_8k_checksum_of_rows_property(gh, oracle):
+    """BASELINE config 4 source geometry (7680x4320): a frame built by tiling a small
+    tile must decode to the tiling of the tile's decode (size-independent property; the
+    tile itself is checked against the oracle)."""
+    ty, tc = gh.random_nv12(256, 16, seed=8)
+    y = np.tile(ty, (270, 30))
+    c = np.tile(tc, (270, 30))
+    out = gh.gpu_decode(y, c, mb.MetalBT709GammaApple)
+    tile = oracle.decode_nv12(0, ty, tc)
+    assert np.array_equal(out, np.tile(tile, (270, 30)))
+
+
+# ------------------------------------------------------------------ alpha channel
+
+def test_alpha_channel(gh, oracle):
+    """hasAlphaChannel: second Y-only buffer decoded as linear alpha, sRGB gamma forced
+    (MetalBT709Decoder.m:165-169; AAPLShaders.metal:411-438)."""
+    w, h = 72, 20
+    y, c = gh.random_nv12(w, h, seed=21)
+    a = np.random.default_rng(22).integers(0, 256, (h, w), dtype=np.uint8)
+    dec = gh.make_decoder(mb.MetalBT709GammaApple, has_alpha=True)
+    assert dec.gamma == mb.MetalBT709GammaSRGB
+    out = gh.gpu_decode(y, c, alpha=a, decoder=dec)
+    assert np.array_equal(out, oracle.decode_nv12(mb.MetalBT709GammaSRGB, y, c, alpha=a))
+    # all 256 alpha codes
+    a2 = np.arange(256, dtype=np.uint8).reshape(4, 64)
+    y2, c2 = gh.random_nv12(64, 4, seed=23)
+    out2 = gh.gpu_decode(y2, c2, alpha=a2, decoder=dec)
+    assert np.array_equal(out2, oracle.decode_nv12(mb.MetalBT709GammaSRGB, y2, c2, alpha=a2))
+
+
+def test_alpha_odd_width_fallback(gh, oracle):
+    w, h = 18, 6
+    y, c = gh.random_nv12(w, h, seed=24)
+    a = np.random.default_rng(25).integers(0, 256, (h, w), dtype=np.uint8)
+    dec = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
+    out = gh.gpu_decode(y, c, alpha=a, decoder=dec)
+    assert np.array_equal(out, oracle.decode_nv12(mb.MetalBT709GammaSRGB, y, c, alpha=a))
+
+
+# ------------------------------------------------------------------ batch / streams
+
+def test_batch_equals_single(gh, oracle):
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    n, w, h = 8, 320, 48
+    frames = [gh.random_nv12(w, h, seed=100 + i) for i in range(n)]
+    bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
+    texs = [ctx.makeBGRATexture((w, h)) for _ in range(n)]
+    assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True)
+    for (y, c), t in zip(frames, texs):
+        got = ctx.getBGRATexturePixels(t).view(np.uint8).reshape(h, w * 4)
+        assert np.array_equal(got, oracle.decode_nv12(0, y, c))
+    too_many = bufs * 5
+    assert not dec.decodeBT709Batch(too_many, texs * 5) and dec.lastStatus == _capi.ERR_UNSUPPORTED
+
+
+def test_one_stream_per_in_flight_frame(gh, oracle):
+    """North-star shape: each in-flight frame on its own HIP stream, no wait until the end."""
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    w, h = 640, 360
+    frames = [gh.random_nv12(w, h, seed=200 + i) for i in range(6)]
+    bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
+    texs = [ctx.makeBGRATexture((w, h)) for _ in frames]
+    cbs = [ctx.commandQueue.commandBuffer(new_stream=True) for _ in frames]
+    for b, t, cb in zip(bufs, texs, cbs):
+        assert dec.decodeBT709(b, None, t, cb, None, w, h, False)
+    for cb in cbs:
+        cb.waitUntilCompleted()
+    for (y, c), t, cb in zip(frames, texs, cbs):
+        got = ctx.getBGRATexturePixels(t).view(np.uint8).reshape(h, w * 4)
+        assert np.array_equal(got, oracle.decode_nv12(0, y, c))
+        cb.release()
+
+
+def test_decode_is_idempotent_and_stateless(gh):
+    """The decoder keeps no per-frame state: decoding A, then B, then A again gives A's bytes."""
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    ya, ca = gh.random_nv12(128, 32, seed=31)
+    yb, cb = gh.random_nv12(128, 32, seed=32)
+    a1 = gh.gpu_decode(ya, ca, decoder=dec)
+    gh.gpu_decode(yb, cb, decoder=dec)
+    a2 = gh.gpu_decode(ya, ca, decoder=dec)
+    assert np.array_equal(a1, a2)
+
+
+# ------------------------------------------------------------------ fused 2:1 rescale
+
+@pytest.mark.parametrize("gamma", GAMMAS)
+@pytest.mark.parametrize("size", [(4, 4), (8, 4), (12, 8), (40, 12), (256, 64), (1920, 1080 - 1080 % 4)])
+def test_half_scale(gh, oracle, gamma, size):
+    """Fused decode + 2:1 downscale against the oracle's two-pass-equivalent restatement
+    (parity unpinned by the reference: it has no CPU twin of pass 2)."""
+    w, h = size
+    y, c = gh.random_nv12(w, h, seed=w + h + gamma)
+    out = gh.gpu_decode_half(y, c, gamma)
+    assert np.array_equal(out, oracle.decode_nv12_half(gamma, y, c))
+
+
+def test_half_scale_flat_frame_is_identity(gh):
+    y = np.full((64, 64), 180, np.uint8)
+    c = np.full((32, 64), 128, np.uint8)
+    full = gh.gpu_decode(y, c)
+    half = gh.gpu_decode_half(y, c)
+    assert (half.reshape(-1, 4) == full.reshape(-1, 4)[0]).all()
+
+
+# ------------------------------------------------------------------ error behaviour
+
+def _decode_status(gh, dec, buf, tex, rw, rh, alpha=None):
+    ok = dec.decodeBT709(buf, alpha, tex, gh.context().commandQueue.commandBuffer(), None, rw, rh, True)
+    return ok, dec.lastStatus
+
+
+def test_error_behaviour(gh):
+    """FALSE on every validation failure, in the reference's order
+    (MetalBT709Decoder.m:272-368)."""
+    ctx = gh.context()
+    y, c = gh.random_nv12(8, 4, seed=1)
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    good = gh.make_buffer(y, c, dec.gamma)
+    tex = ctx.makeBGRATexture((8, 4))
+    assert _decode_status(gh, dec, good, tex, 8, 4) == (True, _capi.OK)
+    # output texture of another size (.m:272-282)
+    assert _decode_status(gh, dec, good, ctx.makeBGRATexture((8, 6)), 8, 4) == (False, _capi.ERR_SIZE_MISMATCH)
+    # render size differs (.m:284-290)
+    assert _decode_status(gh, dec, good, tex, 4, 4) == (False, _capi.ERR_SIZE_MISMATCH)
+    # untagged / BT.601 matrix (.m:311-318)
+    bad = gh.make_buffer(y, c, dec.gamma)
+    bad.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_601_4)
+    assert _decode_status(gh, dec, bad, tex, 8, 4) == (False, _capi.ERR_MATRIX)
+    # transfer tag vs configured gamma (.m:335-353)
+    srgb_tagged = gh.make_buffer(y, c, mb.MetalBT709GammaSRGB)
+    assert _decode_status(gh, dec, srgb_tagged, tex, 8, 4) == (False, _capi.ERR_TRANSFER)
+    for gamma in (mb.MetalBT709GammaSRGB, mb.MetalBT709GammaLinear):
+        d2 = gh.make_decoder(gamma)
+        assert _decode_status(gh, d2, good, tex, 8, 4) == (False, _capi.ERR_TRANSFER)
+        assert _decode_status(gh, d2, gh.make_buffer(y, c, gamma), tex, 8, 4) == (True, _capi.OK)
+    # alpha buffer of another size (.m:294-306) and not tagged linear (.m:357-368)
+    da = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
+    sb = gh.make_buffer(y, c, mb.MetalBT709GammaSRGB)
+    a_small = gh.make_alpha_buffer(np.zeros((2, 8), np.uint8))
+    assert _decode_status(gh, da, sb, tex, 8, 4, a_small) == (False, _capi.ERR_SIZE_MISMATCH)
+    a_bad = gh.make_alpha_buffer(np.zeros((4, 8), np.uint8))
+    a_bad.setAttachment("TransferFunction", mb.kCVImageBufferTransferFunction_sRGB)
+    assert _decode_status(gh, da, sb, tex, 8, 4, a_bad) == (False, _capi.ERR_ALPHA_TRANSFER)
+    assert _decode_status(gh, da, sb, tex, 8, 4, None) == (False, _capi.ERR_INVALID_ARG)
+    # odd dimensions (BGRAToBT709Converter.m:69-74)
+    odd = mb.CVPixelBuffer(ctx, 7, 4)
+    mb.BGRAToBT709Converter.setBT709Attributes(odd)
+    assert _decode_status(gh, dec, odd, ctx.makeBGRATexture((7, 4)), 7, 4) == (False, _capi.ERR_ODD_DIMENSIONS)
+    # a decoder without a render context cannot set up (.m:48-54)
+    orphan = mb.MetalBT709Decoder()
+    assert orphan.setupMetal() is False and orphan.lastStatus == _capi.ERR_NOT_SETUP
+    assert orphan.decodeBT709(good, None, tex, None, None, 8, 4, True) is False
+
+
+def test_empty_frame_is_a_noop(gh):
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    buf = mb.CVPixelBuffer(ctx, 0, 0)
+    mb.BGRAToBT709Converter.setBT709Attributes(buf)
+    assert dec.decodeBT709(buf, None, ctx.makeBGRATexture((0, 0)), None, None, 0, 0, True)
+
+
+def test_output_padding_is_untouched(gh):
+    """Only width*4 bytes of each output row are written."""
+    ctx = gh.context()
+    w, h, stride = 64, 8, 64 * 4 + 64
+    y, c = gh.random_nv12(w, h, seed=77)
+    dec = gh.make_decoder()
+    tex = ctx.makeBGRATexture((w, h), stride=stride)
+    _capi.check(ctx.lib.bt709hip_memset(ctx.handle, tex.ptr, 0xAB, stride * h, None))
+    assert dec.decodeBT709(gh.make_buffer(y, c, dec.gamma), None, tex, None, None, w, h, True)
+    raw = np.empty((h, stride), np.uint8)
+    _capi.check(ctx.lib.bt709hip_download(ctx.handle, raw.ctypes.data, stride, tex.ptr, stride, stride, h, None))
+    ctx._sync(None)
+    assert (raw[:, w * 4:] == 0xAB).all()

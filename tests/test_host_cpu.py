@@ -1,0 +1,237 @@
+"""CPU-side tests of the product (no GPU, no compute calls): the C-ABI library loads
+and exports everything include/bt709hip.h declares, the host-built tables and constants
+equal the reference-pinned goldens, the kernel ISA honours the no-FMA contract, the
+failure behaviour without a device is loud, and the N>1 control flow works over gloo.
+"""
+import ctypes as C
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import metalbt709decoder_amd as mb
+from metalbt709decoder_amd import _capi, build
+from oracle_lib import GAMMA_NAMES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return mb.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(bt709hip_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), "library does not export " + name
+    # and the ctypes table binds exactly that set
+    assert declared == set(_capi.SYMBOLS)
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "bt709hip.h"\nint main(void){bt709hip_frame f; (void)f; return BT709HIP_MAX_BATCH==32?0:1;}\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                        "-o", str(tmp_path / "t")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_matrix_constants_bit_patterns(lib, oracle):
+    """BT709.h:386-397 evaluated in float; patterns recorded in SURVEY.md section 7."""
+    c = (C.c_float * 8)()
+    assert lib.bt709hip_matrix_constants(c) == 0
+    bits = np.array(list(c), dtype=np.float32).view(np.uint32)
+    assert [hex(b) for b in bits[:6]] == ["0x3b808081", "0x3f950a85", "0x3fe5788a", "0xbe5a5dd8", "0xbf086cbf",
+                                          "0x40073197"]
+    # the same numbers drive the oracle: Y=235 grey -> 1.0 exactly after saturation, etc.
+    inv255, my, mcr_r, mcb_g, mcr_g, mcb_b = [np.float32(v) for v in list(c)[:6]]
+    for (Y, Cb, Cr) in [(16, 128, 128), (235, 128, 128), (81, 90, 240), (145, 54, 34), (41, 240, 110), (255, 0, 255)]:
+        yv = np.float32(np.float32(np.float32(Y - 16) * inv255) * my)
+        cbn = np.float32(np.float32(Cb - 128) * inv255)
+        crn = np.float32(np.float32(Cr - 128) * inv255)
+        r = np.float32(yv + np.float32(crn * mcr_r))
+        g = np.float32(np.float32(yv + np.float32(cbn * mcb_g)) + np.float32(crn * mcr_g))
+        b = np.float32(yv + np.float32(cbn * mcb_b))
+        want = oracle.ycbcr_to_rgbn(Y, Cb, Cr)
+        got = np.clip(np.array([r, g, b], np.float32), 0, 1)
+        assert np.array_equal(got.view(np.uint32) & 0x7FFFFFFF, want.view(np.uint32) & 0x7FFFFFFF)
+
+
+@pytest.mark.parametrize("gamma", [0, 1, 2, 3])
+def test_host_built_thresholds_equal_reference(lib, refdata, oracle, gamma):
+    """The table the kernel looks up is built by the product's own host code at
+    -setupMetal time; it must equal the thresholds derived from the reference headers."""
+    t = np.zeros(255, np.float32)
+    assert lib.bt709hip_gamma_thresholds(gamma, t.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    want = np.array([int(x, 16) for x in refdata["thresholds_hex"][GAMMA_NAMES[gamma]]], dtype=np.uint32)
+    assert np.array_equal(t.view(np.uint32), want)
+    assert np.array_equal(t.view(np.uint32), oracle.thresholds(gamma).view(np.uint32))
+    assert lib.bt709hip_gamma_thresholds(7, t.ctypes.data_as(C.POINTER(C.c_float))) == _capi.ERR_INVALID_ARG
+
+
+def test_no_device_fails_loudly(lib):
+    """No GPU here: nothing silently falls back to a CPU path."""
+    import torch  # noqa: F401  (only to learn whether a GPU exists)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert lib.bt709hip_device_count() == 0
+    h = C.c_void_p()
+    assert lib.bt709hip_context_create(0, C.byref(h)) == _capi.ERR_NO_DEVICE and not h.value
+    ctx = mb.MetalRenderContext(0)
+    assert ctx.setupMetal() is False
+    dec = mb.MetalBT709Decoder()
+    dec.metalRenderContext = ctx
+    assert dec.setupMetal() is False and dec.lastStatus == _capi.ERR_NO_DEVICE
+    assert dec.decodeBT709(None, None, None) is False
+    with pytest.raises(RuntimeError):
+        import gpu_helpers
+        gpu_helpers._ctx = None
+        gpu_helpers.context()
+
+
+def test_decoder_without_context(lib):
+    """-setupMetal returns FALSE when metalRenderContext is nil (MetalBT709Decoder.m:48-54)."""
+    d = C.c_void_p()
+    assert lib.bt709hip_decoder_create(None, 0, 0, C.byref(d)) == 0
+    assert lib.bt709hip_decoder_setup(d) == _capi.ERR_NOT_SETUP
+    assert lib.bt709hip_decoder_get_gamma(d) == 0
+    assert lib.bt709hip_decoder_set_alpha_fill(d, 300) == _capi.ERR_INVALID_ARG
+    f, s = _capi.Frame(), _capi.Surface()
+    assert lib.bt709hip_decode(d, C.byref(f), None, C.byref(s), 0, 0, None, 1) == _capi.ERR_NOT_SETUP
+    assert lib.bt709hip_decoder_destroy(d) == 0
+    # hasAlphaChannel forces the sRGB function (.m:165-169)
+    assert lib.bt709hip_decoder_create(None, 0, 1, C.byref(d)) == 0
+    assert lib.bt709hip_decoder_get_gamma(d) == mb.MetalBT709GammaSRGB
+    lib.bt709hip_decoder_destroy(d)
+    assert lib.bt709hip_decoder_create(None, 9, 0, C.byref(d)) == _capi.ERR_INVALID_ARG
+
+
+def test_strerror_covers_every_status(lib):
+    seen = set()
+    for code in range(0, -12, -1):
+        msg = lib.bt709hip_strerror(code).decode()
+        assert msg and msg != "unknown status"
+        seen.add(msg)
+    assert len(seen) == 12
+    assert lib.bt709hip_strerror(-99).decode() == "unknown status"
+
+
+def test_copyBT709ToCoreVideo_packing(oracle):
+    """Host plumbing twin of BGRAToBT709Converter.m:1042-1099, checked against the oracle's
+    restatement without touching a device."""
+    rng = np.random.default_rng(5)
+    w, h = 12, 6
+    packed = rng.integers(0, 1 << 24, w * h, dtype=np.uint32)
+    captured = {}
+
+    class FakeBuf:
+        width, height = w, h
+
+        def upload_planes(self, y, c):
+            captured["y"], captured["c"] = y.copy(), c.copy()
+
+    assert mb.BGRAToBT709Converter.copyBT709ToCoreVideo(packed, FakeBuf())
+    y, c = oracle.packed_to_nv12(packed, w, h)
+    assert np.array_equal(captured["y"], y) and np.array_equal(captured["c"], c)
+
+
+# ------------------------------------------------------------------ ISA contract
+
+@pytest.fixture(scope="module")
+def asm():
+    return open(build.emit_asm()).read()
+
+
+def _kernel_bodies(asm, mangled_fragment):
+    found = re.findall(r"^_ZN5bt709\w*%s\w*:[^\n]*\n(.*?)s_endpgm" % mangled_fragment, asm, flags=re.S | re.M)
+    assert found, mangled_fragment
+    return found
+
+
+def _kernel_body(asm, mangled_fragment):
+    return _kernel_bodies(asm, mangled_fragment)[0]
+
+
+def test_isa_has_no_fused_multiply_add(asm):
+    """Every multiply and add must round separately (BT709.h:424-426 is evaluated without
+    contraction on the CPU); an FMA anywhere in these kernels would break bit-exactness."""
+    n = 0
+    for kernel in ("17decode_nv12_quads", "18decode_nv12_blocks", "16decode_nv12_half"):
+        for body in _kernel_bodies(asm, kernel):
+            assert not re.search(r"\bv_(pk_)?(fma|fmac|mad|mac)_(f32|legacy_f32|f16)", body), kernel
+            n += 1
+    assert n == 8  # every instantiation the launchers can pick
+
+
+def test_isa_memory_shape(asm):
+    body = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1ELi4E")
+    assert body.count("global_store_dwordx4") == 8          # 4 quads x 2 rows, 16 B per lane
+    assert re.search(r"global_store_dwordx4 .* nt", body)   # streaming (non-temporal) stores
+    assert body.count("global_load_dword ") + body.count("global_load_dword\t") >= 12
+    assert "ds_read_b64" in body                            # one 8-byte table bucket per lookup
+    assert "scratch_" not in body                           # no spills
+    meta = re.search(r"\.name:\s+_ZN5bt70917decode_nv12_quadsILb0ELb1ELi4E.*?\.vgpr_count:\s+(\d+)", asm, flags=re.S)
+    assert meta and int(meta.group(1)) <= 64                # 8 waves per SIMD
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.dirname(mb.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert "oracle_lib" not in text and "liboracle" not in text and "bt709_oracle" not in text, f
+    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    assert "oracle" not in hdr
+
+
+# ------------------------------------------------------------------ N > 1 control flow
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bench_two_ranks_gloo_dry_run():
+    """world_size 2 on CPU: rendezvous, barriers, MAX over ranks, exactly one JSON line,
+    whole-job value = 2 x per-rank work / slowest rank."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
+    assert res["unit"] == "Gpixel/s" and res["roofline"]["bound"] == "hbm"
+    # 2 ranks x 5 steps x 64 x 4K pixels over >= 5 x 2 ms
+    px = 2 * 5 * 64 * 3840 * 2160
+    assert res["value"] <= px / (5 * 0.002) / 1e9
+    assert abs(res["value"] - px / (res["ms_per_step"] * 5e-3) / 1e9) / res["value"] < 1e-3
+    assert "cpu_baseline" not in res
+
+
+def test_bench_geometry():
+    import bench
+    g = bench.geometry("4k", 0, 32)
+    assert (g["ring"], g["per_launch"], g["launches"]) == (64, 32, 2)
+    assert g["bytes_per_frame"] == 45_619_200
+    g = bench.geometry("1080p", 0, 32)
+    assert g["bytes_per_frame"] == 11_404_800
+    g = bench.geometry("8k-half", 0, 32)
+    assert g["bytes_per_frame"] == 82_944_000 and (g["OW"], g["OH"]) == (3840, 2160)
+    g = bench.geometry("4k", 40, 32)
+    assert g["ring"] == 32 and g["launches"] == 1
