@@ -121,6 +121,14 @@ class GpuRunner:
         _capi.check(lib.bt709hip_event_create(h, C.byref(self.ev0)))
         _capi.check(lib.bt709hip_event_create(h, C.byref(self.ev1)))
         self.Frame, self.Surface = Frame, Surface
+        # Untimed pre-warm: the device sits in a low-power state between jobs and needs
+        # ~20-50 launches (tens of ms) before its clocks settle (measured: 308 -> 248 us per
+        # launch, tools/launchprobe.py).  Done here, before the W warmup steps, so that a
+        # small --warmup still times the settled kernel.
+        t_end = time.perf_counter() + 0.4
+        while time.perf_counter() < t_end:
+            self.step()
+            self.sync()
 
     def step(self):
         g, lib = self.g, self.lib
@@ -307,6 +315,21 @@ def load_traffic(workload):
         return None
 
 
+def usable_cores():
+    """Threads worth starting: affinity mask, capped by a cgroup CPU quota and by 64."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(frame0, g, gamma, target_seconds):
     """Bounded sample of the same workload on the host cores.  Checker code, timed only:
     this is the one place bench.py touches oracle/."""
@@ -329,22 +352,28 @@ def cpu_baseline(frame0, g, gamma, target_seconds):
         else:
             impl.decode_nv12(gamma, y, c, rows=(0, chunk), out=out)
 
-    cores = min(os.cpu_count() or 1, 64)
+    cores = usable_cores()
     scratch = np.zeros((chunk, W * 4), np.uint8)
+    run_chunk(scratch)  # page in
     t0 = time.perf_counter()
     run_chunk(scratch)
     one = (time.perf_counter() - t0) / (chunk * W)  # seconds per source pixel on one thread
-    chunks_per_thread = max(1, int(target_seconds / (one * chunk * W)))
+
+    deadline = time.perf_counter() + target_seconds
 
     def work(_):
         mine = np.zeros((chunk, W * 4), np.uint8)
-        for _i in range(chunks_per_thread):
+        done = 0
+        while time.perf_counter() < deadline:
             run_chunk(mine)
-        return chunks_per_thread * chunk
+            done += chunk
+        return done
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        rows_done = sum(ex.map(work, range(cores)))
+        per_thread = list(ex.map(work, range(cores)))
+    rows_done = sum(per_thread)
+    chunks_per_thread = max(per_thread) // chunk
     dt = time.perf_counter() - t0
     src_px = rows_done * W
     out_px = src_px // 4 if half else src_px

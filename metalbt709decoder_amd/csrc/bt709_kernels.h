@@ -9,8 +9,10 @@
 
 namespace bt709 {
 
-constexpr int kBlockThreads = 256;  // 4 waves of 64
-constexpr int kMaxBatch = 32;       // == BT709HIP_MAX_BATCH
+constexpr int kBlockThreads = 256;     // general-path workgroup: 4 waves of 64
+constexpr int kMaxBlockThreads = 512;  // fast-path workgroup is sized per frame width, up to 8 waves
+constexpr int kQuadsPerLane = 2;       // 4x2-pixel quads a fast-path lane owns per row pair
+constexpr int kMaxBatch = 32;          // == BT709HIP_MAX_BATCH
 
 enum KernelVariant : int {
   kVariantQuads = 0,   // aligned fast path, 4x2 pixels per lane
@@ -45,7 +47,18 @@ struct DecodeParams {
 // Launchers return the kernel's name (static string) for profiling; launch errors
 // are read by the caller with hipGetLastError().
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
-                          uint32_t grid_x, hipStream_t stream);
+                          uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
+
+// Fast-path workgroup size for a frame width: ceil(quads / kQuadsPerLane) rounded up to a
+// whole wave, within [64, kMaxBlockThreads].  3840 -> 480, 1920 -> 256, 7680 -> 512.
+inline uint32_t quads_block_threads(uint32_t width) {
+  const uint32_t quads = width / 4;
+  uint32_t t = (quads + kQuadsPerLane - 1) / kQuadsPerLane;
+  t = (t + 63) / 64 * 64;
+  if (t < 64) t = 64;
+  if (t > static_cast<uint32_t>(kMaxBlockThreads)) t = kMaxBlockThreads;
+  return t;
+}
 const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
                                hipStream_t stream);
 

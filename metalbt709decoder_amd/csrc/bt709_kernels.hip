@@ -32,8 +32,8 @@
 //     267-277) and two 16-byte stores;
 //   * consecutive lanes own consecutive quads of the same row pair, so a wave reads
 //     3 x 256 contiguous bytes and writes 2 x 1 KiB contiguous, fully coalesced;
-//   * a workgroup walks whole row pairs; all loads of a row pair are issued before
-//     any arithmetic (UNROLL quads per lane in flight);
+//   * one workgroup per row pair (grid.x = H/2), blockDim sized so a lane owns two
+//     quads; all loads of the row pair are issued before any arithmetic;
 //   * grid.y = frame: a batch of independent frames is one launch.
 #include <hip/hip_runtime.h>
 
@@ -127,19 +127,31 @@ __device__ __forceinline__ void store16(uint8_t *p, u32x4 v) {
 // Fast path.  Preconditions (checked by the host shim): width % 4 == 0; y, cbcr,
 // alpha pointers and strides 4-byte aligned; output pointer and stride 16-byte
 // aligned.
+//
+// Launch shape (measured, tools/kernel_lab.hip, DESIGN.md "launch geometry"): ONE
+// workgroup per row pair and per frame -- grid = (H/2, frames) -- with
+// blockDim = ceil(W/8) rounded up to a wave (480 threads for 3840), so that every
+// lane owns UNROLL = 2 quads.  Workgroups are dispatched in address order and live
+// for one burst of loads and one burst of stores; long-lived grid-stride workgroups
+// scatter the DRAM access stream and lose ~20 % of the bandwidth.  The loops below
+// still stride by gridDim/blockDim, so any launch shape is correct.
+//
+// The frame loads of the first tile are issued BEFORE the transfer table is staged
+// into LDS, so the table's L2 round trip hides under the HBM latency of the tile.
 // ---------------------------------------------------------------------------
-template <bool HAS_ALPHA, bool NT, int UNROLL>
-__global__ void __launch_bounds__(kBlockThreads)
+template <bool HAS_ALPHA, bool NT>
+__global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_quads(const DecodeParams p) {
+  constexpr int UNROLL = kQuadsPerLane;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   TransferBucket *tbl = reinterpret_cast<TransferBucket *>(lds_raw);
-  stage_table(tbl, p.table, p.table_bytes);
-  __syncthreads();
 
   const FramePlanes f = p.frames[blockIdx.y];
   const float n = p.table_scale;
   const uint32_t quads = p.width >> 2;
   const uint32_t row_pairs = p.height >> 1;
+  const uint32_t threads = blockDim.x;
+  bool table_ready = false;
 
   for (uint32_t rp = blockIdx.x; rp < row_pairs; rp += gridDim.x) {
     const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
@@ -149,11 +161,11 @@ decode_nv12_quads(const DecodeParams p) {
     uint8_t *o0 = f.out + static_cast<size_t>(2 * rp) * p.out_stride;
     uint8_t *o1 = o0 + p.out_stride;
 
-    for (uint32_t q0 = 0; q0 < quads; q0 += kBlockThreads * UNROLL) {
+    for (uint32_t q0 = 0; q0 < quads; q0 += threads * UNROLL) {
       uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t q = q0 + u * kBlockThreads + threadIdx.x;
+        const uint32_t q = q0 + u * threads + threadIdx.x;
         if (q < quads) {
           ya[u] = *reinterpret_cast<const uint32_t *>(y0 + 4 * q);
           yb[u] = *reinterpret_cast<const uint32_t *>(y1 + 4 * q);
@@ -164,9 +176,14 @@ decode_nv12_quads(const DecodeParams p) {
           }
         }
       }
+      if (!table_ready) {  // uniform across the workgroup
+        stage_table(tbl, p.table, p.table_bytes);
+        __syncthreads();
+        table_ready = true;
+      }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t q = q0 + u * kBlockThreads + threadIdx.x;
+        const uint32_t q = q0 + u * threads + threadIdx.x;
         if (q < quads) {
           const Chroma c0 = chroma_terms(byte_of(cw[u], 0), byte_of(cw[u], 1));
           const Chroma c1 = chroma_terms(byte_of(cw[u], 2), byte_of(cw[u], 3));
@@ -335,22 +352,23 @@ decode_nv12_half(const DecodeParams p) {
 // host-callable launchers (no HIP types in the signature beyond hipStream_t)
 // ---------------------------------------------------------------------------
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
-                          uint32_t grid_x, hipStream_t stream) {
+                          uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
   const dim3 grid(grid_x, static_cast<uint32_t>(frames), 1);
-  const dim3 block(kBlockThreads, 1, 1);
   const size_t lds = p.table_bytes;
   if (variant == kVariantQuads) {
+    const dim3 block(block_threads, 1, 1);
     if (has_alpha) {
-      hipLaunchKernelGGL((decode_nv12_quads<true, true, 2>), grid, block, lds, stream, p);
+      hipLaunchKernelGGL((decode_nv12_quads<true, true>), grid, block, lds, stream, p);
       return "decode_nv12_quads<alpha>";
     }
     if (nontemporal) {
-      hipLaunchKernelGGL((decode_nv12_quads<false, true, 4>), grid, block, lds, stream, p);
+      hipLaunchKernelGGL((decode_nv12_quads<false, true>), grid, block, lds, stream, p);
       return "decode_nv12_quads<nt>";
     }
-    hipLaunchKernelGGL((decode_nv12_quads<false, false, 4>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((decode_nv12_quads<false, false>), grid, block, lds, stream, p);
     return "decode_nv12_quads";
   }
+  const dim3 block(kBlockThreads, 1, 1);
   if (has_alpha) {
     hipLaunchKernelGGL((decode_nv12_blocks<true>), grid, block, lds, stream, p);
     return "decode_nv12_blocks<alpha>";

@@ -432,9 +432,12 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
   p.alpha_word = dec->alpha_fill << 24;
 
   hipStream_t s = pick(dec->ctx, stream);
-  const uint32_t gx = grid_x_for(dec->ctx, p.height / 2, count);
+  // Fast path: one workgroup per row pair (dispatch order == address order, see the kernel's
+  // header comment).  General path keeps the grid-strided shape.
+  const uint32_t gx = fast ? p.height / 2 : grid_x_for(dec->ctx, p.height / 2, count);
+  const uint32_t threads = env_int("BT709HIP_BLOCK_THREADS", static_cast<int>(quads_block_threads(p.width)));
   tl_kernel_name = launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
-                                 dec->nontemporal, gx, s);
+                                 dec->nontemporal, gx, threads, s);
   HIP_TRY(hipGetLastError());
   if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));  // .m:486-489
   return BT709HIP_OK;

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_gpu.sh output directory (gpurun_out/prof_<tag>/) into the
+small, committed files under profiles/:
+
+    profiles/<round>_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+    profiles/<round>_<tag>_pmc.json           per-launch means of every counter collected
+    profiles/pmc_traffic.json                 {workload: {"hbm_bytes_per_launch": ...}} read by bench.py
+
+HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB and
+come from separate --pmc passes; on gfx950 FETCH_SIZE reports half the bytes of a coalesced
+streaming read, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  The
+decode kernels read with 4-byte-per-lane loads, a width the guide calls uncalibrated, so
+the doubled figure is cross-checked against the algorithmic read bytes and both are kept.
+
+    python tools/pmc_summary.py gpurun_out/prof_4k r01 4k
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    src, rnd, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    kernel_filter = sys.argv[4] if len(sys.argv) > 4 else "decode_nv12"
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+
+    stats = os.path.join(src, "trace", "trace_kernel_stats.csv")
+    if os.path.exists(stats):
+        shutil.copy(stats, os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (rnd, tag)))
+
+    # durations from the kernel trace of the --stats run
+    durs = []
+    kt = os.path.join(src, "trace", "trace_kernel_trace.csv")
+    if os.path.exists(kt):
+        for r in csv.DictReader(open(kt)):
+            if kernel_filter in r["Kernel_Name"]:
+                durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    counters = collections.defaultdict(list)
+    meta = {}
+    for d in sorted(os.listdir(src)):
+        f = os.path.join(src, d, "pmc_counter_collection.csv")
+        if not (d.startswith("pmc_") and os.path.exists(f)):
+            continue
+        for r in csv.DictReader(open(f)):
+            if kernel_filter in r["Kernel_Name"]:
+                counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size",
+                                          "VGPR_Count", "SGPR_Count")}
+    mean = {k: sum(v) / len(v) for k, v in counters.items()}
+    summary = {"source": os.path.relpath(src, ROOT), "kernel": meta, "launches_profiled": {k: len(v) for k, v in counters.items()},
+               "per_launch_mean": mean}
+    if durs:
+        durs.sort()
+        summary["duration_ns"] = {"n": len(durs), "mean": sum(durs) / len(durs), "median": durs[len(durs) // 2],
+                                  "min": durs[0], "max": durs[-1]}
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        fetch_raw = mean["FETCH_SIZE"] * 1024
+        write = mean["WRITE_SIZE"] * 1024
+        summary["hbm"] = {
+            "fetch_bytes_raw": fetch_raw,
+            "fetch_bytes_gfx950_corrected": 2 * fetch_raw,
+            "write_bytes": write,
+            "hbm_bytes_per_launch": 2 * fetch_raw + write,
+            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); "
+                    "WRITE_SIZE exact for 16 B/lane stores",
+        }
+    if "TCC_HIT_sum" in mean and "TCC_MISS_sum" in mean:
+        summary["l2_hit_rate"] = mean["TCC_HIT_sum"] / (mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"])
+    if "GRBM_GUI_ACTIVE" in mean and durs:
+        summary["effective_clock_ghz"] = mean["GRBM_GUI_ACTIVE"] / 8 / (summary["duration_ns"]["mean"])
+    if "SQ_LDS_IDX_ACTIVE" in mean and "SQ_INSTS_LDS" in mean:
+        summary["lds_cycles_per_instruction"] = mean["SQ_LDS_IDX_ACTIVE"] / mean["SQ_INSTS_LDS"]
+    json.dump(summary, open(os.path.join(out_dir, "%s_%s_pmc.json" % (rnd, tag)), "w"), indent=1)
+
+    if "hbm" in summary:
+        tpath = os.path.join(out_dir, "pmc_traffic.json")
+        traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        traffic[tag] = {"hbm_bytes_per_launch": summary["hbm"]["hbm_bytes_per_launch"], "round": rnd,
+                        "fetch_bytes_corrected": summary["hbm"]["fetch_bytes_gfx950_corrected"],
+                        "write_bytes": summary["hbm"]["write_bytes"]}
+        json.dump(traffic, open(tpath, "w"), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
