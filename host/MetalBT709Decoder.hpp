@@ -1,0 +1,219 @@
+// C++ host-side mirror of the reference's decode operator over the C ABI
+// (include/bt709hip.h).  Header-only; link with -lbt709hip.
+//
+// The reference's host side is Objective-C:
+//     Renderer/MetalRenderContext.h:17-105    @interface MetalRenderContext
+//     Renderer/MetalBT709Decoder.h:21-72      @interface MetalBT709Decoder
+// There is no Objective-C runtime on this platform, so the same interface is kept in
+// C++: same class and property names, same argument meaning, BOOL-style results
+// (true/false, diagnostics through lastStatus()/bt709hip_strerror instead of NSLog).
+// INTEGRATION.md shows the Objective-C binding a maintainer of the reference would add.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../include/bt709hip.h"
+
+namespace bt709 {
+
+enum MetalBT709Gamma {  // Renderer/MetalBT709Decoder.h:15-19
+  MetalBT709GammaApple = BT709HIP_GAMMA_APPLE,
+  MetalBT709GammaSRGB = BT709HIP_GAMMA_SRGB,
+  MetalBT709GammaLinear = BT709HIP_GAMMA_LINEAR,
+  MetalBT709GammaITU709 = BT709HIP_GAMMA_ITU709  // extension
+};
+
+// Device + queue holder (MetalRenderContext.h:17-43).
+class MetalRenderContext {
+ public:
+  int device = 0;  // HIP ordinal; MTLCreateSystemDefaultDevice() ~ 0
+
+  ~MetalRenderContext() { bt709hip_context_destroy(ctx_); }
+  MetalRenderContext() = default;
+  MetalRenderContext(const MetalRenderContext &) = delete;
+  MetalRenderContext &operator=(const MetalRenderContext &) = delete;
+
+  // -setupMetal: idempotent (MetalRenderContext.m:36-74)
+  bool setupMetal() {
+    if (ctx_) return true;
+    lastStatus_ = bt709hip_context_create(device, &ctx_);
+    return lastStatus_ == BT709HIP_OK;
+  }
+  bt709hip_context *handle() const { return ctx_; }
+  int lastStatus() const { return lastStatus_; }
+
+  // commandQueue / -commandBuffer: a HIP stream per in-flight frame
+  void *newCommandBuffer() {
+    void *s = nullptr;
+    lastStatus_ = bt709hip_stream_create(ctx_, &s);
+    return s;
+  }
+  void releaseCommandBuffer(void *s) { bt709hip_stream_destroy(ctx_, s); }
+  bool waitUntilCompleted(void *s) { return bt709hip_stream_synchronize(ctx_, s) == BT709HIP_OK; }
+
+ private:
+  bt709hip_context *ctx_ = nullptr;
+  int lastStatus_ = BT709HIP_OK;
+};
+
+// 420v buffer in device memory + the two attachments the decoder validates
+// (createCoreVideoYCbCrBuffer / setBT709Attributes, BGRAToBT709Converter.m:412-494).
+class CVPixelBuffer {
+ public:
+  CVPixelBuffer(MetalRenderContext &ctx, int width, int height) : ctx_(ctx) {
+    f_.width = width;
+    f_.height = height;
+    f_.y_stride = f_.cbcr_stride = (static_cast<size_t>(width) + 15) / 16 * 16;
+    const size_t ysz = (f_.y_stride * height + 255) / 256 * 256;
+    void *p = nullptr;
+    if (bt709hip_malloc(ctx.handle(), ysz + f_.cbcr_stride * (height / 2) + 16, &p) == BT709HIP_OK) {
+      base_ = p;
+      f_.y = p;
+      f_.cbcr = static_cast<uint8_t *>(p) + ysz;
+    }
+  }
+  ~CVPixelBuffer() { bt709hip_free(ctx_.handle(), base_); }
+  CVPixelBuffer(const CVPixelBuffer &) = delete;
+  CVPixelBuffer &operator=(const CVPixelBuffer &) = delete;
+
+  void setBT709Attributes() {
+    f_.matrix = BT709HIP_MATRIX_ITU_R_709_2;
+    f_.transfer = BT709HIP_TRANSFER_ITU_R_709_2;
+  }
+  void setAttachments(int matrix, int transfer) {
+    f_.matrix = matrix;
+    f_.transfer = transfer;
+  }
+  // copyBT709ToCoreVideo (BGRAToBT709Converter.m:1042-1099): packed (Cr<<16)|(Cb<<8)|Y words in;
+  // CbCr of even columns, every row writing into row/2 (the odd row's pair remains).
+  bool copyBT709ToCoreVideo(const uint32_t *packed) {
+    const int w = f_.width, h = f_.height;
+    std::vector<uint8_t> y(static_cast<size_t>(w) * h), c(static_cast<size_t>(w) * (h / 2));
+    for (int row = 0; row < h; ++row)
+      for (int col = 0; col < w; ++col) {
+        const uint32_t p = packed[static_cast<size_t>(row) * w + col];
+        y[static_cast<size_t>(row) * w + col] = static_cast<uint8_t>(p & 0xFF);
+        if ((col & 1) == 0) {
+          c[static_cast<size_t>(row / 2) * w + col] = static_cast<uint8_t>((p >> 8) & 0xFF);
+          c[static_cast<size_t>(row / 2) * w + col + 1] = static_cast<uint8_t>((p >> 16) & 0xFF);
+        }
+      }
+    return uploadPlanes(y.data(), c.data());
+  }
+  bool uploadPlanes(const uint8_t *y, const uint8_t *cbcr) {
+    const size_t w = static_cast<size_t>(f_.width);
+    int rc = bt709hip_upload(ctx_.handle(), const_cast<void *>(f_.y), f_.y_stride, y, w, w, f_.height, nullptr);
+    if (rc == BT709HIP_OK)
+      rc = bt709hip_upload(ctx_.handle(), const_cast<void *>(f_.cbcr), f_.cbcr_stride, cbcr, w, w, f_.height / 2,
+                           nullptr);
+    if (rc == BT709HIP_OK) rc = bt709hip_stream_synchronize(ctx_.handle(), nullptr);
+    return rc == BT709HIP_OK;
+  }
+  const bt709hip_frame *frame() const { return &f_; }
+
+ private:
+  MetalRenderContext &ctx_;
+  bt709hip_frame f_{};
+  void *base_ = nullptr;
+};
+
+// BGRA8Unorm_sRGB render target (-makeBGRATexture / -getBGRATexturePixels, MetalRenderContext.h:62-105)
+class BGRATexture {
+ public:
+  BGRATexture(MetalRenderContext &ctx, int width, int height) : ctx_(ctx) {
+    s_.width = width;
+    s_.height = height;
+    s_.stride = (static_cast<size_t>(width) * 4 + 15) / 16 * 16;
+    bt709hip_malloc(ctx.handle(), s_.stride * height + 16, &s_.bgra);
+  }
+  ~BGRATexture() { bt709hip_free(ctx_.handle(), s_.bgra); }
+  BGRATexture(const BGRATexture &) = delete;
+  BGRATexture &operator=(const BGRATexture &) = delete;
+
+  std::vector<uint32_t> getBGRATexturePixels() const {
+    std::vector<uint32_t> px(static_cast<size_t>(s_.width) * s_.height);
+    if (px.empty()) return px;
+    const size_t row = static_cast<size_t>(s_.width) * 4;
+    bt709hip_download(ctx_.handle(), px.data(), row, s_.bgra, s_.stride, row, s_.height, nullptr);
+    bt709hip_stream_synchronize(ctx_.handle(), nullptr);
+    return px;
+  }
+  const bt709hip_surface *surface() const { return &s_; }
+  int width() const { return s_.width; }
+  int height() const { return s_.height; }
+
+ private:
+  MetalRenderContext &ctx_;
+  bt709hip_surface s_{};
+};
+
+class MetalBT709Decoder {
+ public:
+  MetalRenderContext *metalRenderContext = nullptr;
+  MetalBT709Gamma gamma = MetalBT709GammaApple;  // "Defaults to apple gamma"
+  bool useComputeRenderer = true;                // only a compute path exists here
+  bool hasAlphaChannel = false;
+  int alphaFill = 0xFF;
+
+  ~MetalBT709Decoder() {
+    if (metalRenderContext && metalRenderContext->handle()) bt709hip_decoder_destroy(dec_);
+  }
+  MetalBT709Decoder() = default;
+  MetalBT709Decoder(const MetalBT709Decoder &) = delete;
+  MetalBT709Decoder &operator=(const MetalBT709Decoder &) = delete;
+
+  int lastStatus() const { return lastStatus_; }
+
+  // - (BOOL) setupMetal  (MetalBT709Decoder.m:46-104)
+  bool setupMetal() {
+    if (metalRenderContext == nullptr) return fail(BT709HIP_ERR_NOT_SETUP);
+    if (!metalRenderContext->setupMetal()) return fail(BT709HIP_ERR_NO_DEVICE);
+    if (dec_) return true;  // second call is a nop
+    int rc = bt709hip_decoder_create(metalRenderContext->handle(), gamma, hasAlphaChannel ? 1 : 0, &dec_);
+    if (rc == BT709HIP_OK) rc = bt709hip_decoder_set_alpha_fill(dec_, alphaFill);
+    if (rc == BT709HIP_OK) rc = bt709hip_decoder_setup(dec_);
+    if (rc != BT709HIP_OK) return fail(rc);
+    gamma = static_cast<MetalBT709Gamma>(bt709hip_decoder_get_gamma(dec_));  // alpha forces sRGB (.m:165-169)
+    return true;
+  }
+
+  // - (BOOL) decodeBT709:alphaPixelBuffer:bgraSRGBTexture:commandBuffer:renderPassDescriptor:
+  //          renderWidth:renderHeight:waitUntilCompleted:   (MetalBT709Decoder.h:65-72)
+  // renderPassDescriptor has no HIP meaning (a drawable is just another BGRATexture).
+  bool decodeBT709(const CVPixelBuffer *yCbCrInputTexture, const CVPixelBuffer *alphaPixelBuffer,
+                   const BGRATexture *bgraSRGBTexture, void *commandBuffer, const void * /*renderPassDescriptor*/,
+                   int renderWidth, int renderHeight, bool waitUntilCompleted) {
+    if (!setupMetal()) return false;
+    if (yCbCrInputTexture == nullptr || bgraSRGBTexture == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
+    const int rc = bt709hip_decode(dec_, yCbCrInputTexture->frame(),
+                                   alphaPixelBuffer ? alphaPixelBuffer->frame() : nullptr,
+                                   bgraSRGBTexture->surface(), renderWidth, renderHeight, commandBuffer,
+                                   waitUntilCompleted ? 1 : 0);
+    return rc == BT709HIP_OK ? ok() : fail(rc);
+  }
+
+  // decode + MetalScaleRenderContext -renderScaled: fused for the exact 2:1 ratio
+  bool decodeBT709Scaled(const CVPixelBuffer *in, const BGRATexture *out, void *commandBuffer,
+                         bool waitUntilCompleted) {
+    if (!setupMetal()) return false;
+    const int rc = bt709hip_decode_half(dec_, in->frame(), out->surface(), commandBuffer, waitUntilCompleted ? 1 : 0);
+    return rc == BT709HIP_OK ? ok() : fail(rc);
+  }
+
+ private:
+  bool ok() {
+    lastStatus_ = BT709HIP_OK;
+    return true;
+  }
+  bool fail(int rc) {
+    lastStatus_ = rc;
+    std::fprintf(stderr, "MetalBT709Decoder: %s\n", bt709hip_strerror(rc));  // NSLog in the reference
+    return false;
+  }
+  bt709hip_decoder *dec_ = nullptr;
+  int lastStatus_ = BT709HIP_OK;
+};
+
+}  // namespace bt709

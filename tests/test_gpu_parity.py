@@ -325,3 +325,17 @@ def test_output_padding_is_untouched(gh):
     _capi.check(ctx.lib.bt709hip_download(ctx.handle, raw.ctypes.data, stride, tex.ptr, stride, stride, h, None))
     ctx._sync(None)
     assert (raw[:, w * 4:] == 0xAB).all()
+
+
+def test_cpp_host_mirror_reference_vectors(gh, vectors, tmp_path):
+    """The C++ twin of the reference's Metal decode test (host/decoder_selftest.cpp over
+    host/MetalBT709Decoder.hpp) on the 28 reference vectors."""
+    import subprocess
+    from test_host_cpu import build_cpp_selftest
+    exe = build_cpp_selftest(tmp_path)
+    args = []
+    for r in vectors["metal_decode"]:
+        args += [str(v) for v in r["ycbcr"] + r["rgb_out"]]
+    res = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "28 vectors, 0 failures" in res.stdout

@@ -173,13 +173,13 @@ def test_isa_has_no_fused_multiply_add(asm):
 
 
 def test_isa_memory_shape(asm):
-    body = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1ELi4E")
-    assert body.count("global_store_dwordx4") == 8          # 4 quads x 2 rows, 16 B per lane
-    assert re.search(r"global_store_dwordx4 .* nt", body)   # streaming (non-temporal) stores
-    assert body.count("global_load_dword ") + body.count("global_load_dword\t") >= 12
+    body = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1EE")
+    assert body.count("global_store_dwordx4") == 4          # 2 quads x 2 rows, 16 B per lane
+    assert len(re.findall(r"global_store_dwordx4 .* nt", body)) == 4  # streaming (non-temporal) stores
+    assert len(re.findall(r"global_load_dword\s", body)) == 6  # 2 quads x (2 luma rows + 1 CbCr row)
     assert "ds_read_b64" in body                            # one 8-byte table bucket per lookup
     assert "scratch_" not in body                           # no spills
-    meta = re.search(r"\.name:\s+_ZN5bt70917decode_nv12_quadsILb0ELb1ELi4E.*?\.vgpr_count:\s+(\d+)", asm, flags=re.S)
+    meta = re.search(r"\.name:\s+_ZN5bt70917decode_nv12_quadsILb0ELb1EE.*?\.vgpr_count:\s+(\d+)", asm, flags=re.S)
     assert meta and int(meta.group(1)) <= 64                # 8 waves per SIMD
 
 
@@ -235,3 +235,23 @@ def test_bench_geometry():
     assert g["bytes_per_frame"] == 82_944_000 and (g["OW"], g["OH"]) == (3840, 2160)
     g = bench.geometry("4k", 40, 32)
     assert g["ring"] == 32 and g["launches"] == 1
+
+
+def build_cpp_selftest(tmpdir):
+    """g++ compile + link of the C++ host mirror against the C-ABI library."""
+    exe = os.path.join(str(tmpdir), "decoder_selftest")
+    libdir = os.path.dirname(build.LIB)
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", os.path.join(ROOT, "host", "decoder_selftest.cpp"),
+                        "-L" + libdir, "-lbt709hip", "-Wl,-rpath," + libdir, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_cpp_host_mirror_builds_and_fails_without_gpu(lib, tmp_path):
+    exe = build_cpp_selftest(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, "235", "128", "128", "255", "255", "255"], capture_output=True, text=True)
+    assert r.returncode == 3  # setupMetal() false: no device, no fallback
