@@ -18,7 +18,10 @@ ASM = os.path.join(HERE, "build", "bt709_kernels.s")
 SOURCES = ["bt709_kernels.hip", "bt709hip.cpp", "transfer_tables.cpp"]
 HEADERS = ["bt709_kernels.h", "bt709_constants.h", "transfer_tables.h"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC", "-Wall"]
+# -fno-slp-vectorize: hipcc otherwise pairs scalar f32 multiplies/adds into v_pk_* ops, which run
+# at half rate on gfx950 and need v_mov shuffles to build their operand pairs (measured: 458 VALU
+# instructions of which 66 packed + 55 moves, vs 427 single-rate ones without it, per 16 pixels).
+FLAGS = ["-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-Wall"]
 
 
 def _hipcc():

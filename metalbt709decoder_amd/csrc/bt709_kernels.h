@@ -35,6 +35,8 @@ struct DecodeParams {
   uint32_t table2_bytes;
   float table_scale;   // N of `table`
   float table2_scale;  // N of `table2`
+  // BT709.h:389-397 matrix entries times table_scale (exact: power-of-two scaling)
+  float m_y, m_cr_r, m_cb_g, m_cr_g, m_cb_b;
   uint32_t width;      // luma (source) dimensions
   uint32_t height;
   uint32_t y_stride;
@@ -46,23 +48,32 @@ struct DecodeParams {
 
 // Launchers return the kernel's name (static string) for profiling; launch errors
 // are read by the caller with hipGetLastError().
+// decode: variant kVariantQuads -> grid = (grid_x tiles, H/2, frames) x block_threads;
+//         variant kVariantBlocks -> grid = (grid_x, frames) x kBlockThreads, grid-strided.
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
+// half: grid = (grid_x, H/2 output rows, frames) x block_threads.
+const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
+                               uint32_t block_threads, hipStream_t stream);
 
-// Fast-path workgroup size for a frame width: ceil(quads / kQuadsPerLane) rounded up to a
-// whole wave, within [64, kMaxBlockThreads].  3840 -> 480, 1920 -> 256, 7680 -> 512.
+// Fast-path launch geometry for a frame width: tiles (workgroups) per row pair and the
+// workgroup size -- ceil(quads per tile / kQuadsPerLane) rounded up to a whole wave.
+//   3840 -> 1 tile x 480 threads, 1920 -> 1 x 256, 7680 -> 2 x 480.
+inline uint32_t quads_tiles(uint32_t width) {
+  const uint32_t quads = width / 4, cap = kMaxBlockThreads * kQuadsPerLane;
+  return quads == 0 ? 1 : (quads + cap - 1) / cap;
+}
 inline uint32_t quads_block_threads(uint32_t width) {
-  const uint32_t quads = width / 4;
-  uint32_t t = (quads + kQuadsPerLane - 1) / kQuadsPerLane;
+  const uint32_t tiles = quads_tiles(width);
+  const uint32_t per_tile = (width / 4 + tiles - 1) / tiles;
+  uint32_t t = (per_tile + kQuadsPerLane - 1) / kQuadsPerLane;
   t = (t + 63) / 64 * 64;
   if (t < 64) t = 64;
   if (t > static_cast<uint32_t>(kMaxBlockThreads)) t = kMaxBlockThreads;
   return t;
 }
-const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
-                               hipStream_t stream);
 
-// Raises the dynamic-LDS cap of the half kernels (two tables can exceed 64 KiB).
+// Raises the dynamic-LDS cap of the kernels (tables can exceed the 64 KiB default).
 hipError_t prepare_kernels();
 
 }  // namespace bt709

@@ -21,20 +21,31 @@
 // operation: this file is compiled with -ffp-contract=off and the arithmetic goes
 // through __fmul_rn/__fadd_rn so no FMA can form (a CPU test greps the ISA).
 //
-// The transfer step is an exact bucketed threshold table (transfer_tables.h)
-// staged in LDS: q = (uint)(x*N); byte = base[q] + (x >= edge[q]).
+// SCALED DOMAIN.  The five matrix constants arrive pre-multiplied by N, the
+// (power-of-two) bucket count of the transfer table.  Binary floating-point
+// rounding commutes with scaling by a power of two (no overflow or subnormal is
+// reachable here: the smallest non-zero magnitude is ~8e-4, the largest ~2.2*N), so
+// every product and sum below is exactly N times the reference's value, bit for
+// bit in the mantissa.  That removes one multiply per lookup (q = (uint)xs directly)
+// and the explicit saturate: v_cvt_u32_f32 clamps negatives to bucket 0 (byte 0),
+// and the table simply extends to 2.25*N (any reachable R,G,B is < 2.15), where
+// every bucket answers 255.  See transfer_tables.h for the table itself:
+//       byte = base[q] + (xs >= edge_scaled[q]),  q = (uint)xs.
 //
 // Memory plan (HBM-bound: 1.5 B read + 4 B written per pixel, no reuse between
 // workgroups, so no XCD-aware remap is needed):
-//   * a lane owns a 4-wide x 2-high pixel quad-pair: one dword of each luma row,
-//     one dword of CbCr (two Cb,Cr pairs, each shared by a 2x2 block -- chroma is
+//   * a lane owns 4-wide x 2-high pixel "quads": one dword of each luma row, one
+//     dword of CbCr (two Cb,Cr pairs, each shared by a 2x2 block -- chroma is
 //     REPLICATED, not interpolated: AAPLShaders.metal:350, BGRAToBT709Converter.m:
-//     267-277) and two 16-byte stores;
+//     267-277) and two 16-byte non-temporal stores per quad;
 //   * consecutive lanes own consecutive quads of the same row pair, so a wave reads
 //     3 x 256 contiguous bytes and writes 2 x 1 KiB contiguous, fully coalesced;
-//   * one workgroup per row pair (grid.x = H/2), blockDim sized so a lane owns two
-//     quads; all loads of the row pair are issued before any arithmetic;
-//   * grid.y = frame: a batch of independent frames is one launch.
+//   * grid = (tiles per row pair, row pairs, frames): one short-lived workgroup per
+//     tile, dispatched in address order (x fastest).  Measured: long-lived
+//     grid-strided workgroups lose ~20 % of the bandwidth to a scattered DRAM stream,
+//     and every extra instruction per wave costs about its share of run time, so the
+//     kernels have no loops and no integer divisions;
+//   * the tile's global loads are issued before the table is staged into LDS.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -46,9 +57,10 @@ namespace bt709 {
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float byte_of(uint32_t w, int i) {
-  return static_cast<float>((w >> (8 * i)) & 0xffu);  // -> v_cvt_f32_ubyte{i}
+  return static_cast<float>((w >> (8 * i)) & 0xffu);  // -> v_cvt_f32_ubyte{i} / sdwa
 }
 
 // (v - off) * (1/255f): integer-valued floats subtract exactly, so this equals the
@@ -57,56 +69,70 @@ __device__ __forceinline__ float centre_norm(float v, float off) {
   return __fmul_rn(__fadd_rn(v, -off), kInv255);
 }
 
-__device__ __forceinline__ float sat(float v) {
-  // saturatef (Renderer/sRGB.h:18-27); v is never NaN here
-  return __builtin_fminf(__builtin_fmaxf(v, 0.0f), 1.0f);
-}
-
-__device__ __forceinline__ uint32_t lookup(const TransferBucket *__restrict__ tbl, float n, float x) {
-  const uint32_t q = static_cast<uint32_t>(__fmul_rn(x, n));  // exact: n is a power of two
+// xs = N * x.  Returns the output byte of the decoder's gamma for pre-gamma value x.
+__device__ __forceinline__ uint32_t lookup(const TransferBucket *__restrict__ tbl, float xs) {
+#if defined(BT709_LAB_NO_LDS)  // tools/decode_lab only: price of the LDS lookups (wrong output)
+  return static_cast<uint32_t>(xs) + (xs >= 77.0f ? 1u : 0u) + (tbl == nullptr ? 1u : 0u);
+#else
+  const uint32_t q = static_cast<uint32_t>(xs);  // floor for xs >= 0, 0 for xs < 0
   const TransferBucket e = tbl[q];
-  return e.base + (x >= e.edge ? 1u : 0u);
+  return e.base + (xs >= e.edge ? 1u : 0u);
+#endif
 }
 
-struct Chroma {  // the four Cb/Cr products of one 2x2 block
+// (A<<24)|(R<<16)|(G<<8)|B in two VALU ops: v_perm_b32 places R and G (bytes 2 and 1, zeros
+// elsewhere), v_or3_b32 merges B and the alpha word.
+__device__ __forceinline__ uint32_t pack_bgra(uint32_t R, uint32_t G, uint32_t B, uint32_t alpha_word) {
+  // selector bytes, MSB first: 0x0c -> 0x00, 0x04 -> byte 0 of the first operand (R),
+  // 0x00 -> byte 0 of the second operand (G), 0x0c -> 0x00
+  const uint32_t rg = __builtin_amdgcn_perm(R, G, 0x0c04000cu);
+  return rg | B | alpha_word;
+}
+
+struct Matrix {  // BT709.h:389-397 times N (DecodeParams::m_*)
+  float y, cr_r, cb_g, cr_g, cb_b;
+};
+
+struct Chroma {  // the four scaled Cb/Cr products of one 2x2 block
   float cr_r, cb_g, cr_g, cb_b;
 };
 
-__device__ __forceinline__ Chroma chroma_terms(float cb, float cr) {
+__device__ __forceinline__ Chroma chroma_terms(const Matrix &m, float cb, float cr) {
   const float cbn = centre_norm(cb, 128.0f);
   const float crn = centre_norm(cr, 128.0f);
   Chroma c;
-  c.cr_r = __fmul_rn(crn, kMCrR);
-  c.cb_g = __fmul_rn(cbn, kMCbG);
-  c.cr_g = __fmul_rn(crn, kMCrG);
-  c.cb_b = __fmul_rn(cbn, kMCbB);
+  c.cr_r = __fmul_rn(crn, m.cr_r);
+  c.cb_g = __fmul_rn(cbn, m.cb_g);
+  c.cr_g = __fmul_rn(crn, m.cr_g);
+  c.cb_b = __fmul_rn(cbn, m.cb_b);
   return c;
 }
 
-// saturated non-linear R,G,B of one pixel
-__device__ __forceinline__ void pixel_rgbn(float ybyte, const Chroma &c, float &r, float &g, float &b) {
-  const float yv = __fmul_rn(centre_norm(ybyte, 16.0f), kMY);
-  r = sat(__fadd_rn(yv, c.cr_r));
-  g = sat(__fadd_rn(__fadd_rn(yv, c.cb_g), c.cr_g));
-  b = sat(__fadd_rn(yv, c.cb_b));
+// scaled (N x) non-linear R,G,B of one pixel, NOT saturated
+__device__ __forceinline__ void pixel_rgbs(const Matrix &m, float ybyte, const Chroma &c, float &r, float &g,
+                                           float &b) {
+  const float yv = __fmul_rn(centre_norm(ybyte, 16.0f), m.y);
+  r = __fadd_rn(yv, c.cr_r);
+  g = __fadd_rn(__fadd_rn(yv, c.cb_g), c.cr_g);
+  b = __fadd_rn(yv, c.cb_b);
 }
 
-__device__ __forceinline__ uint32_t decode_px(const TransferBucket *__restrict__ tbl, float n, float ybyte,
+__device__ __forceinline__ uint32_t decode_px(const TransferBucket *__restrict__ tbl, const Matrix &m, float ybyte,
                                               const Chroma &c, uint32_t alpha_word) {
   float r, g, b;
-  pixel_rgbn(ybyte, c, r, g, b);
-  const uint32_t R = lookup(tbl, n, r);
-  const uint32_t G = lookup(tbl, n, g);
-  const uint32_t B = lookup(tbl, n, b);
-  return alpha_word | (R << 16) | (G << 8) | B;
+  pixel_rgbs(m, ybyte, c, r, g, b);
+  const uint32_t R = lookup(tbl, r);
+  const uint32_t G = lookup(tbl, g);
+  const uint32_t B = lookup(tbl, b);
+  return pack_bgra(R, G, B, alpha_word);
 }
 
 // linear alpha sample -> byte: R channel of the matrix with Cb=Cr=128, then plain
-// 8-bit quantisation (AAPLShaders.metal:249-271; CPU twin BT709.h:466-513).  `ident`
-// is the identity-gamma table, which is exactly round(x*255).
-__device__ __forceinline__ uint32_t decode_alpha(const TransferBucket *__restrict__ ident, float n, float abyte) {
-  const float yv = __fmul_rn(centre_norm(abyte, 16.0f), kMY);
-  return lookup(ident, n, sat(yv)) << 24;
+// 8-bit quantisation (AAPLShaders.metal:249-271; CPU twin BT709.h:466-513).  An alpha
+// decoder always runs the identity (sRGB-mode) table, which is exactly round(x*255).
+__device__ __forceinline__ uint32_t decode_alpha(const TransferBucket *__restrict__ ident, const Matrix &m,
+                                                 float abyte) {
+  return lookup(ident, __fmul_rn(centre_norm(abyte, 16.0f), m.y)) << 24;
 }
 
 __device__ __forceinline__ void stage_table(void *lds, const void *src, uint32_t bytes) {
@@ -121,23 +147,22 @@ __device__ __forceinline__ void store16(uint8_t *p, u32x4 v) {
   else *reinterpret_cast<u32x4 *>(p) = v;
 }
 
+template <bool NT>
+__device__ __forceinline__ void store8(uint8_t *p, u32x2 v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p));
+  else *reinterpret_cast<u32x2 *>(p) = v;
+}
+
+__device__ __forceinline__ Matrix matrix_of(const DecodeParams &p) {
+  return Matrix{p.m_y, p.m_cr_r, p.m_cb_g, p.m_cr_g, p.m_cb_b};
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
 // Fast path.  Preconditions (checked by the host shim): width % 4 == 0; y, cbcr,
 // alpha pointers and strides 4-byte aligned; output pointer and stride 16-byte
-// aligned.
-//
-// Launch shape (measured, tools/kernel_lab.hip, DESIGN.md "launch geometry"): ONE
-// workgroup per row pair and per frame -- grid = (H/2, frames) -- with
-// blockDim = ceil(W/8) rounded up to a wave (480 threads for 3840), so that every
-// lane owns UNROLL = 2 quads.  Workgroups are dispatched in address order and live
-// for one burst of loads and one burst of stores; long-lived grid-stride workgroups
-// scatter the DRAM access stream and lose ~20 % of the bandwidth.  The loops below
-// still stride by gridDim/blockDim, so any launch shape is correct.
-//
-// The frame loads of the first tile are issued BEFORE the transfer table is staged
-// into LDS, so the table's L2 round trip hides under the HBM latency of the tile.
+// aligned.  grid = (tiles, H/2, frames); a tile is blockDim * kQuadsPerLane quads.
 // ---------------------------------------------------------------------------
 template <bool HAS_ALPHA, bool NT>
 __global__ void __launch_bounds__(kMaxBlockThreads)
@@ -146,74 +171,77 @@ decode_nv12_quads(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   TransferBucket *tbl = reinterpret_cast<TransferBucket *>(lds_raw);
 
-  const FramePlanes f = p.frames[blockIdx.y];
-  const float n = p.table_scale;
+  const FramePlanes f = p.frames[blockIdx.z];
+  const Matrix m = matrix_of(p);
   const uint32_t quads = p.width >> 2;
-  const uint32_t row_pairs = p.height >> 1;
-  const uint32_t threads = blockDim.x;
-  bool table_ready = false;
+  const uint32_t rp = blockIdx.y;
+  const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
 
-  for (uint32_t rp = blockIdx.x; rp < row_pairs; rp += gridDim.x) {
-    const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
-    const uint8_t *y1 = y0 + p.y_stride;
-    const uint8_t *cc = f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride;
-    const uint8_t *a0 = HAS_ALPHA ? f.alpha + static_cast<size_t>(2 * rp) * p.alpha_stride : nullptr;
-    uint8_t *o0 = f.out + static_cast<size_t>(2 * rp) * p.out_stride;
-    uint8_t *o1 = o0 + p.out_stride;
+  const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
+  const uint8_t *y1 = y0 + p.y_stride;
+  const uint8_t *cc = f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride;
+  const uint8_t *a0 = HAS_ALPHA ? f.alpha + static_cast<size_t>(2 * rp) * p.alpha_stride : nullptr;
+  uint8_t *o0 = f.out + static_cast<size_t>(2 * rp) * p.out_stride;
+  uint8_t *o1 = o0 + p.out_stride;
 
-    for (uint32_t q0 = 0; q0 < quads; q0 += threads * UNROLL) {
-      uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
+  // Straight-line code: lanes past the row's end load a clamped (valid) quad and only their
+  // stores are predicated.  A divergent `if (q < quads)` around the arithmetic made hipcc put
+  // s_waitcnt vmcnt(0) at the join, i.e. each wave waited for the write acknowledgement of its
+  // first quad's stores before touching its second quad.
+  uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t q = q0 + u * threads + threadIdx.x;
-        if (q < quads) {
-          ya[u] = *reinterpret_cast<const uint32_t *>(y0 + 4 * q);
-          yb[u] = *reinterpret_cast<const uint32_t *>(y1 + 4 * q);
-          cw[u] = *reinterpret_cast<const uint32_t *>(cc + 4 * q);
-          if (HAS_ALPHA) {
-            aa[u] = *reinterpret_cast<const uint32_t *>(a0 + 4 * q);
-            ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
-          }
-        }
-      }
-      if (!table_ready) {  // uniform across the workgroup
-        stage_table(tbl, p.table, p.table_bytes);
-        __syncthreads();
-        table_ready = true;
-      }
+  for (int u = 0; u < UNROLL; ++u) {
+    const uint32_t q = min(q0 + u * blockDim.x, quads - 1);
+    ya[u] = *reinterpret_cast<const uint32_t *>(y0 + 4 * q);
+    yb[u] = *reinterpret_cast<const uint32_t *>(y1 + 4 * q);
+    cw[u] = *reinterpret_cast<const uint32_t *>(cc + 4 * q);
+    if (HAS_ALPHA) {
+      aa[u] = *reinterpret_cast<const uint32_t *>(a0 + 4 * q);
+      ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
+    }
+  }
+  stage_table(tbl, p.table, p.table_bytes);  // after the tile's loads are in flight
+  __syncthreads();
+  // Pin every loaded dword here: hipcc then waits for all of the tile's loads once, before any
+  // store is issued, instead of emitting s_waitcnt vmcnt(0) between the first quad's stores and
+  // the second quad's arithmetic (which would wait for the stores' write acknowledgements).
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t q = q0 + u * threads + threadIdx.x;
-        if (q < quads) {
-          const Chroma c0 = chroma_terms(byte_of(cw[u], 0), byte_of(cw[u], 1));
-          const Chroma c1 = chroma_terms(byte_of(cw[u], 2), byte_of(cw[u], 3));
-          u32x4 top, bot;
-          uint32_t al[8];
+  for (int u = 0; u < UNROLL; ++u) {
+    asm volatile("" : "+v"(ya[u]), "+v"(yb[u]), "+v"(cw[u]));
+    if (HAS_ALPHA) asm volatile("" : "+v"(aa[u]), "+v"(ab[u]));
+  }
+
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            al[i] = HAS_ALPHA ? decode_alpha(tbl, n, byte_of(aa[u], i)) : p.alpha_word;
-            al[4 + i] = HAS_ALPHA ? decode_alpha(tbl, n, byte_of(ab[u], i)) : p.alpha_word;
-          }
-          top.x = decode_px(tbl, n, byte_of(ya[u], 0), c0, al[0]);
-          top.y = decode_px(tbl, n, byte_of(ya[u], 1), c0, al[1]);
-          top.z = decode_px(tbl, n, byte_of(ya[u], 2), c1, al[2]);
-          top.w = decode_px(tbl, n, byte_of(ya[u], 3), c1, al[3]);
-          bot.x = decode_px(tbl, n, byte_of(yb[u], 0), c0, al[4]);
-          bot.y = decode_px(tbl, n, byte_of(yb[u], 1), c0, al[5]);
-          bot.z = decode_px(tbl, n, byte_of(yb[u], 2), c1, al[6]);
-          bot.w = decode_px(tbl, n, byte_of(yb[u], 3), c1, al[7]);
-          store16<NT>(o0 + 16 * q, top);
-          store16<NT>(o1 + 16 * q, bot);
-        }
-      }
+  for (int u = 0; u < UNROLL; ++u) {
+    const uint32_t q = q0 + u * blockDim.x;
+    const Chroma c0 = chroma_terms(m, byte_of(cw[u], 0), byte_of(cw[u], 1));
+    const Chroma c1 = chroma_terms(m, byte_of(cw[u], 2), byte_of(cw[u], 3));
+    u32x4 top, bot;
+    uint32_t al[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      al[i] = HAS_ALPHA ? decode_alpha(tbl, m, byte_of(aa[u], i)) : p.alpha_word;
+      al[4 + i] = HAS_ALPHA ? decode_alpha(tbl, m, byte_of(ab[u], i)) : p.alpha_word;
+    }
+    top.x = decode_px(tbl, m, byte_of(ya[u], 0), c0, al[0]);
+    top.y = decode_px(tbl, m, byte_of(ya[u], 1), c0, al[1]);
+    top.z = decode_px(tbl, m, byte_of(ya[u], 2), c1, al[2]);
+    top.w = decode_px(tbl, m, byte_of(ya[u], 3), c1, al[3]);
+    bot.x = decode_px(tbl, m, byte_of(yb[u], 0), c0, al[4]);
+    bot.y = decode_px(tbl, m, byte_of(yb[u], 1), c0, al[5]);
+    bot.z = decode_px(tbl, m, byte_of(yb[u], 2), c1, al[6]);
+    bot.w = decode_px(tbl, m, byte_of(yb[u], 3), c1, al[7]);
+    if (q < quads) {
+      store16<NT>(o0 + 16 * q, top);
+      store16<NT>(o1 + 16 * q, bot);
     }
   }
 }
 
 // ---------------------------------------------------------------------------
 // General path: any even width/height, any stride, byte-aligned planes, 4-byte
-// aligned output.  One lane per 2x2 block.  Correctness first; used for ragged or
-// misaligned frames only.
+// aligned output.  One lane per 2x2 block, grid-strided over row pairs.  Correctness
+// first; used for ragged or misaligned frames only.
 // ---------------------------------------------------------------------------
 template <bool HAS_ALPHA>
 __global__ void __launch_bounds__(kBlockThreads)
@@ -224,7 +252,7 @@ decode_nv12_blocks(const DecodeParams p) {
   __syncthreads();
 
   const FramePlanes f = p.frames[blockIdx.y];
-  const float n = p.table_scale;
+  const Matrix m = matrix_of(p);
   const uint32_t bw = p.width >> 1;
   const uint32_t row_pairs = p.height >> 1;
 
@@ -235,20 +263,20 @@ decode_nv12_blocks(const DecodeParams p) {
     uint32_t *o0 = reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(2 * rp) * p.out_stride);
     uint32_t *o1 = reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(2 * rp + 1) * p.out_stride);
     for (uint32_t bx = threadIdx.x; bx < bw; bx += kBlockThreads) {
-      const Chroma c = chroma_terms(static_cast<float>(cc[2 * bx]), static_cast<float>(cc[2 * bx + 1]));
+      const Chroma c = chroma_terms(m, static_cast<float>(cc[2 * bx]), static_cast<float>(cc[2 * bx + 1]));
       uint32_t al[4] = {p.alpha_word, p.alpha_word, p.alpha_word, p.alpha_word};
       if (HAS_ALPHA) {
         const uint8_t *a0 = f.alpha + static_cast<size_t>(2 * rp) * p.alpha_stride;
         const uint8_t *a1 = a0 + p.alpha_stride;
-        al[0] = decode_alpha(tbl, n, static_cast<float>(a0[2 * bx]));
-        al[1] = decode_alpha(tbl, n, static_cast<float>(a0[2 * bx + 1]));
-        al[2] = decode_alpha(tbl, n, static_cast<float>(a1[2 * bx]));
-        al[3] = decode_alpha(tbl, n, static_cast<float>(a1[2 * bx + 1]));
+        al[0] = decode_alpha(tbl, m, static_cast<float>(a0[2 * bx]));
+        al[1] = decode_alpha(tbl, m, static_cast<float>(a0[2 * bx + 1]));
+        al[2] = decode_alpha(tbl, m, static_cast<float>(a1[2 * bx]));
+        al[3] = decode_alpha(tbl, m, static_cast<float>(a1[2 * bx + 1]));
       }
-      o0[2 * bx] = decode_px(tbl, n, static_cast<float>(y0[2 * bx]), c, al[0]);
-      o0[2 * bx + 1] = decode_px(tbl, n, static_cast<float>(y0[2 * bx + 1]), c, al[1]);
-      o1[2 * bx] = decode_px(tbl, n, static_cast<float>(y1[2 * bx]), c, al[2]);
-      o1[2 * bx + 1] = decode_px(tbl, n, static_cast<float>(y1[2 * bx + 1]), c, al[3]);
+      o0[2 * bx] = decode_px(tbl, m, static_cast<float>(y0[2 * bx]), c, al[0]);
+      o0[2 * bx + 1] = decode_px(tbl, m, static_cast<float>(y0[2 * bx + 1]), c, al[1]);
+      o1[2 * bx] = decode_px(tbl, m, static_cast<float>(y1[2 * bx]), c, al[2]);
+      o1[2 * bx + 1] = decode_px(tbl, m, static_cast<float>(y1[2 * bx + 1]), c, al[3]);
     }
   }
 }
@@ -257,93 +285,126 @@ decode_nv12_blocks(const DecodeParams p) {
 // Fused decode + exact 2:1 downscale (pass 1 + pass 2 of the reference).  A 2x2
 // luma block shares one CbCr sample and becomes one output pixel.  Two-pass
 // equivalent arithmetic: each decoded byte is linearised as the sRGB8 sampler
-// would (table returns the linear float directly), the four are averaged
-// (((a+b)+c)+d)*0.25f, then sRGB-encoded and quantised through the LINEAR-mode
-// table (second LDS table).
-// A lane owns 4 output pixels (8 luma columns x 2 rows): two dwordx2 luma loads,
-// one dwordx2 chroma load, one 16-byte store.  Preconditions: width % 8 == 0,
-// planes/strides 8-byte aligned, output 16-byte aligned; otherwise the shim uses
-// decode_half_blocks.
+// would (the decode-side table returns the linear float directly), the four are
+// averaged (((a+b)+c)+d)*0.25f, then sRGB-encoded and quantised through the
+// LINEAR-mode table (second LDS table, same scaled-domain lookup).
+//
+// WIDE: a lane owns one quad = 4x2 source pixels = 2 output pixels (two dword luma
+// loads, one dword CbCr load, one 8-byte store); grid = (tiles, H/2, frames) as in
+// the 1:1 kernel.  Preconditions: width % 4 == 0, planes/strides 4-byte aligned,
+// output 8-byte aligned.  !WIDE: one lane per output pixel, byte loads, any layout.
 // ---------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ float lookup_linear(const TransferBucketLinear *__restrict__ tbl, float n, float x) {
-  const uint32_t q = static_cast<uint32_t>(__fmul_rn(x, n));
-  const TransferBucketLinear e = tbl[q];
-  return x >= e.edge ? e.lin_above : e.lin_below;
+// The decode-side table of the rescale kernel is NOT extended past N (16-byte entries: an
+// extended LINEAR-mode table would not fit LDS next to the encode table), so xs is clamped.
+__device__ __forceinline__ uint32_t linear_index(float n, float &xs) {
+  xs = __builtin_fminf(xs, n);
+  return static_cast<uint32_t>(xs);
 }
 
-__device__ __forceinline__ uint32_t half_px(const TransferBucketLinear *__restrict__ dec, float dn,
-                                            const TransferBucket *__restrict__ enc, float en,
-                                            float y00, float y01, float y10, float y11, const Chroma &c,
-                                            uint32_t alpha_word) {
-  float r[4], g[4], b[4];
-  pixel_rgbn(y00, c, r[0], g[0], b[0]);
-  pixel_rgbn(y01, c, r[1], g[1], b[1]);
-  pixel_rgbn(y10, c, r[2], g[2], b[2]);
-  pixel_rgbn(y11, c, r[3], g[3], b[3]);
-  float lr[4], lg[4], lb[4];
+// One 16-byte bucket {edge, lin_below, lin_above, base} with a single ds_read_b128 (the caller
+// pins whole vectors, which keeps hipcc from narrowing the read to the much slower ds_read_b96).
+__device__ __forceinline__ u32x4 linear_fetch(const TransferBucketLinear *__restrict__ tbl, uint32_t q) {
+  return reinterpret_cast<const u32x4 *>(tbl)[q];
+}
+
+__device__ __forceinline__ float linear_select(const u32x4 &e, float xs) {
+  return xs >= __uint_as_float(e.x) ? __uint_as_float(e.z) : __uint_as_float(e.y);
+}
+
+__device__ __forceinline__ uint32_t half_px(const TransferBucketLinear *__restrict__ dec, float dn, const Matrix &m,
+                                            const TransferBucket *__restrict__ enc, float en, float y00, float y01,
+                                            float y10, float y11, const Chroma &c, uint32_t alpha_word) {
+  float x[12];  // r0..r3, g0..g3, b0..b3 of the four source pixels
+  pixel_rgbs(m, y00, c, x[0], x[4], x[8]);
+  pixel_rgbs(m, y01, c, x[1], x[5], x[9]);
+  pixel_rgbs(m, y10, c, x[2], x[6], x[10]);
+  pixel_rgbs(m, y11, c, x[3], x[7], x[11]);
+  uint32_t q[12];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lr[i] = lookup_linear(dec, dn, r[i]);
-    lg[i] = lookup_linear(dec, dn, g[i]);
-    lb[i] = lookup_linear(dec, dn, b[i]);
+  for (int i = 0; i < 12; ++i) q[i] = linear_index(dn, x[i]);
+  float lin[12];
+  // six buckets in flight at a time (24 VGPRs): enough to cover the LDS latency, few enough
+  // to stay at 8 waves per SIMD
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u32x4 e[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[i] = linear_fetch(dec, q[6 * h + i]);
+    asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait for all six
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lin[6 * h + i] = linear_select(e[i], x[6 * h + i]);
   }
-  const float mr = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]), 0.25f);
-  const float mg = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]), 0.25f);
-  const float mb = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]), 0.25f);
-  const uint32_t R = lookup(enc, en, mr);
-  const uint32_t G = lookup(enc, en, mg);
-  const uint32_t B = lookup(enc, en, mb);
-  return alpha_word | (R << 16) | (G << 8) | B;
+  const float *lr = lin, *lg = lin + 4, *lb = lin + 8;
+  // (((a+b)+c)+d) * 0.25f, then scale into the encode table's domain (both exact powers of two)
+  const float k = __fmul_rn(0.25f, en);
+  const float mr = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]), k);
+  const float mg = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]), k);
+  const float mb = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]), k);
+  const uint32_t R = lookup(enc, mr);
+  const uint32_t G = lookup(enc, mg);
+  const uint32_t B = lookup(enc, mb);
+  return pack_bgra(R, G, B, alpha_word);
 }
 
 }  // namespace
 
 template <bool NT, bool WIDE>
-__global__ void __launch_bounds__(kBlockThreads)
+__global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_half(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   TransferBucketLinear *dec = reinterpret_cast<TransferBucketLinear *>(lds_raw);
   TransferBucket *enc = reinterpret_cast<TransferBucket *>(lds_raw + p.table_bytes);
-  stage_table(dec, p.table, p.table_bytes);
-  stage_table(enc, p.table2, p.table2_bytes);
-  __syncthreads();
 
-  const FramePlanes f = p.frames[blockIdx.y];
-  const float dn = p.table_scale, en = p.table2_scale;
-  const uint32_t out_w = p.width >> 1;
-  const uint32_t out_rows = p.height >> 1;
+  const FramePlanes f = p.frames[blockIdx.z];
+  const Matrix m = matrix_of(p);
+  const float en = p.table2_scale, dn = p.table_scale;
+  const uint32_t orow = blockIdx.y;
+  const uint8_t *y0 = f.y + static_cast<size_t>(2 * orow) * p.y_stride;
+  const uint8_t *y1 = y0 + p.y_stride;
+  const uint8_t *cc = f.cbcr + static_cast<size_t>(orow) * p.cbcr_stride;
+  uint8_t *o = f.out + static_cast<size_t>(orow) * p.out_stride;
 
-  for (uint32_t orow = blockIdx.x; orow < out_rows; orow += gridDim.x) {
-    const uint8_t *y0 = f.y + static_cast<size_t>(2 * orow) * p.y_stride;
-    const uint8_t *y1 = y0 + p.y_stride;
-    const uint8_t *cc = f.cbcr + static_cast<size_t>(orow) * p.cbcr_stride;
-    uint8_t *o = f.out + static_cast<size_t>(orow) * p.out_stride;
-    if (WIDE) {
-      const uint32_t groups = out_w >> 2;  // 4 output pixels per lane
-      for (uint32_t gq = threadIdx.x; gq < groups; gq += kBlockThreads) {
-        const uint2 ya = *reinterpret_cast<const uint2 *>(y0 + 8 * gq);
-        const uint2 yb = *reinterpret_cast<const uint2 *>(y1 + 8 * gq);
-        const uint2 cw = *reinterpret_cast<const uint2 *>(cc + 8 * gq);
-        const Chroma c0 = chroma_terms(byte_of(cw.x, 0), byte_of(cw.x, 1));
-        const Chroma c1 = chroma_terms(byte_of(cw.x, 2), byte_of(cw.x, 3));
-        const Chroma c2 = chroma_terms(byte_of(cw.y, 0), byte_of(cw.y, 1));
-        const Chroma c3 = chroma_terms(byte_of(cw.y, 2), byte_of(cw.y, 3));
-        u32x4 v;
-        v.x = half_px(dec, dn, enc, en, byte_of(ya.x, 0), byte_of(ya.x, 1), byte_of(yb.x, 0), byte_of(yb.x, 1), c0, p.alpha_word);
-        v.y = half_px(dec, dn, enc, en, byte_of(ya.x, 2), byte_of(ya.x, 3), byte_of(yb.x, 2), byte_of(yb.x, 3), c1, p.alpha_word);
-        v.z = half_px(dec, dn, enc, en, byte_of(ya.y, 0), byte_of(ya.y, 1), byte_of(yb.y, 0), byte_of(yb.y, 1), c2, p.alpha_word);
-        v.w = half_px(dec, dn, enc, en, byte_of(ya.y, 2), byte_of(ya.y, 3), byte_of(yb.y, 2), byte_of(yb.y, 3), c3, p.alpha_word);
-        store16<NT>(o + 16 * gq, v);
-      }
-    } else {
-      for (uint32_t ox = threadIdx.x; ox < out_w; ox += kBlockThreads) {
-        const Chroma c = chroma_terms(static_cast<float>(cc[2 * ox]), static_cast<float>(cc[2 * ox + 1]));
-        reinterpret_cast<uint32_t *>(o)[ox] =
-            half_px(dec, dn, enc, en, static_cast<float>(y0[2 * ox]), static_cast<float>(y0[2 * ox + 1]),
-                    static_cast<float>(y1[2 * ox]), static_cast<float>(y1[2 * ox + 1]), c, p.alpha_word);
-      }
+  if (WIDE) {
+    constexpr int UNROLL = kQuadsPerLane;
+    const uint32_t quads = p.width >> 2;
+    const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
+    uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t q = min(q0 + u * blockDim.x, quads - 1);  // clamped load, predicated store (see 1:1 kernel)
+      ya[u] = *reinterpret_cast<const uint32_t *>(y0 + 4 * q);
+      yb[u] = *reinterpret_cast<const uint32_t *>(y1 + 4 * q);
+      cw[u] = *reinterpret_cast<const uint32_t *>(cc + 4 * q);
+    }
+    stage_table(dec, p.table, p.table_bytes);
+    stage_table(enc, p.table2, p.table2_bytes);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("" : "+v"(ya[u]), "+v"(yb[u]), "+v"(cw[u]));  // see 1:1 kernel
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t q = q0 + u * blockDim.x;
+      const Chroma c0 = chroma_terms(m, byte_of(cw[u], 0), byte_of(cw[u], 1));
+      const Chroma c1 = chroma_terms(m, byte_of(cw[u], 2), byte_of(cw[u], 3));
+      u32x2 v;
+      v.x = half_px(dec, dn, m, enc, en, byte_of(ya[u], 0), byte_of(ya[u], 1), byte_of(yb[u], 0), byte_of(yb[u], 1), c0,
+                    p.alpha_word);
+      v.y = half_px(dec, dn, m, enc, en, byte_of(ya[u], 2), byte_of(ya[u], 3), byte_of(yb[u], 2), byte_of(yb[u], 3), c1,
+                    p.alpha_word);
+      if (q < quads) store8<NT>(o + 8 * q, v);
+    }
+  } else {
+    stage_table(dec, p.table, p.table_bytes);
+    stage_table(enc, p.table2, p.table2_bytes);
+    __syncthreads();
+    const uint32_t out_w = p.width >> 1;
+    for (uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x; ox < out_w; ox += gridDim.x * blockDim.x) {
+      const Chroma c = chroma_terms(m, static_cast<float>(cc[2 * ox]), static_cast<float>(cc[2 * ox + 1]));
+      reinterpret_cast<uint32_t *>(o)[ox] =
+          half_px(dec, dn, m, enc, en, static_cast<float>(y0[2 * ox]), static_cast<float>(y0[2 * ox + 1]),
+                  static_cast<float>(y1[2 * ox]), static_cast<float>(y1[2 * ox + 1]), c, p.alpha_word);
     }
   }
 }
@@ -353,9 +414,10 @@ decode_nv12_half(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
-  const dim3 grid(grid_x, static_cast<uint32_t>(frames), 1);
   const size_t lds = p.table_bytes;
   if (variant == kVariantQuads) {
+    // grid_x = tiles per row pair
+    const dim3 grid(grid_x, p.height / 2, static_cast<uint32_t>(frames));
     const dim3 block(block_threads, 1, 1);
     if (has_alpha) {
       hipLaunchKernelGGL((decode_nv12_quads<true, true>), grid, block, lds, stream, p);
@@ -368,6 +430,8 @@ const char *launch_decode(const DecodeParams &p, int frames, int variant, bool h
     hipLaunchKernelGGL((decode_nv12_quads<false, false>), grid, block, lds, stream, p);
     return "decode_nv12_quads";
   }
+  // grid_x = workgroups per frame, grid-strided over row pairs
+  const dim3 grid(grid_x, static_cast<uint32_t>(frames), 1);
   const dim3 block(kBlockThreads, 1, 1);
   if (has_alpha) {
     hipLaunchKernelGGL((decode_nv12_blocks<true>), grid, block, lds, stream, p);
@@ -379,20 +443,27 @@ const char *launch_decode(const DecodeParams &p, int frames, int variant, bool h
 
 hipError_t prepare_kernels() {
   const int cap = 160 * 1024;  // gfx950: 160 KiB LDS per workgroup
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_nv12_half<true, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_nv12_half<false, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_nv12_half<false, false>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  const void *fns[] = {
+      reinterpret_cast<const void *>(&decode_nv12_half<true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_half<false, true>),
+      reinterpret_cast<const void *>(&decode_nv12_half<false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_quads<true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_quads<false, true>),
+      reinterpret_cast<const void *>(&decode_nv12_quads<false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_blocks<true>),
+      reinterpret_cast<const void *>(&decode_nv12_blocks<false>),
+  };
+  for (const void *fn : fns) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
-                               hipStream_t stream) {
-  const dim3 grid(grid_x, static_cast<uint32_t>(frames), 1);
-  const dim3 block(kBlockThreads, 1, 1);
+                               uint32_t block_threads, hipStream_t stream) {
+  const dim3 grid(grid_x, p.height / 2, static_cast<uint32_t>(frames));
+  const dim3 block(block_threads, 1, 1);
   const size_t lds = static_cast<size_t>(p.table_bytes) + p.table2_bytes;
   if (wide) {
     if (nontemporal) hipLaunchKernelGGL((decode_nv12_half<true, true>), grid, block, lds, stream, p);

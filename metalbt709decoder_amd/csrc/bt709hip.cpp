@@ -122,6 +122,17 @@ int upload_table(const void *src, size_t bytes, void **dst) {
   return BT709HIP_OK;
 }
 
+// Matrix of BT709.h:389-397 scaled by the table's bucket count (a power of two: exact).
+void set_matrix(DecodeParams *p, uint32_t n) {
+  const float fn = static_cast<float>(n);
+  p->table_scale = fn;
+  p->m_y = kMY * fn;
+  p->m_cr_r = kMCrR * fn;
+  p->m_cb_g = kMCbG * fn;
+  p->m_cr_g = kMCrG * fn;
+  p->m_cb_b = kMCbB * fn;
+}
+
 uint32_t grid_x_for(const bt709hip_context *ctx, uint32_t rows, int frames) {
   uint32_t per_frame = static_cast<uint32_t>(ctx->grid_blocks / (frames > 0 ? frames : 1));
   if (per_frame < 1) per_frame = 1;
@@ -378,9 +389,11 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
     return BT709HIP_ERR_UNSUPPORTED;
   dec->table_n = t.n;
   dec->table_bytes = static_cast<uint32_t>(t.buckets.size() * sizeof(TransferBucket));
-  dec->table_linear_bytes = static_cast<uint32_t>(t.buckets_linear.size() * sizeof(TransferBucketLinear));
+  // rescale kernel: unit part only (it clamps), see lookup_linear
+  dec->table_linear_bytes = static_cast<uint32_t>(t.unit_entries * sizeof(TransferBucketLinear));
   dec->encode_n = enc.n;
-  dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
+  // the encode side of the rescale only ever sees means in [0,1]: upload the unit part only
+  dec->encode_bytes = static_cast<uint32_t>(enc.unit_entries * sizeof(TransferBucket));
   if (int rc = upload_table(t.buckets.data(), dec->table_bytes, &dec->d_table)) return rc;
   if (int rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &dec->d_table_linear)) return rc;
   if (int rc = upload_table(enc.buckets.data(), dec->encode_bytes, &dec->d_encode)) return rc;
@@ -422,7 +435,7 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
 
   p.table = dec->d_table;
   p.table_bytes = dec->table_bytes;
-  p.table_scale = static_cast<float>(dec->table_n);
+  set_matrix(&p, dec->table_n);
   p.width = static_cast<uint32_t>(f0.width);
   p.height = static_cast<uint32_t>(f0.height);
   p.y_stride = static_cast<uint32_t>(f0.y_stride);
@@ -432,10 +445,10 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
   p.alpha_word = dec->alpha_fill << 24;
 
   hipStream_t s = pick(dec->ctx, stream);
-  // Fast path: one workgroup per row pair (dispatch order == address order, see the kernel's
-  // header comment).  General path keeps the grid-strided shape.
-  const uint32_t gx = fast ? p.height / 2 : grid_x_for(dec->ctx, p.height / 2, count);
-  const uint32_t threads = env_int("BT709HIP_BLOCK_THREADS", static_cast<int>(quads_block_threads(p.width)));
+  // Fast path: one short-lived workgroup per tile of a row pair, dispatched in address order
+  // (see the kernel file's header).  General path keeps the grid-strided shape.
+  const uint32_t gx = fast ? quads_tiles(p.width) : grid_x_for(dec->ctx, p.height / 2, count);
+  const uint32_t threads = quads_block_threads(p.width);
   tl_kernel_name = launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
                                  dec->nontemporal, gx, threads, s);
   HIP_TRY(hipGetLastError());
@@ -468,7 +481,7 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   const bt709hip_surface &o0 = outs[0];
   DecodeParams p;
   std::memset(&p, 0, sizeof p);
-  bool wide = (f0.width % 8) == 0 && (f0.y_stride % 8) == 0 && (f0.cbcr_stride % 8) == 0 && (o0.stride % 16) == 0;
+  bool wide = (f0.y_stride % 4) == 0 && (f0.cbcr_stride % 4) == 0 && (o0.stride % 8) == 0;
   for (int i = 0; i < count; ++i) {
     if ((frames[i].width & 3) || (frames[i].height & 3)) return BT709HIP_ERR_ODD_DIMENSIONS;
     if (int rc = validate(dec, &frames[i], nullptr, &outs[i], frames[i].width / 2, frames[i].height / 2,
@@ -480,13 +493,13 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
     p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
     p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
     p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
-    wide = wide && aligned(frames[i].y, 8) && aligned(frames[i].cbcr, 8) && aligned(outs[i].bgra, 16);
+    wide = wide && aligned(frames[i].y, 4) && aligned(frames[i].cbcr, 4) && aligned(outs[i].bgra, 8);
   }
   if (f0.width == 0 || f0.height == 0) return BT709HIP_OK;
 
   p.table = dec->d_table_linear;
   p.table_bytes = dec->table_linear_bytes;
-  p.table_scale = static_cast<float>(dec->table_n);
+  set_matrix(&p, dec->table_n);
   p.table2 = dec->d_encode;
   p.table2_bytes = dec->encode_bytes;
   p.table2_scale = static_cast<float>(dec->encode_n);
@@ -498,8 +511,10 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   p.alpha_word = dec->alpha_fill << 24;
 
   hipStream_t s = pick(dec->ctx, stream);
-  const uint32_t gx = grid_x_for(dec->ctx, p.height / 2, count);
-  tl_kernel_name = launch_decode_half(p, count, wide, dec->nontemporal, gx, s);
+  // wide: same tiling as the 1:1 kernel over the source width; narrow: 256 output pixels per workgroup
+  const uint32_t gx = wide ? quads_tiles(p.width) : (p.width / 2 + kBlockThreads - 1) / kBlockThreads;
+  const uint32_t threads = wide ? quads_block_threads(p.width) : kBlockThreads;
+  tl_kernel_name = launch_decode_half(p, count, wide, dec->nontemporal, gx, threads, s);
   HIP_TRY(hipGetLastError());
   if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;

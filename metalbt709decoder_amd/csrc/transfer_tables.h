@@ -11,8 +11,12 @@
 // by 255 thresholds.  The kernel wants O(1) lookup, so the thresholds are laid
 // out in N uniform buckets, N a power of two chosen so no bucket holds two
 // thresholds:
-//     byte(x) = bucket[q].base + (x >= bucket[q].edge),   q = (uint)(x * N)
-// x*N is exact (power of two), so q is exact.
+//     byte(x) = bucket[q].base + (xs >= bucket[q].edge),   xs = N * x,  q = (uint)xs
+// The kernels work in the SCALED domain xs = N*x (their matrix constants are pre-multiplied
+// by N; scaling by a power of two commutes with IEEE rounding), so `edge` is stored as
+// N * threshold, and the table extends past N (x > 1, before saturation) with buckets that
+// answer 255, up to kTableReach * N: the largest reachable pre-saturation value is
+// B(Y=255, Cb=255) = 2.1434.  Negative xs convert to bucket 0, whose answer is 0.
 #pragma once
 
 #include <cstdint>
@@ -22,7 +26,9 @@ namespace bt709 {
 
 enum Gamma : int { kGammaApple = 0, kGammaSRGB = 1, kGammaLinear = 2, kGammaITU709 = 3, kGammaCount = 4 };
 
-// One bucket.  `edge` is the single threshold strictly inside the bucket or +inf.
+constexpr float kTableReach = 2.25f;  // table covers xs in [0, kTableReach * N]
+
+// One bucket.  `edge` is N times the single threshold strictly inside the bucket, or +inf.
 struct alignas(8) TransferBucket {
   float edge;
   uint32_t base;
@@ -42,7 +48,8 @@ struct TransferTable {
   int gamma = 0;
   uint32_t n = 0;                        // bucket count N (power of two); table has N + 1 entries
   float thresholds[255];                 // t[k-1] = min { x in [0,1] : byte(x) >= k }
-  std::vector<TransferBucket> buckets;   // N + 1 (+ padding to a 16-byte multiple)
+  uint32_t unit_entries = 0;             // entries covering x in [0,1] (N + 1, padded to 16 bytes)
+  std::vector<TransferBucket> buckets;   // kTableReach * N + 2 entries (+ padding to a 16-byte multiple)
   std::vector<TransferBucketLinear> buckets_linear;  // same buckets, linearised outputs
 };
 

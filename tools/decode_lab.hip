@@ -1,0 +1,137 @@
+// Decode lab: times the PRODUCTION kernels (csrc/bt709_kernels.hip included verbatim) over a
+// ring of 64 distinct 4K frames, several launch shapes, interleaved rounds (median / min).
+// Build variants with -DBT709_LAB_NO_LDS / -DBT709_LAB_NO_CONFLICT to price the LDS lookups.
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 tools/decode_lab.hip \
+//         metalbt709decoder_amd/csrc/transfer_tables.cpp -o tools/bin/decode_lab
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../metalbt709decoder_amd/csrc/bt709_kernels.hip"
+
+#define CK(x)                                                                        \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) {                                                          \
+      std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      std::exit(1);                                                                  \
+    }                                                                                \
+  } while (0)
+
+using namespace bt709;
+
+struct Ring {
+  int W, H, ring, batch;
+  size_t yb, cb, ob, in_stride, out_stride;
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  void *d_table = nullptr;
+  TransferTable tt;
+  std::vector<DecodeParams> params;
+  hipStream_t s;
+  hipEvent_t e0, e1;
+
+  Ring(int w, int h, int ring_, int batch_, int gamma) : W(w), H(h), ring(ring_), batch(batch_) {
+    yb = size_t(W) * H;
+    cb = yb / 2;
+    ob = yb * 4;
+    in_stride = (yb + cb + 255) / 256 * 256;
+    out_stride = ob;
+    CK(hipMalloc(&d_in, in_stride * ring));
+    CK(hipMalloc(&d_out, out_stride * ring));
+    std::vector<uint8_t> h8(in_stride);
+    uint64_t st = 0x709;
+    for (int i = 0; i < ring; ++i) {
+      for (size_t j = 0; j + 8 <= h8.size(); j += 8) {
+        st += 0x9E3779B97F4A7C15ull;
+        uint64_t z = st;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        std::memcpy(&h8[j], &z, 8);
+      }
+      CK(hipMemcpy(d_in + i * in_stride, h8.data(), h8.size(), hipMemcpyHostToDevice));
+    }
+    CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    if (!build_transfer_table(gamma, &tt)) std::exit(2);
+    const size_t tb = tt.buckets.size() * sizeof(TransferBucket);
+    CK(hipMalloc(&d_table, tb));
+    CK(hipMemcpy(d_table, tt.buckets.data(), tb, hipMemcpyHostToDevice));
+    params.resize(ring / batch);
+    for (int l = 0; l < ring / batch; ++l) {
+      DecodeParams &p = params[l];
+      std::memset(&p, 0, sizeof p);
+      for (int i = 0; i < batch; ++i) {
+        uint8_t *base = d_in + size_t(l * batch + i) * in_stride;
+        p.frames[i] = FramePlanes{base, base + yb, nullptr, d_out + size_t(l * batch + i) * out_stride};
+      }
+      p.table = d_table;
+      p.table_bytes = uint32_t(tb);
+      p.table_scale = float(tt.n);
+      p.m_y = kMY * tt.n; p.m_cr_r = kMCrR * tt.n; p.m_cb_g = kMCbG * tt.n; p.m_cr_g = kMCrG * tt.n; p.m_cb_b = kMCbB * tt.n;
+      p.width = W;
+      p.height = H;
+      p.y_stride = W;
+      p.cbcr_stride = W;
+      p.out_stride = W * 4;
+      p.alpha_word = 0xff000000u;
+    }
+  }
+  double bytes_per_launch() const { return double(yb + cb + ob) * batch; }
+  double once(const std::function<void(int)> &fn, int reps) {
+    CK(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r)
+      for (size_t l = 0; l < params.size(); ++l) fn(int(l));
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipGetLastError());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / (reps * params.size());
+  }
+};
+
+struct Variant {
+  std::string name;
+  std::function<void(int)> fn;
+  std::vector<double> ms;
+};
+
+int main(int argc, char **argv) {
+  const int gamma = argc > 1 ? std::atoi(argv[1]) : 0;
+  const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
+  Ring r(3840, 2160, 64, 32, gamma);
+  hipStream_t s = r.s;
+  std::vector<Variant> vs;
+  auto add = [&](const std::string &n, std::function<void(int)> f) { vs.push_back({n, f, {}}); };
+  for (int t : {448, 480, 512})
+    add("quads<nt> grid=(1,1080,32) threads=" + std::to_string(t),
+        [&r, s, t](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, true, 1, t, s); });
+  add("quads<plain> grid=(1,1080,32) threads=480",
+      [&r, s](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, false, 1, 480, s); });
+  add("quads<nt> grid=(2,1080,32) threads=256",
+      [&r, s](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, true, 2, 256, s); });
+
+  // warm the clocks
+  for (int i = 0; i < 3; ++i)
+    for (auto &v : vs) r.once(v.fn, 20);
+  for (int k = 0; k < rounds; ++k)
+    for (auto &v : vs) v.ms.push_back(r.once(v.fn, 50));
+  for (auto &v : vs) {
+    std::sort(v.ms.begin(), v.ms.end());
+    const double med = v.ms[v.ms.size() / 2], mn = v.ms.front();
+    std::printf("%-48s median %8.2f us %7.1f GB/s (%.3f)   best %8.2f us %7.1f GB/s\n", v.name.c_str(), med * 1e3,
+                r.bytes_per_launch() / med / 1e6, r.bytes_per_launch() / med / 1e6 / 8000.0, mn * 1e3,
+                r.bytes_per_launch() / mn / 1e6);
+  }
+  return 0;
+}
