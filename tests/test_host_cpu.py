@@ -152,7 +152,7 @@ def asm():
 
 
 def _kernel_bodies(asm, mangled_fragment):
-    found = re.findall(r"^_ZN5bt709\w*%s\w*:[^\n]*\n(.*?)s_endpgm" % mangled_fragment, asm, flags=re.S | re.M)
+    found = re.findall(r"^_ZN5bt709\w*%s\w*:[^\n]*\n(.*?)^\.Lfunc_end" % mangled_fragment, asm, flags=re.S | re.M)
     assert found, mangled_fragment
     return found
 
@@ -178,6 +178,13 @@ def test_isa_memory_shape(asm):
     assert len(re.findall(r"global_store_dwordx4 .* nt", body)) == 4  # streaming (non-temporal) stores
     assert len(re.findall(r"global_load_dword\s", body)) == 6  # 2 quads x (2 luma rows + 1 CbCr row)
     assert "ds_read_b64" in body                            # one 8-byte table bucket per lookup
+    assert body.count("ds_read_b64") == 48                  # 16 pixels x 3 channels
+    assert not re.search(r"\bv_pk_(mul|add|fma)_f32", body)  # half-rate packed f32 ops stay out (-fno-slp-vectorize)
+    assert "v_perm_b32" in body                             # 2-op BGRA pack
+    # no wait on VMEM between the first quad's stores and the last ones: the wave never waits
+    # for a write acknowledgement
+    first, last = body.index("global_store_dwordx4"), body.rindex("global_store_dwordx4")
+    assert "vmcnt" not in body[first:last]
     assert "scratch_" not in body                           # no spills
     meta = re.search(r"\.name:\s+_ZN5bt70917decode_nv12_quadsILb0ELb1EE.*?\.vgpr_count:\s+(\d+)", asm, flags=re.S)
     assert meta and int(meta.group(1)) <= 64                # 8 waves per SIMD
