@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--gamma", default="apple", choices=sorted(GAMMAS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
+    ap.add_argument("--content", default="random", choices=["random", "smooth"],
+                    help="random: uniform bytes (headline; worst case for the LDS table). smooth: video-like "
+                         "low-frequency planes + small noise (neighbouring pixels share table buckets)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: sleep instead of decoding (control-flow test)")
     return ap.parse_args(argv)
 
@@ -104,8 +107,11 @@ class GpuRunner:
         _capi.check(lib.bt709hip_malloc(h, out_stride * ring, C.byref(self.d_out)), "malloc out")
         self.host_frames = {}
         for i in range(ring):  # uploads are outside the timed region
-            rng = np.random.default_rng(0x709 + i + 1000 * rank)  # full byte range: exercises saturation
-            buf = rng.integers(0, 256, (1, g["y_bytes"] + g["c_bytes"]), dtype=np.uint8)
+            rng = np.random.default_rng(0x709 + i + 1000 * rank)
+            if args.content == "random":  # full byte range: exercises saturation
+                buf = rng.integers(0, 256, (1, g["y_bytes"] + g["c_bytes"]), dtype=np.uint8)
+            else:
+                buf = smooth_frame(np, rng, g, i).reshape(1, -1)
             _capi.check(lib.bt709hip_upload(h, self.d_in.value + i * in_stride, buf.shape[1], buf.ctypes.data,
                                             buf.shape[1], buf.shape[1], 1, None), "upload")
             _capi.check(lib.bt709hip_stream_synchronize(h, None))
@@ -196,6 +202,21 @@ class DryRunner:
         return "dry-run"
 
 
+def smooth_frame(np, rng, g, i):
+    """Video-like synthetic frame: low-frequency luma/chroma fields plus +-2 noise, video-legal range."""
+    W, H = g["W"], g["H"]
+    xx = np.arange(W, dtype=np.float32)[None, :]
+    yy = np.arange(H, dtype=np.float32)[:, None]
+    y = 126 + 95 * np.sin(xx / 97.0 + i) * np.cos(yy / 61.0 + 0.5 * i) + rng.integers(-2, 3, (H, W))
+    cx, cy = xx[:, ::2], yy[::2]
+    cb = 128 + 80 * np.sin(cx / 151.0 + 0.3 * i) * np.sin(cy / 83.0) + rng.integers(-2, 3, (H // 2, W // 2))
+    cr = 128 + 80 * np.cos(cx / 131.0) * np.sin(cy / 113.0 + 0.7 * i) + rng.integers(-2, 3, (H // 2, W // 2))
+    c = np.empty((H // 2, W), np.uint8)
+    c[:, 0::2] = np.clip(cb, 16, 240).astype(np.uint8)
+    c[:, 1::2] = np.clip(cr, 16, 240).astype(np.uint8)
+    return np.concatenate([np.clip(y, 16, 235).astype(np.uint8).reshape(-1), c.reshape(-1)])
+
+
 def split_planes(buf, g):
     y = buf[:g["y_bytes"]].reshape(g["H"], g["W"])
     c = buf[g["y_bytes"]:].reshape(g["H"] // 2, g["W"])
@@ -271,10 +292,11 @@ def main(argv=None):
         "data": "synthetic",
         "config": {
             "workload": "%dx%d NV12 BT.709 -> %dx%d BGRA8 sRGB, gamma=%s%s; per GPU a ring of %d distinct frames "
-                        "(uniform random bytes, seed 0x709+i) resident in HBM; one step = the whole ring = "
+                        "(%s, seed 0x709+i) resident in HBM; one step = the whole ring = "
                         "%d launches x %d frames"
                         % (g["W"], g["H"], g["OW"], g["OH"], args.gamma, ", fused 2:1 rescale" if g["half"] else "",
-                           g["ring"], g["launches"], g["per_launch"]),
+                           g["ring"], "uniform random bytes" if args.content == "random" else "smooth video-like planes",
+                           g["launches"], g["per_launch"]),
             "frames_per_step_per_gpu": g["ring"],
             "sharding": "independent frames per GPU, no collective",
             "device": runner.device,

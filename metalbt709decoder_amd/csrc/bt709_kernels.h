@@ -73,6 +73,14 @@ inline uint32_t quads_block_threads(uint32_t width) {
   return t;
 }
 
+// Row pairs stacked in one workgroup (blockDim.y): only when one tile spans the row and the
+// row needs few threads, so the workgroup still has up to kMaxBlockThreads threads.
+inline uint32_t quads_rows_per_block(uint32_t block_threads, uint32_t tiles) {
+  if (tiles != 1 || block_threads == 0) return 1;
+  const uint32_t by = kMaxBlockThreads / block_threads;
+  return by < 1 ? 1 : by;
+}
+
 // Raises the dynamic-LDS cap of the kernels (tables can exceed the 64 KiB default).
 hipError_t prepare_kernels();
 

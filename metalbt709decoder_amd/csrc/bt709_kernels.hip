@@ -138,7 +138,8 @@ __device__ __forceinline__ uint32_t decode_alpha(const TransferBucket *__restric
 __device__ __forceinline__ void stage_table(void *lds, const void *src, uint32_t bytes) {
   u32x4 *d = reinterpret_cast<u32x4 *>(lds);
   const u32x4 *s = reinterpret_cast<const u32x4 *>(src);
-  for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+  const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
+  for (uint32_t i = tid; i < bytes / 16; i += nthreads) d[i] = s[i];
 }
 
 template <bool NT>
@@ -174,7 +175,11 @@ decode_nv12_quads(const DecodeParams p) {
   const FramePlanes f = p.frames[blockIdx.z];
   const Matrix m = matrix_of(p);
   const uint32_t quads = p.width >> 2;
-  const uint32_t rp = blockIdx.y;
+  const uint32_t row_pairs = p.height >> 1;
+  // blockDim.y > 1 only for narrow frames: a workgroup then covers blockDim.y consecutive row
+  // pairs so that it still has ~8 waves (1920-wide: 256 x 2)
+  const uint32_t rp_raw = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t rp = min(rp_raw, row_pairs - 1);
   const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
 
   const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
@@ -231,7 +236,7 @@ decode_nv12_quads(const DecodeParams p) {
     bot.y = decode_px(tbl, m, byte_of(yb[u], 1), c0, al[5]);
     bot.z = decode_px(tbl, m, byte_of(yb[u], 2), c1, al[6]);
     bot.w = decode_px(tbl, m, byte_of(yb[u], 3), c1, al[7]);
-    if (q < quads) {
+    if (q < quads && rp_raw < row_pairs) {
       store16<NT>(o0 + 16 * q, top);
       store16<NT>(o1 + 16 * q, bot);
     }
@@ -298,6 +303,11 @@ namespace {
 
 // The decode-side table of the rescale kernel is NOT extended past N (16-byte entries: an
 // extended LINEAR-mode table would not fit LDS next to the encode table), so xs is clamped.
+#ifndef BT709_HALF_BATCH
+#define BT709_HALF_BATCH 6
+#endif
+constexpr int kHalfBatch = BT709_HALF_BATCH;
+
 __device__ __forceinline__ uint32_t linear_index(float n, float &xs) {
   xs = __builtin_fminf(xs, n);
   return static_cast<uint32_t>(xs);
@@ -325,16 +335,16 @@ __device__ __forceinline__ uint32_t half_px(const TransferBucketLinear *__restri
 #pragma unroll
   for (int i = 0; i < 12; ++i) q[i] = linear_index(dn, x[i]);
   float lin[12];
-  // six buckets in flight at a time (24 VGPRs): enough to cover the LDS latency, few enough
-  // to stay at 8 waves per SIMD
+  // kHalfBatch buckets in flight at a time: enough to cover the LDS latency without costing occupancy
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    u32x4 e[6];
+  for (int h = 0; h < 12 / kHalfBatch; ++h) {
+    u32x4 e[kHalfBatch];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) e[i] = linear_fetch(dec, q[6 * h + i]);
-    asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait for all six
+    for (int i = 0; i < kHalfBatch; ++i) e[i] = linear_fetch(dec, q[kHalfBatch * h + i]);
+    if (kHalfBatch == 4) asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));  // one wait for the batch
+    if (kHalfBatch == 6) asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4 % kHalfBatch]), "+v"(e[5 % kHalfBatch]));
 #pragma unroll
-    for (int i = 0; i < 6; ++i) lin[6 * h + i] = linear_select(e[i], x[6 * h + i]);
+    for (int i = 0; i < kHalfBatch; ++i) lin[kHalfBatch * h + i] = linear_select(e[i], x[kHalfBatch * h + i]);
   }
   const float *lr = lin, *lg = lin + 4, *lb = lin + 8;
   // (((a+b)+c)+d) * 0.25f, then scale into the encode table's domain (both exact powers of two)
@@ -350,6 +360,8 @@ __device__ __forceinline__ uint32_t half_px(const TransferBucketLinear *__restri
 
 }  // namespace
 
+// (Forcing 8 waves/SIMD with __launch_bounds__(512, 8) spills 21 VGPRs and halves the speed;
+// the natural 75-79 VGPRs = 6 waves/SIMD is the better point.)
 template <bool NT, bool WIDE>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_half(const DecodeParams p) {
@@ -360,7 +372,9 @@ decode_nv12_half(const DecodeParams p) {
   const FramePlanes f = p.frames[blockIdx.z];
   const Matrix m = matrix_of(p);
   const float en = p.table2_scale, dn = p.table_scale;
-  const uint32_t orow = blockIdx.y;
+  const uint32_t out_rows = p.height >> 1;
+  const uint32_t orow_raw = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t orow = min(orow_raw, out_rows - 1);
   const uint8_t *y0 = f.y + static_cast<size_t>(2 * orow) * p.y_stride;
   const uint8_t *y1 = y0 + p.y_stride;
   const uint8_t *cc = f.cbcr + static_cast<size_t>(orow) * p.cbcr_stride;
@@ -393,14 +407,15 @@ decode_nv12_half(const DecodeParams p) {
                     p.alpha_word);
       v.y = half_px(dec, dn, m, enc, en, byte_of(ya[u], 2), byte_of(ya[u], 3), byte_of(yb[u], 2), byte_of(yb[u], 3), c1,
                     p.alpha_word);
-      if (q < quads) store8<NT>(o + 8 * q, v);
+      if (q < quads && orow_raw < out_rows) store8<NT>(o + 8 * q, v);
     }
   } else {
     stage_table(dec, p.table, p.table_bytes);
     stage_table(enc, p.table2, p.table2_bytes);
     __syncthreads();
     const uint32_t out_w = p.width >> 1;
-    for (uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x; ox < out_w; ox += gridDim.x * blockDim.x) {
+    for (uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x; ox < out_w && orow_raw < out_rows;
+         ox += gridDim.x * blockDim.x) {
       const Chroma c = chroma_terms(m, static_cast<float>(cc[2 * ox]), static_cast<float>(cc[2 * ox + 1]));
       reinterpret_cast<uint32_t *>(o)[ox] =
           half_px(dec, dn, m, enc, en, static_cast<float>(y0[2 * ox]), static_cast<float>(y0[2 * ox + 1]),
@@ -416,9 +431,10 @@ const char *launch_decode(const DecodeParams &p, int frames, int variant, bool h
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
   const size_t lds = p.table_bytes;
   if (variant == kVariantQuads) {
-    // grid_x = tiles per row pair
-    const dim3 grid(grid_x, p.height / 2, static_cast<uint32_t>(frames));
-    const dim3 block(block_threads, 1, 1);
+    // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
+    const uint32_t by = quads_rows_per_block(block_threads, grid_x);
+    const dim3 grid(grid_x, (p.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
+    const dim3 block(block_threads, by, 1);
     if (has_alpha) {
       hipLaunchKernelGGL((decode_nv12_quads<true, true>), grid, block, lds, stream, p);
       return "decode_nv12_quads<alpha>";
@@ -462,8 +478,9 @@ hipError_t prepare_kernels() {
 
 const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
                                uint32_t block_threads, hipStream_t stream) {
-  const dim3 grid(grid_x, p.height / 2, static_cast<uint32_t>(frames));
-  const dim3 block(block_threads, 1, 1);
+  const uint32_t by = wide ? quads_rows_per_block(block_threads, grid_x) : 1;
+  const dim3 grid(grid_x, (p.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
+  const dim3 block(block_threads, by, 1);
   const size_t lds = static_cast<size_t>(p.table_bytes) + p.table2_bytes;
   if (wide) {
     if (nontemporal) hipLaunchKernelGGL((decode_nv12_half<true, true>), grid, block, lds, stream, p);
