@@ -86,9 +86,14 @@ class GpuRunner:
         from metalbt709decoder_amd._capi import Frame, Surface
         self.np, self._capi, self.g = np, _capi, g
         gamma = GAMMAS[args.gamma]
-        self.ctx = mb.MetalRenderContext(local_rank)
+        ndev = mb.load_library().bt709hip_device_count()
+        if ndev <= 0:
+            sys.exit("no HIP device: the product has no CPU fallback")
+        # one rank per GPU; ranks beyond the device count (only in functional tests on a
+        # smaller box) wrap around
+        self.ctx = mb.MetalRenderContext(local_rank % ndev)
         if not self.ctx.setupMetal():
-            sys.exit("no HIP device %d: the product has no CPU fallback" % local_rank)
+            sys.exit("HIP device %d could not be set up" % (local_rank % ndev))
         self.lib, self.h = self.ctx.lib, self.ctx.handle
         info = self.ctx.info()
         self.device, self.arch = info.name.decode(), info.arch.decode()
