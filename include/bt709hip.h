@@ -214,6 +214,20 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count,
                                const bt709hip_frame *frames, const bt709hip_surface *outs,
                                void *stream, int wait_until_completed);
 
+/* ------------------------------------------------------------------ encoder */
+/* The step before the decode path, on the GPU: 8-bit BGRA -> NV12 BT.709 video range with
+ * the reference's linear-light 2x2 chroma averaging.  Replaces
+ * +[BGRAToBT709Converter convertIntoCoreVideoBuffer:cvPixelBuffer:inputGamma:outputGamma:]
+ * (Renderer/BGRAToBT709Converter.h:73-76, .m:532-569) -> cvpbu_ycbcr_subsample
+ * (Renderer/CVPixelBufferUtils.h:241-399) -> BT709_average_pixel_values
+ * (Renderer/BT709.h:1349-1509).  input_gamma / output_gamma are bt709hip_gamma values
+ * APPLE, SRGB or LINEAR (BT709Gamma, BT709.h:20-25); the app encodes with (SRGB, APPLE),
+ * (SRGB, SRGB) or (LINEAR, LINEAR) (BGRAToBT709Converter.m:919-935).
+ * `in` is read (alpha ignored), the planes `out` points to are written; out->matrix and
+ * out->transfer are ignored.  Width and height must be even and equal on both sides. */
+int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_frame *out,
+                    int input_gamma, int output_gamma, void *stream, int wait_until_completed);
+
 /* -------------------------------------------------------------- diagnostics */
 const char *bt709hip_strerror(int status);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none). */

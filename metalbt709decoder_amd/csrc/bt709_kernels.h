@@ -46,6 +46,21 @@ struct DecodeParams {
   uint32_t alpha_word;  // alpha_fill << 24
 };
 
+// BGRA -> NV12 encoder (bt709_encode.hip).  One frame per launch.
+struct EncodeParams {
+  const uint8_t *bgra;  // W x H words (A<<24)|(R<<16)|(G<<8)|B, alpha ignored
+  uint8_t *y;
+  uint8_t *cbcr;
+  const EncodeByteEntry *per_byte;  // 256 entries for the (input gamma, output gamma) pair
+  const TransferBucket *from_linear;  // unit part of the BT709_from_linear(., output gamma) table
+  uint32_t from_linear_bytes;
+  float from_linear_scale;  // its N
+  uint32_t width, height;
+  uint32_t bgra_stride, y_stride, cbcr_stride;
+};
+const char *launch_encode(const EncodeParams &p, bool fast, hipStream_t stream);
+hipError_t prepare_encode_kernels();
+
 // Launchers return the kernel's name (static string) for profiling; launch errors
 // are read by the caller with hipGetLastError().
 // decode: variant kVariantQuads -> grid = (grid_x tiles, H/2, frames) x block_threads;

@@ -21,11 +21,20 @@
 
 using namespace bt709;
 
+struct EncoderTables {  // device copies for one (input gamma, output gamma) pair
+  void *d_per_byte = nullptr;
+  void *d_from_linear = nullptr;
+  uint32_t from_linear_bytes = 0;
+  uint32_t from_linear_n = 0;
+};
+
 struct bt709hip_context {
   int device = 0;
   hipDeviceProp_t props;
   hipStream_t default_stream = nullptr;
   int grid_blocks = 0;  // workgroups a launch aims for (all frames together)
+  std::mutex encoder_mutex;
+  EncoderTables encoders[3][3];  // [input gamma][output gamma], built on first use
 };
 
 struct bt709hip_decoder {
@@ -172,6 +181,7 @@ int bt709hip_context_create(int device_ordinal, bt709hip_context **out) {
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->props, device_ordinal);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->default_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = prepare_kernels();
+  if (e == hipSuccess) e = prepare_encode_kernels();
   if (e != hipSuccess) {
     delete ctx;
     return hip_fail(e);
@@ -188,6 +198,11 @@ int bt709hip_context_destroy(bt709hip_context *ctx) {
   if (hipSetDevice(ctx->device) == hipSuccess && ctx->default_stream) {
     (void)hipStreamSynchronize(ctx->default_stream);
     (void)hipStreamDestroy(ctx->default_stream);
+    for (auto &row : ctx->encoders)
+      for (EncoderTables &t : row) {
+        if (t.d_per_byte) (void)hipFree(t.d_per_byte);
+        if (t.d_from_linear) (void)hipFree(t.d_from_linear);
+      }
   }
   delete ctx;
   return BT709HIP_OK;
@@ -523,6 +538,60 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
 int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
                          void *stream, int wait_until_completed) {
   return bt709hip_decode_half_batch(dec, 1, frame, out, stream, wait_until_completed);
+}
+
+// ------------------------------------------------------------------ encoder
+
+int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_frame *out, int input_gamma,
+                    int output_gamma, void *stream, int wait_until_completed) {
+  if (ctx == nullptr || in == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (input_gamma < 0 || input_gamma > 2 || output_gamma < 0 || output_gamma > 2) return BT709HIP_ERR_INVALID_ARG;
+  if (in->width < 0 || in->height < 0) return BT709HIP_ERR_INVALID_ARG;
+  if (in->width != out->width || in->height != out->height) return BT709HIP_ERR_SIZE_MISMATCH;
+  if ((in->width & 1) || (in->height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;  // BGRAToBT709Converter.m:540-541
+  if (in->width == 0 || in->height == 0) return BT709HIP_OK;
+  if (in->bgra == nullptr || out->y == nullptr || out->cbcr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  const size_t w = static_cast<size_t>(in->width);
+  if (in->stride < 4 * w || (in->stride & 3) || !aligned(in->bgra, 4) || out->y_stride < w || out->cbcr_stride < w)
+    return BT709HIP_ERR_STRIDE;
+  if (int rc = bind(ctx)) return rc;
+
+  EncoderTables &t = ctx->encoders[input_gamma][output_gamma];
+  {
+    std::lock_guard<std::mutex> lock(ctx->encoder_mutex);
+    if (t.d_per_byte == nullptr) {
+      EncodeTables host;
+      TransferTable fl;
+      if (!build_encode_tables(input_gamma, output_gamma, &host) || !build_transfer_table(host.from_linear_kind, &fl))
+        return BT709HIP_ERR_UNSUPPORTED;
+      t.from_linear_n = fl.n;
+      t.from_linear_bytes = static_cast<uint32_t>(fl.unit_entries * sizeof(TransferBucket));  // averages stay in [0,1]
+      if (int rc = upload_table(fl.buckets.data(), t.from_linear_bytes, &t.d_from_linear)) return rc;
+      if (int rc = upload_table(host.per_byte, sizeof host.per_byte, &t.d_per_byte)) return rc;
+    }
+  }
+
+  EncodeParams p;
+  std::memset(&p, 0, sizeof p);
+  p.bgra = static_cast<const uint8_t *>(in->bgra);
+  p.y = static_cast<uint8_t *>(const_cast<void *>(out->y));
+  p.cbcr = static_cast<uint8_t *>(const_cast<void *>(out->cbcr));
+  p.per_byte = static_cast<const EncodeByteEntry *>(t.d_per_byte);
+  p.from_linear = static_cast<const TransferBucket *>(t.d_from_linear);
+  p.from_linear_bytes = t.from_linear_bytes;
+  p.from_linear_scale = static_cast<float>(t.from_linear_n);
+  p.width = static_cast<uint32_t>(in->width);
+  p.height = static_cast<uint32_t>(in->height);
+  p.bgra_stride = static_cast<uint32_t>(in->stride);
+  p.y_stride = static_cast<uint32_t>(out->y_stride);
+  p.cbcr_stride = static_cast<uint32_t>(out->cbcr_stride);
+  const bool fast = (p.width % 4) == 0 && (in->stride % 16) == 0 && aligned(in->bgra, 16) && (out->y_stride % 4) == 0 &&
+                    (out->cbcr_stride % 4) == 0 && aligned(out->y, 4) && aligned(out->cbcr, 4);
+  hipStream_t s = pick(ctx, stream);
+  tl_kernel_name = launch_encode(p, fast, s);
+  HIP_TRY(hipGetLastError());
+  if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
+  return BT709HIP_OK;
 }
 
 // -------------------------------------------------------------- diagnostics

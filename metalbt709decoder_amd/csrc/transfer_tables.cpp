@@ -45,6 +45,13 @@ float apple196_to_linear(float v) {
   return static_cast<float>(std::pow(static_cast<double>(v), static_cast<double>(gamma)));
 }
 
+float linear_to_apple196(float v) {
+  const float y_intercept = 0.00349f;
+  if (v < y_intercept) return v * 16.0f;
+  const float gamma = 1.0f / 1.960938f;  // 1.0f / APPLE_GAMMA_196, BT709.h:146
+  return static_cast<float>(std::pow(static_cast<double>(v), static_cast<double>(gamma)));
+}
+
 int quantize_byte(float v) {
   const float scaled = v * 255.0f;  // float multiply first
   return static_cast<int>(std::round(static_cast<double>(scaled)));
@@ -60,6 +67,8 @@ int transfer_to_byte(int gamma, float v) {
       return quantize_byte(linear_to_srgb(v));
     case kGammaITU709:
       return quantize_byte(linear_to_srgb(itu709_to_linear(v)));
+    case kTableEncodeApple:  // BT709_from_linear(v, Apple), BT709.h:1158-1159
+      return quantize_byte(linear_to_apple196(v));
     default:
       return -1;
   }
@@ -89,7 +98,7 @@ float find_threshold(int gamma, int k) {
 }  // namespace
 
 bool build_transfer_table(int gamma, TransferTable *out) {
-  if (gamma < 0 || gamma >= kGammaCount || out == nullptr) return false;
+  if (gamma < 0 || gamma >= kTableKinds || out == nullptr) return false;
   out->gamma = gamma;
   for (int k = 1; k <= 255; ++k) out->thresholds[k - 1] = find_threshold(gamma, k);
 
@@ -138,6 +147,23 @@ bool build_transfer_table(int gamma, TransferTable *out) {
     return true;
   }
   return false;
+}
+
+bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out) {
+  if (out == nullptr) return false;
+  auto ok = [](int g) { return g == kGammaApple || g == kGammaSRGB || g == kGammaLinear; };
+  if (!ok(in_gamma) || !ok(out_gamma)) return false;
+  out->from_linear_kind = out_gamma == kGammaSRGB ? kGammaLinear : (out_gamma == kGammaLinear ? kGammaSRGB : kTableEncodeApple);
+  for (int b = 0; b < 256; ++b) {
+    const float n = b * (1.0f / 255.0f);  // byteNorm
+    float lin = n;                        // BT709_tolinearNorm, BT709.h:1125-1139
+    if (in_gamma == kGammaSRGB) lin = srgb_to_linear(n);
+    else if (in_gamma == kGammaApple) lin = apple196_to_linear(n);
+    const int e = transfer_to_byte(out->from_linear_kind, lin);  // BT709_from_linear(lin, outputGamma)
+    out->per_byte[b].lin = lin;
+    out->per_byte[b].enc_norm = e * (1.0f / 255.0f);  // byteNorm inside sRGB_from_sRGB_convertRGBToYCbCr
+  }
+  return true;
 }
 
 }  // namespace bt709

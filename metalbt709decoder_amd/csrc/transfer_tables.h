@@ -26,6 +26,14 @@ namespace bt709 {
 
 enum Gamma : int { kGammaApple = 0, kGammaSRGB = 1, kGammaLinear = 2, kGammaITU709 = 3, kGammaCount = 4 };
 
+// Table kinds build_transfer_table understands: the four decode composites above, plus the one
+// extra composite the ENCODER needs: byte = round(255 * Apple196_linearNormToNonLinear(v))
+// (BT709_from_linear(v, BT709GammaApple), Renderer/BT709.h:1150-1167).  The other two
+// BT709_from_linear flavours coincide with decode composites: Srgb == kGammaLinear's,
+// Linear (plain quantise) == kGammaSRGB's.
+constexpr int kTableEncodeApple = 4;
+constexpr int kTableKinds = 5;
+
 constexpr float kTableReach = 2.25f;  // table covers xs in [0, kTableReach * N]
 
 // One bucket.  `edge` is N times the single threshold strictly inside the bucket, or +inf.
@@ -58,10 +66,24 @@ float srgb_to_linear(float v);      // Renderer/sRGB.h:43-57
 float linear_to_srgb(float v);      // Renderer/sRGB.h:62-74
 float itu709_to_linear(float v);    // Renderer/BT709.h:68-81
 float apple196_to_linear(float v);  // Renderer/BT709.h:125-137
+float linear_to_apple196(float v);  // Renderer/BT709.h:139-151
 int quantize_byte(float v);         // (int)round(v * 255.0f), Renderer/BT709.h:881-883
 
 // Per-channel composite of one gamma mode.
 int transfer_to_byte(int gamma, float v);
+
+// Encoder tables for one (input gamma, output gamma) pair of cvpbu_ycbcr_subsample /
+// BT709_average_pixel_values (Renderer/CVPixelBufferUtils.h:241-399, Renderer/BT709.h:1349-1509);
+// gammas use this file's ids (kGammaApple / kGammaSRGB / kGammaLinear).
+struct alignas(8) EncodeByteEntry {
+  float lin;       // BT709_tolinearNorm of the byte for the input gamma (BT709.h:1100-1146)
+  float enc_norm;  // byteNorm(BT709_from_linear(lin, output gamma)): the per-pixel value fed to the matrix
+};
+struct EncodeTables {
+  EncodeByteEntry per_byte[256];
+  int from_linear_kind = 0;  // table kind whose buckets implement BT709_from_linear(., output gamma)
+};
+bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out);
 
 // Builds thresholds + buckets.  Returns false if gamma is unknown or the
 // single-threshold-per-bucket property cannot be met with N <= 65536.

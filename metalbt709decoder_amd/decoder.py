@@ -155,6 +155,20 @@ class CVPixelBuffer:
         self.ctx._upload(self.cbcr_ptr, self.cbcr_stride, cbcr, commandBuffer)
         self.ctx._sync(commandBuffer)
 
+    def download_planes(self, commandBuffer=None):
+        """Tight (H, W) luma and (H/2, W) interleaved CbCr arrays read back from the device."""
+        y = np.empty((self.height, self.width), dtype=np.uint8)
+        c = np.empty((self.height // 2, self.width), dtype=np.uint8)
+        if self.width and self.height:
+            stream = commandBuffer.stream if commandBuffer else None
+            lib, h = self.ctx.lib, self.ctx.handle
+            _capi.check(lib.bt709hip_download(h, y.ctypes.data, self.width, self.y_ptr, self.y_stride, self.width,
+                                              self.height, stream), "download Y")
+            _capi.check(lib.bt709hip_download(h, c.ctypes.data, self.width, self.cbcr_ptr, self.cbcr_stride,
+                                              self.width, self.height // 2, stream), "download CbCr")
+            self.ctx._sync(commandBuffer)
+        return y, c
+
 
 class MetalRenderContext:
     """Device + queue holder (Renderer/MetalRenderContext.h:17-43)."""
@@ -240,6 +254,23 @@ class BGRAToBT709Converter:
     def setBT709Attributes(buf):
         buf.setAttachment("YCbCrMatrix", kCVImageBufferYCbCrMatrix_ITU_R_709_2)  # .m:412-451
         buf.setAttachment("TransferFunction", kCVImageBufferTransferFunction_ITU_R_709_2)
+        return True
+
+    @staticmethod
+    def convertIntoCoreVideoBuffer(bgraTexture, cvPixelBuffer, inputGamma, outputGamma, commandBuffer=None,
+                                   waitUntilCompleted=True):
+        """+convertIntoCoreVideoBuffer:cvPixelBuffer:inputGamma:outputGamma: (BGRAToBT709Converter.h:73-76)
+        -> cvpbu_ycbcr_subsample: BGRA pixels -> NV12 with linear-light 2x2 chroma averaging, on the GPU.
+        The source is a BGRATexture (device memory) instead of a CGImage.  Gammas are MetalBT709Gamma*
+        values Apple / SRGB / Linear.  Returns True/False like the reference."""
+        ctx = bgraTexture.ctx
+        surf, frame = bgraTexture.surface(), cvPixelBuffer.frame()
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = ctx.lib.bt709hip_encode(ctx.handle, C.byref(surf), C.byref(frame), int(inputGamma), int(outputGamma),
+                                     stream, int(bool(waitUntilCompleted)))
+        if rc != _capi.OK:
+            log.error("convertIntoCoreVideoBuffer: %s", _capi.strerror(rc))
+            return False
         return True
 
     @staticmethod

@@ -111,6 +111,9 @@ int bt709o_transfer_to_byte(int gamma, float v) {
     case BT709O_GAMMA_ITU709: /* BT709.h:540-545 + 704-716 */
       v = bt709o_linear_to_srgb(bt709o_itu709_to_linear(v));
       break;
+    case BT709O_TABLE_ENCODE_APPLE: /* BT709_from_linear(v, Apple), BT709.h:1158-1159 */
+      v = bt709o_linear_to_apple196(v);
+      break;
     default:
       return -1;
   }

@@ -44,7 +44,11 @@ enum {
   BT709O_GAMMA_SRGB = 1,
   BT709O_GAMMA_LINEAR = 2,
   BT709O_GAMMA_ITU709 = 3,
-  BT709O_GAMMA_COUNT = 4
+  BT709O_GAMMA_COUNT = 4,
+  /* not a decode mode: the encoder-side composite round(255*Apple196enc(v)) =
+   * BT709_from_linear(v, BT709GammaApple) (BT709.h:1150-1167); accepted by
+   * bt709o_transfer_to_byte / bt709o_thresholds / bt709o_check_thresholds only */
+  BT709O_TABLE_ENCODE_APPLE = 4
 };
 
 /* ---- scalar transfer functions (normalised float in, normalised float out) */

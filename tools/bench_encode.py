@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Throughput of the GPU encoder (BGRA -> NV12) on resident 4K frames.
+Not the headline bench (that is bench.py); same method: ring of distinct frames in HBM,
+HIP events on the launch stream, algorithmic bytes = 4 B read + 1.5 B written per pixel.
+
+    python tools/bench_encode.py [--ring 32] [--steps 50]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+import metalbt709decoder_amd as mb  # noqa: E402
+from metalbt709decoder_amd import _capi  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ring", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    args = ap.parse_args()
+    W, H = args.width, args.height
+    ctx = mb.MetalRenderContext(0)
+    assert ctx.setupMetal()
+    lib, h = ctx.lib, ctx.handle
+    rng = np.random.default_rng(0x709)
+    texs, bufs = [], []
+    for i in range(args.ring):
+        texs.append(ctx.makeBGRATexture((W, H), pixels=rng.integers(0, 1 << 32, W * H, dtype=np.uint32)))
+        bufs.append(mb.BGRAToBT709Converter.createCoreVideoYCbCrBuffer(ctx, (W, H)))
+    surfs = [t.surface() for t in texs]
+    frames = [b.frame() for b in bufs]
+
+    def step():
+        for s, f in zip(surfs, frames):
+            _capi.check(lib.bt709hip_encode(h, C.byref(s), C.byref(f), 1, 0, None, 0))
+
+    t_end = time.perf_counter() + 0.4
+    while time.perf_counter() < t_end:
+        step()
+        _capi.check(lib.bt709hip_stream_synchronize(h, None))
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    lib.bt709hip_event_create(h, C.byref(e0))
+    lib.bt709hip_event_create(h, C.byref(e1))
+    lib.bt709hip_event_record(h, e0, None)
+    for _ in range(args.steps):
+        step()
+    lib.bt709hip_event_record(h, e1, None)
+    _capi.check(lib.bt709hip_stream_synchronize(h, None))
+    ms = C.c_float()
+    lib.bt709hip_event_elapsed_ms(h, e0, e1, C.byref(ms))
+    n = args.steps * args.ring
+    us = ms.value * 1e3 / n
+    bytes_per_frame = W * H * 4 + W * H * 3 // 2
+    print(json.dumps({"workload": "%dx%d BGRA -> NV12 encode (sRGB in, Apple gamma out), 1 frame per launch" % (W, H),
+                      "us_per_frame": round(us, 3), "gpixel_per_s": round(W * H / us / 1e3, 1),
+                      "algorithmic_GBps": round(bytes_per_frame / us / 1e3, 1),
+                      "frac_of_8TBps": round(bytes_per_frame / us / 1e3 / 8000, 4),
+                      "kernel": lib.bt709hip_last_kernel_name().decode()}))
+
+
+if __name__ == "__main__":
+    main()
