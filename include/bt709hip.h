@@ -228,6 +228,18 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count,
 int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_frame *out,
                     int input_gamma, int output_gamma, void *stream, int wait_until_completed);
 
+/* ------------------------------------------------------------ plane layouts */
+/* The reference's on-disk 4:2:0 format is YUV4MPEG2 "C420jpeg": planar Y, then U (Cb), then V
+ * (Cr) per frame (Renderer/y4m_writer.h:194-241).  These move the two chroma planes to / from
+ * NV12's interleaved CbCr plane on the device (the Y plane is identical in both layouts).
+ * chroma_width x chroma_height = (W/2) x (H/2); strides in bytes. */
+int bt709hip_interleave_cbcr(bt709hip_context *ctx, const void *u, size_t u_stride, const void *v, size_t v_stride,
+                             void *cbcr, size_t cbcr_stride, int chroma_width, int chroma_height,
+                             void *stream, int wait_until_completed);
+int bt709hip_deinterleave_cbcr(bt709hip_context *ctx, const void *cbcr, size_t cbcr_stride, void *u, size_t u_stride,
+                               void *v, size_t v_stride, int chroma_width, int chroma_height,
+                               void *stream, int wait_until_completed);
+
 /* -------------------------------------------------------------- diagnostics */
 const char *bt709hip_strerror(int status);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none). */

@@ -61,6 +61,17 @@ struct EncodeParams {
 const char *launch_encode(const EncodeParams &p, bool fast, hipStream_t stream);
 hipError_t prepare_encode_kernels();
 
+// Planar U,V <-> interleaved CbCr (bt709_planes.hip).  The kernel that reads a plane never writes it.
+struct PlaneParams {
+  const uint8_t *u;  // chroma_width x chroma_height bytes (written by deinterleave_cbcr)
+  const uint8_t *v;
+  uint8_t *cbcr;     // chroma_width byte pairs per row (read by deinterleave_cbcr)
+  uint32_t u_stride, v_stride, cbcr_stride;
+  uint32_t chroma_width, chroma_height;
+  uint32_t wide;     // 1: 8 samples per lane with 8/16-byte accesses
+};
+const char *launch_planes(const PlaneParams &p, bool interleave, hipStream_t stream);
+
 // Launchers return the kernel's name (static string) for profiling; launch errors
 // are read by the caller with hipGetLastError().
 // decode: variant kVariantQuads -> grid = (grid_x tiles, H/2, frames) x block_threads;

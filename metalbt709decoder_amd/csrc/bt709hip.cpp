@@ -594,6 +594,50 @@ int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt7
   return BT709HIP_OK;
 }
 
+// ------------------------------------------------------------ plane layouts
+
+static int planes_call(bt709hip_context *ctx, const void *u, size_t u_stride, const void *v, size_t v_stride,
+                       void *cbcr, size_t cbcr_stride, int cw, int ch, bool interleave, void *stream, int wait) {
+  if (ctx == nullptr || cw < 0 || ch < 0) return BT709HIP_ERR_INVALID_ARG;
+  if (cw == 0 || ch == 0) return BT709HIP_OK;
+  if (u == nullptr || v == nullptr || cbcr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  const size_t w = static_cast<size_t>(cw);
+  if (u_stride < w || v_stride < w || cbcr_stride < 2 * w) return BT709HIP_ERR_STRIDE;
+  if (u_stride > 0xffffffffu || v_stride > 0xffffffffu || cbcr_stride > 0xffffffffu) return BT709HIP_ERR_STRIDE;
+  if (int rc = bind(ctx)) return rc;
+  PlaneParams p;
+  std::memset(&p, 0, sizeof p);
+  p.u = static_cast<const uint8_t *>(u);
+  p.v = static_cast<const uint8_t *>(v);
+  p.cbcr = static_cast<uint8_t *>(cbcr);
+  p.u_stride = static_cast<uint32_t>(u_stride);
+  p.v_stride = static_cast<uint32_t>(v_stride);
+  p.cbcr_stride = static_cast<uint32_t>(cbcr_stride);
+  p.chroma_width = static_cast<uint32_t>(cw);
+  p.chroma_height = static_cast<uint32_t>(ch);
+  p.wide = (cw % 8) == 0 && (u_stride % 8) == 0 && (v_stride % 8) == 0 && (cbcr_stride % 16) == 0 && aligned(u, 8) &&
+           aligned(v, 8) && aligned(cbcr, 16);
+  hipStream_t s = pick(ctx, stream);
+  tl_kernel_name = launch_planes(p, interleave, s);
+  HIP_TRY(hipGetLastError());
+  if (wait) HIP_TRY(hipStreamSynchronize(s));
+  return BT709HIP_OK;
+}
+
+int bt709hip_interleave_cbcr(bt709hip_context *ctx, const void *u, size_t u_stride, const void *v, size_t v_stride,
+                             void *cbcr, size_t cbcr_stride, int chroma_width, int chroma_height, void *stream,
+                             int wait_until_completed) {
+  return planes_call(ctx, u, u_stride, v, v_stride, cbcr, cbcr_stride, chroma_width, chroma_height, true, stream,
+                     wait_until_completed);
+}
+
+int bt709hip_deinterleave_cbcr(bt709hip_context *ctx, const void *cbcr, size_t cbcr_stride, void *u, size_t u_stride,
+                               void *v, size_t v_stride, int chroma_width, int chroma_height, void *stream,
+                               int wait_until_completed) {
+  return planes_call(ctx, u, u_stride, v, v_stride, const_cast<void *>(cbcr), cbcr_stride, chroma_width, chroma_height,
+                     false, stream, wait_until_completed);
+}
+
 // -------------------------------------------------------------- diagnostics
 
 const char *bt709hip_strerror(int status) {
