@@ -6,7 +6,7 @@
 A "step" is one pass of the hot path over one batch of synthetic frames already
 resident in HBM: the whole ring of `--ring` distinct frames (default 64 x 4K =
 0.8 GB in + 2.1 GB out, far beyond the 256 MB Infinity Cache, so the kernel streams
-from and to HBM), issued as ring/32 launches of 32 frames (grid.y = frame).
+from and to HBM), issued as ONE launch (grid.z = frame; the ring is an evenly spaced slab).
 For N > 1 the driver starts one process per GPU (torch.distributed.run); every rank
 owns a ring on its own GPU and decodes it with no data-path collective (frames are
 independent); rank 0 prints ONE JSON line with the whole-job Gpixel/s.
@@ -34,8 +34,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 WORKLOADS = {
     # name: (width, height, half_scale, default ring, frames per launch)
-    "4k": (3840, 2160, False, 64, 32),
-    "1080p": (1920, 1080, False, 256, 32),
+    # The ring is one evenly spaced slab, so a whole ring is ONE launch (grid.z = frame).
+    "4k": (3840, 2160, False, 64, 64),
+    "1080p": (1920, 1080, False, 256, 256),
     "8k-half": (7680, 4320, True, 16, 16),
 }
 GAMMAS = {"apple": 0, "srgb": 1, "linear": 2, "itu709": 3}
@@ -248,7 +249,7 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    g = geometry(args.workload, args.ring, 32)
+    g = geometry(args.workload, args.ring, 65535)
     runner = DryRunner() if args.dry_run else GpuRunner(args, g, rank, local_rank)
 
     def barrier():

@@ -194,10 +194,13 @@ int bt709hip_decode(bt709hip_decoder *dec,
                     int render_width, int render_height,
                     void *stream, int wait_until_completed);
 
-/* The same operator over `count` <= BT709HIP_MAX_BATCH independent frames of one
- * geometry (same width/height/strides/tags) in ONE launch: grid.y = frame.  This
- * is how a stream of small frames stays off the launch-latency floor.  alphas may
- * be NULL. */
+/* The same operator over `count` independent frames of one geometry (same
+ * width/height/strides/tags) in ONE launch: grid.z = frame.  This is how a stream of
+ * small frames stays off the launch-latency floor.  count <= BT709HIP_MAX_BATCH in
+ * general (the plane pointers travel in the kernel-argument block); when the frames,
+ * alphas and outputs are EVENLY SPACED in memory -- frame i at frame 0 + i * (frame 1
+ * - frame 0), as in a ring carved from one allocation -- any count <= 65535 is accepted.
+ * alphas may be NULL. */
 int bt709hip_decode_batch(bt709hip_decoder *dec, int count,
                           const bt709hip_frame *frames, const bt709hip_frame *alphas,
                           const bt709hip_surface *outs,

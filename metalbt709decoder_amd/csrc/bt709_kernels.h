@@ -12,7 +12,8 @@ namespace bt709 {
 constexpr int kBlockThreads = 256;     // general-path workgroup: 4 waves of 64
 constexpr int kMaxBlockThreads = 512;  // fast-path workgroup is sized per frame width, up to 8 waves
 constexpr int kQuadsPerLane = 2;       // 4x2-pixel quads a fast-path lane owns per row pair
-constexpr int kMaxBatch = 32;          // == BT709HIP_MAX_BATCH
+constexpr int kMaxBatch = 32;          // == BT709HIP_MAX_BATCH: frames in the kernarg table
+constexpr int kMaxUniformBatch = 65535;  // evenly spaced frames per launch (grid.z limit)
 
 enum KernelVariant : int {
   kVariantQuads = 0,   // aligned fast path, 4x2 pixels per lane
@@ -44,6 +45,9 @@ struct DecodeParams {
   uint32_t alpha_stride;
   uint32_t out_stride;
   uint32_t alpha_word;  // alpha_fill << 24
+  // uniform != 0: frame i = frames[0] + i * step_* (bytes); lets one launch cover any number of frames
+  uint32_t uniform;
+  int64_t step_y, step_cbcr, step_alpha, step_out;
 };
 
 // BGRA -> NV12 encoder (bt709_encode.hip).  One frame per launch.

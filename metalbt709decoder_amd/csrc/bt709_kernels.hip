@@ -161,6 +161,19 @@ __device__ __forceinline__ void store8(uint8_t *p, u32x2 v) {
   else *reinterpret_cast<u32x2 *>(p) = v;
 }
 
+// Frame i of the launch: from the kernarg table, or -- when the caller's frames are evenly
+// spaced in memory (a ring / pool) -- frame 0 plus i times the spacing, which lifts the
+// 32-frame limit of the table.
+__device__ __forceinline__ FramePlanes frame_planes(const DecodeParams &p, uint32_t i) {
+  if (!p.uniform) return p.frames[i];
+  FramePlanes f = p.frames[0];
+  f.y += static_cast<int64_t>(i) * p.step_y;
+  f.cbcr += static_cast<int64_t>(i) * p.step_cbcr;
+  if (f.alpha) f.alpha += static_cast<int64_t>(i) * p.step_alpha;
+  f.out += static_cast<int64_t>(i) * p.step_out;
+  return f;
+}
+
 __device__ __forceinline__ Matrix matrix_of(const DecodeParams &p) {
   return Matrix{p.m_y, p.m_cr_r, p.m_cb_g, p.m_cr_g, p.m_cb_b};
 }
@@ -179,7 +192,7 @@ decode_nv12_quads(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   TransferBucket *tbl = reinterpret_cast<TransferBucket *>(lds_raw);
 
-  const FramePlanes f = p.frames[blockIdx.z];
+  const FramePlanes f = frame_planes(p, blockIdx.z);
   const Matrix m = matrix_of(p);
   const uint32_t quads = p.width >> 2;
   const uint32_t row_pairs = p.height >> 1;
@@ -263,7 +276,7 @@ decode_nv12_blocks(const DecodeParams p) {
   stage_table(tbl, p.table, p.table_bytes);
   __syncthreads();
 
-  const FramePlanes f = p.frames[blockIdx.y];
+  const FramePlanes f = frame_planes(p, blockIdx.y);
   const Matrix m = matrix_of(p);
   const uint32_t bw = p.width >> 1;
   const uint32_t row_pairs = p.height >> 1;
@@ -376,7 +389,7 @@ decode_nv12_half(const DecodeParams p) {
   TransferBucketLinear *dec = reinterpret_cast<TransferBucketLinear *>(lds_raw);
   TransferBucket *enc = reinterpret_cast<TransferBucket *>(lds_raw + p.table_bytes);
 
-  const FramePlanes f = p.frames[blockIdx.z];
+  const FramePlanes f = frame_planes(p, blockIdx.z);
   const Matrix m = matrix_of(p);
   const float en = p.table2_scale, dn = p.table_scale;
   const uint32_t out_rows = p.height >> 1;

@@ -142,6 +142,27 @@ void set_matrix(DecodeParams *p, uint32_t n) {
   p->m_cb_b = kMCbB * fn;
 }
 
+int64_t byte_step(const void *a, const void *b) {
+  return static_cast<int64_t>(reinterpret_cast<intptr_t>(b) - reinterpret_cast<intptr_t>(a));
+}
+
+// True when frame i sits at frame 0 + i * (frame 1 - frame 0) for every plane: a ring or pool
+// carved from one allocation.  Such a batch needs no per-frame pointer table in the kernarg.
+bool evenly_spaced(int count, const bt709hip_frame *frames, const bt709hip_frame *alphas,
+                   const bt709hip_surface *outs) {
+  if (count < 2 || frames == nullptr || outs == nullptr) return false;
+  const int64_t dy = byte_step(frames[0].y, frames[1].y), dc = byte_step(frames[0].cbcr, frames[1].cbcr);
+  const int64_t dout = byte_step(outs[0].bgra, outs[1].bgra);
+  const int64_t da = alphas ? byte_step(alphas[0].y, alphas[1].y) : 0;
+  for (int i = 2; i < count; ++i) {
+    if (byte_step(frames[0].y, frames[i].y) != dy * i || byte_step(frames[0].cbcr, frames[i].cbcr) != dc * i ||
+        byte_step(outs[0].bgra, outs[i].bgra) != dout * i)
+      return false;
+    if (alphas && byte_step(alphas[0].y, alphas[i].y) != da * i) return false;
+  }
+  return true;
+}
+
 uint32_t grid_x_for(const bt709hip_context *ctx, uint32_t rows, int frames) {
   uint32_t per_frame = static_cast<uint32_t>(ctx->grid_blocks / (frames > 0 ? frames : 1));
   if (per_frame < 1) per_frame = 1;
@@ -420,7 +441,8 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
                           const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
                           int wait_until_completed) {
   if (dec == nullptr || frames == nullptr || outs == nullptr || count < 0) return BT709HIP_ERR_INVALID_ARG;
-  if (count > kMaxBatch) return BT709HIP_ERR_UNSUPPORTED;
+  const bool uniform = evenly_spaced(count, frames, dec->has_alpha ? alphas : nullptr, outs);
+  if (count > (uniform ? kMaxUniformBatch : kMaxBatch)) return BT709HIP_ERR_UNSUPPORTED;
   if (int rc = bt709hip_decoder_setup(dec)) return rc;  // -decodeBT709 calls -setupMetal first (.m:228-231)
   if (count == 0) return BT709HIP_OK;
   if (int rc = bind(dec->ctx)) return rc;
@@ -439,15 +461,24 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
         frames[i].cbcr_stride != f0.cbcr_stride || outs[i].stride != o0.stride)
       return BT709HIP_ERR_SIZE_MISMATCH;
     if (dec->has_alpha && a->y_stride != alphas[0].y_stride) return BT709HIP_ERR_SIZE_MISMATCH;
-    p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
-    p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
-    p.frames[i].alpha = dec->has_alpha ? static_cast<const uint8_t *>(a->y) : nullptr;
-    p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
+    if (i < kMaxBatch) {
+      p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
+      p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
+      p.frames[i].alpha = dec->has_alpha ? static_cast<const uint8_t *>(a->y) : nullptr;
+      p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
+    }
     fast = fast && aligned(frames[i].y, 4) && aligned(frames[i].cbcr, 4) && aligned(outs[i].bgra, 16);
     if (dec->has_alpha) fast = fast && aligned(a->y, 4) && (a->y_stride % 4) == 0;
   }
   if (f0.width == 0 || f0.height == 0) return BT709HIP_OK;
 
+  if (uniform && count > 1) {
+    p.uniform = 1;
+    p.step_y = byte_step(frames[0].y, frames[1].y);
+    p.step_cbcr = byte_step(frames[0].cbcr, frames[1].cbcr);
+    p.step_alpha = dec->has_alpha ? byte_step(alphas[0].y, alphas[1].y) : 0;
+    p.step_out = byte_step(outs[0].bgra, outs[1].bgra);
+  }
   p.table = dec->d_table;
   p.table_bytes = dec->table_bytes;
   set_matrix(&p, dec->table_n);
@@ -486,7 +517,8 @@ int bt709hip_decode(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt
 int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
                                const bt709hip_surface *outs, void *stream, int wait_until_completed) {
   if (dec == nullptr || frames == nullptr || outs == nullptr || count < 0) return BT709HIP_ERR_INVALID_ARG;
-  if (count > kMaxBatch) return BT709HIP_ERR_UNSUPPORTED;
+  const bool uniform = evenly_spaced(count, frames, nullptr, outs);
+  if (count > (uniform ? kMaxUniformBatch : kMaxBatch)) return BT709HIP_ERR_UNSUPPORTED;
   if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;
   if (int rc = bt709hip_decoder_setup(dec)) return rc;
   if (count == 0) return BT709HIP_OK;
@@ -505,13 +537,21 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
     if (frames[i].width != f0.width || frames[i].height != f0.height || frames[i].y_stride != f0.y_stride ||
         frames[i].cbcr_stride != f0.cbcr_stride || outs[i].stride != o0.stride)
       return BT709HIP_ERR_SIZE_MISMATCH;
-    p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
-    p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
-    p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
+    if (i < kMaxBatch) {
+      p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
+      p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
+      p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
+    }
     wide = wide && aligned(frames[i].y, 4) && aligned(frames[i].cbcr, 4) && aligned(outs[i].bgra, 8);
   }
   if (f0.width == 0 || f0.height == 0) return BT709HIP_OK;
 
+  if (uniform && count > 1) {
+    p.uniform = 1;
+    p.step_y = byte_step(frames[0].y, frames[1].y);
+    p.step_cbcr = byte_step(frames[0].cbcr, frames[1].cbcr);
+    p.step_out = byte_step(outs[0].bgra, outs[1].bgra);
+  }
   p.table = dec->d_table_linear;
   p.table_bytes = dec->table_linear_bytes;
   set_matrix(&p, dec->table_n);

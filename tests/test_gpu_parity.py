@@ -203,6 +203,36 @@ def test_batch_equals_single(gh, oracle):
     assert not dec.decodeBT709Batch(too_many, texs * 5) and dec.lastStatus == _capi.ERR_UNSUPPORTED
 
 
+def test_evenly_spaced_batch_beyond_table_limit(gh, oracle):
+    """Frames carved at a constant pitch from one allocation (a ring) need no pointer table:
+    one launch takes more than BT709HIP_MAX_BATCH of them."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    n, w, h = 45, 64, 16
+    in_pitch, out_pitch = w * h * 3 // 2, w * h * 4
+    slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
+    frames = [gh.random_nv12(w, h, seed=300 + i) for i in range(n)]
+    bufs, texs = [], []
+    for i, (y, c) in enumerate(frames):
+        base = slab_in.ptr + i * in_pitch
+        b = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h))
+        mb.BGRAToBT709Converter.setBT709Attributes(b)
+        b.upload_planes(y, c)
+        bufs.append(b)
+        texs.append(mb.BGRATexture(ctx, w, h, w * 4, ptr=slab_out.ptr + i * out_pitch))
+    assert n > _capi.MAX_BATCH
+    assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True)
+    for (y, c), t in zip(frames, texs):
+        got = ctx.getBGRATexturePixels(t).view(np.uint8).reshape(h, w * 4)
+        assert np.array_equal(got, oracle.decode_nv12(0, y, c))
+    # the same frames in shuffled order are not evenly spaced: the table limit applies again
+    order = list(range(n))
+    order[3], order[7] = order[7], order[3]
+    assert not dec.decodeBT709Batch([bufs[i] for i in order], [texs[i] for i in order])
+    assert dec.lastStatus == _capi.ERR_UNSUPPORTED
+
+
 def test_one_stream_per_in_flight_frame(gh, oracle):
     """North-star shape: each in-flight frame on its own HIP stream, no wait until the end."""
     ctx = gh.context()

@@ -224,7 +224,7 @@ def test_bench_two_ranks_gloo_dry_run():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
     assert res["unit"] == "Gpixel/s" and res["roofline"]["bound"] == "hbm"
-    # 2 ranks x 5 steps x 64 x 4K pixels over >= 5 x 2 ms
+    # 2 ranks x 5 steps x 64 x 4K pixels over >= 5 x 2 ms (dry run sleeps 2 ms per step)
     px = 2 * 5 * 64 * 3840 * 2160
     assert res["value"] <= px / (5 * 0.002) / 1e9
     assert abs(res["value"] - px / (res["ms_per_step"] * 5e-3) / 1e9) / res["value"] < 1e-3
@@ -233,6 +233,8 @@ def test_bench_two_ranks_gloo_dry_run():
 
 def test_bench_geometry():
     import bench
+    g = bench.geometry("4k", 0, 65535)
+    assert (g["ring"], g["per_launch"], g["launches"]) == (64, 64, 1)
     g = bench.geometry("4k", 0, 32)
     assert (g["ring"], g["per_launch"], g["launches"]) == (64, 32, 2)
     assert g["bytes_per_frame"] == 45_619_200
