@@ -6,7 +6,7 @@
 A "step" is one pass of the hot path over one batch of synthetic frames already
 resident in HBM: the whole ring of `--ring` distinct frames (default 64 x 4K =
 0.8 GB in + 2.1 GB out, far beyond the 256 MB Infinity Cache, so the kernel streams
-from and to HBM), issued as ONE launch (grid.z = frame; the ring is an evenly spaced slab).
+from and to HBM), issued as ring/32 launches of 32 frames (grid.z = frame; 1080p: 128 per launch).
 For N > 1 the driver starts one process per GPU (torch.distributed.run); every rank
 owns a ring on its own GPU and decodes it with no data-path collective (frames are
 independent); rank 0 prints ONE JSON line with the whole-job Gpixel/s.
@@ -34,9 +34,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 WORKLOADS = {
     # name: (width, height, half_scale, default ring, frames per launch)
-    # The ring is one evenly spaced slab, so a whole ring is ONE launch (grid.z = frame).
-    "4k": (3840, 2160, False, 64, 64),
-    "1080p": (1920, 1080, False, 256, 256),
+    # The ring is one evenly spaced slab, so a launch may hold any number of frames (grid.z = frame);
+    # ~1.5 GB of traffic per launch measured best (4K: 32 frames 1 % faster than 64; 1080p: 128 frames
+    # 5 % faster than 32).
+    "4k": (3840, 2160, False, 64, 32),
+    "1080p": (1920, 1080, False, 256, 128),
     "8k-half": (7680, 4320, True, 16, 16),
 }
 GAMMAS = {"apple": 0, "srgb": 1, "linear": 2, "itu709": 3}
@@ -51,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=0, help="distinct frames resident per GPU (0 = workload default)")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = workload default (the whole ring)")
     ap.add_argument("--gamma", default="apple", choices=sorted(GAMMAS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
@@ -61,9 +64,10 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def geometry(workload, ring_arg, max_batch):
+def geometry(workload, ring_arg, max_batch, per_launch_arg=0):
     """Per-GPU plan of one step: ring size, frames per launch, launches, byte counts."""
     W, H, half, ring_default, per_launch = WORKLOADS[workload]
+    per_launch = per_launch_arg or per_launch
     ring = ring_arg or ring_default
     per_launch = max(1, min(per_launch, ring, max_batch))
     ring -= ring % per_launch
@@ -249,7 +253,7 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    g = geometry(args.workload, args.ring, 65535)
+    g = geometry(args.workload, args.ring, 65535, args.frames_per_launch)
     runner = DryRunner() if args.dry_run else GpuRunner(args, g, rank, local_rank)
 
     def barrier():

@@ -234,9 +234,11 @@ def test_bench_two_ranks_gloo_dry_run():
 def test_bench_geometry():
     import bench
     g = bench.geometry("4k", 0, 65535)
-    assert (g["ring"], g["per_launch"], g["launches"]) == (64, 64, 1)
-    g = bench.geometry("4k", 0, 32)
     assert (g["ring"], g["per_launch"], g["launches"]) == (64, 32, 2)
+    g = bench.geometry("1080p", 0, 65535)
+    assert (g["ring"], g["per_launch"], g["launches"]) == (256, 128, 2)
+    g = bench.geometry("4k", 0, 65535, 64)
+    assert (g["ring"], g["per_launch"], g["launches"]) == (64, 64, 1)
     assert g["bytes_per_frame"] == 45_619_200
     g = bench.geometry("1080p", 0, 32)
     assert g["bytes_per_frame"] == 11_404_800
