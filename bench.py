@@ -141,7 +141,7 @@ class GpuRunner:
         # ~20-50 launches (tens of ms) before its clocks settle (measured: 308 -> 248 us per
         # launch, tools/launchprobe.py).  Done here, before the W warmup steps, so that a
         # small --warmup still times the settled kernel.
-        t_end = time.perf_counter() + 0.4
+        t_end = time.perf_counter() + float(os.environ.get("BT709_BENCH_PREWARM_S", "0.4"))
         while time.perf_counter() < t_end:
             self.step()
             self.sync()

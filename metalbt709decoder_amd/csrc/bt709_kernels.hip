@@ -219,14 +219,34 @@ decode_nv12_quads(const DecodeParams p) {
     const uint32_t q = min(q0 + u * blockDim.x, quads - 1);
     ya[u] = load32<NT>(y0 + 4 * q);
     yb[u] = load32<NT>(y1 + 4 * q);
+#if !defined(BT709_LAB_LDS_CHROMA)
     cw[u] = load32<NT>(cc + 4 * q);
+#endif
     if (HAS_ALPHA) {
       aa[u] = *reinterpret_cast<const uint32_t *>(a0 + 4 * q);
       ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
     }
   }
+#if defined(BT709_LAB_LDS_CHROMA)
+  // tools/decode_lab only: the north-star's "LDS-staged chroma tile" -- the CbCr row segment of
+  // the tile is fetched with 16-byte loads by a quarter of the lanes, parked in LDS behind the
+  // table, and every lane reads its dword(s) back after the barrier.  (Needs quads % 4 == 0.)
+  uint32_t *chroma_lds = reinterpret_cast<uint32_t *>(lds_raw + p.table_bytes);
+  {
+    const uint32_t span = blockDim.x * UNROLL;                  // dwords of CbCr this tile needs
+    const uint32_t base = blockIdx.x * span;
+    for (uint32_t i = threadIdx.x; i < span / 4; i += blockDim.x) {
+      const uint32_t qd = min(base + 4 * i, quads - 4);
+      reinterpret_cast<u32x4 *>(chroma_lds)[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(cc + 4 * qd));
+    }
+  }
+#endif
   stage_table(tbl, p.table, p.table_bytes);  // after the tile's loads are in flight
   __syncthreads();
+#if defined(BT709_LAB_LDS_CHROMA)
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) cw[u] = chroma_lds[threadIdx.x + u * blockDim.x];
+#endif
   // Pin every loaded dword here: hipcc then waits for all of the tile's loads once, before any
   // store is issued, instead of emitting s_waitcnt vmcnt(0) between the first quad's stores and
   // the second quad's arithmetic (which would wait for the stores' write acknowledgements).
@@ -449,7 +469,11 @@ decode_nv12_half(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
+#if defined(BT709_LAB_LDS_CHROMA)
+  const size_t lds = p.table_bytes + 4 * block_threads * kQuadsPerLane;  // + the staged CbCr segment
+#else
   const size_t lds = p.table_bytes;
+#endif
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
     const uint32_t by = quads_rows_per_block(block_threads, grid_x);

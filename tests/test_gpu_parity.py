@@ -252,6 +252,32 @@ def test_one_stream_per_in_flight_frame(gh, oracle):
         cb.release()
 
 
+def test_one_decoder_shared_by_host_threads(gh, oracle):
+    """The decoder keeps no per-frame state (unlike the reference, MetalBT709Decoder.m:449-452),
+    so host threads may share it, each with its own stream."""
+    from concurrent.futures import ThreadPoolExecutor
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    w, h = 256, 32
+    jobs = []
+    for t in range(8):
+        y, c = gh.random_nv12(w, h, seed=500 + t)
+        jobs.append((y, c, gh.make_buffer(y, c, dec.gamma), ctx.makeBGRATexture((w, h)),
+                     ctx.commandQueue.commandBuffer(new_stream=True)))
+
+    def work(job):
+        y, c, buf, tex, cb = job
+        for _ in range(20):
+            assert dec.decodeBT709(buf, None, tex, cb, None, w, h, True)
+        return ctx.getBGRATexturePixels(tex, cb).view(np.uint8).reshape(h, w * 4)
+
+    with ThreadPoolExecutor(8) as ex:
+        outs = list(ex.map(work, jobs))
+    for (y, c, _, _, cb), got in zip(jobs, outs):
+        assert np.array_equal(got, oracle.decode_nv12(0, y, c))
+        cb.release()
+
+
 def test_decode_is_idempotent_and_stateless(gh):
     """The decoder keeps no per-frame state: decoding A, then B, then A again gives A's bytes."""
     dec = gh.make_decoder(mb.MetalBT709GammaApple)

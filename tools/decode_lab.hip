@@ -16,6 +16,11 @@
 #include <vector>
 
 #include "../metalbt709decoder_amd/csrc/bt709_kernels.hip"
+#if defined(BT709_LAB_LDS_CHROMA)
+#define LAB_EXTRA_LDS 4096
+#else
+#define LAB_EXTRA_LDS 0
+#endif
 
 #define CK(x)                                                                        \
   do {                                                                               \
