@@ -9,14 +9,24 @@
 //   (., Cb, Cr) = sRGB_from_sRGB_convertRGBToYCbCr(avgByte)     BT709.h:914-944 -> 199-268
 //   Y[i]       = sRGB_from_sRGB_convertRGBToYCbCr(BT709_from_linear(lin[i][c], outputGamma))[0]
 //                                                               BT709.h:1423-1487   (per-byte LUT, exact)
-// with the matrix of BT709.h:222-244: Ey = (Kr*R + Kg*G) + Kb*B, Eb = (B-Ey)/1.8556f,
-// Er = (R-Ey)/1.5748f, Y = round(Ey*219 + 16), C = round(E*224 + 128).  The two divisions
-// are IEEE correctly rounded (__fdiv_rn); round() is C's half-away-from-zero on a positive
-// float.  No multiply-add is contracted (-ffp-contract=off); the division's own internal
-// FMAs are part of a correctly rounded quotient.
+// with the matrix of BT709.h:222-246: Ey = (Kr*R + Kg*G) + Kb*B, Eb = (B-Ey)/1.8556f,
+// Er = (R-Ey)/1.5748f, Y = round(Ey*219 + 16), C = round(E*224 + 128).
+//
+// Exactness notes:
+//   * the per-byte LUT already holds the float product K_c * byteNorm(encoded byte), so a pixel's
+//     Ey is two adds;
+//   * x / c for the two constant divisors is computed as q0 = x*rc, q = fma(fma(-c, q0, x), rc, q0)
+//     with rc = fl(1/c): this equals the correctly rounded quotient for EVERY float with
+//     1e-30 <= |x| <= 4 (exhaustive check over all 2^32 patterns: tools/div_exact.hip, run by
+//     tests/test_encoder.py); operands here are in [-1.1, 1.1], and a zero operand only differs in
+//     the sign of zero, which the following "+ 128" erases.  These two FMAs are the division's own
+//     error-correction steps, not a contracted multiply-add of the reference's expression;
+//   * round() of a positive float v is ((uint)(2v) + 1) >> 1 (floor(v + 1/2) in integers); the
+//     doubling is folded into the constants (power of two: exact).
 //
 // A lane owns a 4x2-pixel quad (two blocks): two 16-byte loads, three 4-byte stores; lanes
-// of a wave are consecutive quads of one row pair; grid = (tiles, row pairs, 1).
+// of a wave are consecutive quads of one row pair; grid = (tiles, row pairs / 2, 1).  LDS holds
+// the three 2 KiB per-byte tables and the two-resolution BT709_from_linear table.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -29,106 +39,136 @@ namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t round_pos(float v) {
-  // (int)round((double)v) for v >= 0: ties away from zero
-  const float t = __builtin_truncf(v);
-  return static_cast<uint32_t>(t) + ((v - t) >= 0.5f ? 1u : 0u);
+constexpr float kRcCb = 1.0f / kCbSpan;  // fl(1/1.8556f)
+constexpr float kRcCr = 1.0f / kCrSpan;  // fl(1/1.5748f)
+
+__device__ __forceinline__ float div_const(float x, float c, float rc) {
+  const float q0 = __fmul_rn(x, rc);
+  return __fmaf_rn(__fmaf_rn(-c, q0, x), rc, q0);
 }
 
-struct Ycc {
-  float ey, eb, er;
+// (int)round((double)(e * scale + offset)) for a positive result, via the doubled value
+__device__ __forceinline__ uint32_t quant2(float e, float scale2, float offset2) {
+  const uint32_t t2 = static_cast<uint32_t>(__fadd_rn(__fmul_rn(e, scale2), offset2));  // floor(2v)
+  return (t2 + 1u) >> 1;
+}
+
+struct EncodeLds {
+  const EncodeByteEntry *r, *g, *b;
+  const TransferBucket *fl;  // two-resolution table (transfer_tables.h SplitTable)
+  float split, coarse;
+  uint32_t offset;
 };
 
-__device__ __forceinline__ Ycc rgbn_to_e(float rn, float gn, float bn) {
-  Ycc o;
-  o.ey = __fadd_rn(__fadd_rn(__fmul_rn(kKr, rn), __fmul_rn(kKg, gn)), __fmul_rn(kKb, bn));  // BT709.h:222
-  o.eb = __fdiv_rn(__fadd_rn(bn, -o.ey), kCbSpan);                                            // BT709.h:223
-  o.er = __fdiv_rn(__fadd_rn(rn, -o.ey), kCrSpan);                                            // BT709.h:224
-  return o;
-}
-
-__device__ __forceinline__ uint32_t quant_y(float ey) {  // BT709.h:233, 244
-  return round_pos(__fadd_rn(__fmul_rn(ey, static_cast<float>(kYMax - kYMin)), 16.0f));
-}
-__device__ __forceinline__ uint32_t quant_c(float e) {  // BT709.h:234-235, 245-246
-  return round_pos(__fadd_rn(__fmul_rn(e, static_cast<float>(kCMax - kCMin)), 128.0f));
-}
-
-__device__ __forceinline__ uint32_t from_linear(const TransferBucket *__restrict__ tbl, float n, float v) {
-  const float xs = __fmul_rn(v, n);  // exact: n is a power of two
-  const uint32_t q = static_cast<uint32_t>(xs);
-  const TransferBucket e = tbl[q];
+__device__ __forceinline__ uint32_t from_linear(const EncodeLds &t, float xs) {
+  const uint32_t qf = static_cast<uint32_t>(xs);
+  const uint32_t qc = static_cast<uint32_t>(__fmul_rn(xs, t.coarse)) + t.offset;  // exact: power of two
+  const TransferBucket e = t.fl[xs < t.split ? qf : qc];
   return e.base + (xs >= e.edge ? 1u : 0u);
 }
 
 // one 2x2 block: p = {top-left, top-right, bottom-left, bottom-right} BGRA words
-__device__ __forceinline__ void encode_block(const EncodeByteEntry *__restrict__ bytes,
-                                             const TransferBucket *__restrict__ fl, float fl_n, const uint32_t p[4],
-                                             uint32_t y[4], uint32_t &cb, uint32_t &cr) {
-  float sum[3] = {0.f, 0.f, 0.f};
+__device__ __forceinline__ void encode_block(const EncodeLds &t, float fl_quarter_n, const uint32_t p[4], uint32_t y[4],
+                                             uint32_t &cb, uint32_t &cr) {
+  float sr = 0.f, sg = 0.f, sb = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const EncodeByteEntry r = bytes[(p[i] >> 16) & 0xff];
-    const EncodeByteEntry g = bytes[(p[i] >> 8) & 0xff];
-    const EncodeByteEntry b = bytes[p[i] & 0xff];
-    sum[0] = i ? __fadd_rn(sum[0], r.lin) : r.lin;
-    sum[1] = i ? __fadd_rn(sum[1], g.lin) : g.lin;
-    sum[2] = i ? __fadd_rn(sum[2], b.lin) : b.lin;
-    y[i] = quant_y(rgbn_to_e(r.enc_norm, g.enc_norm, b.enc_norm).ey);
+    const EncodeByteEntry r = t.r[(p[i] >> 16) & 0xff];
+    const EncodeByteEntry g = t.g[(p[i] >> 8) & 0xff];
+    const EncodeByteEntry b = t.b[p[i] & 0xff];
+    sr = i ? __fadd_rn(sr, r.lin) : r.lin;
+    sg = i ? __fadd_rn(sg, g.lin) : g.lin;
+    sb = i ? __fadd_rn(sb, b.lin) : b.lin;
+    const float ey = __fadd_rn(__fadd_rn(r.k_enc, g.k_enc), b.k_enc);                 // BT709.h:222
+    y[i] = quant2(ey, 2.0f * static_cast<float>(kYMax - kYMin), 32.0f);               // BT709.h:233, 244
   }
-  float an[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-    an[c] = __fmul_rn(static_cast<float>(from_linear(fl, fl_n, __fmul_rn(sum[c], 0.25f))), kInv255);  // /4.0f, byteNorm
-  const Ycc a = rgbn_to_e(an[0], an[1], an[2]);
-  cb = quant_c(a.eb);
-  cr = quant_c(a.er);
+  // ave = sum / 4.0f, then scaled into the table's domain: sum * (0.25 * N), both powers of two
+  const float rn = __fmul_rn(static_cast<float>(from_linear(t, __fmul_rn(sr, fl_quarter_n))), kInv255);
+  const float gn = __fmul_rn(static_cast<float>(from_linear(t, __fmul_rn(sg, fl_quarter_n))), kInv255);
+  const float bn = __fmul_rn(static_cast<float>(from_linear(t, __fmul_rn(sb, fl_quarter_n))), kInv255);
+  const float ey = __fadd_rn(__fadd_rn(__fmul_rn(kKr, rn), __fmul_rn(kKg, gn)), __fmul_rn(kKb, bn));
+  const float eb = div_const(__fadd_rn(bn, -ey), kCbSpan, kRcCb);                      // BT709.h:223
+  const float er = div_const(__fadd_rn(rn, -ey), kCrSpan, kRcCr);                      // BT709.h:224
+  cb = quant2(eb, 2.0f * static_cast<float>(kCMax - kCMin), 256.0f);                   // BT709.h:234, 245
+  cr = quant2(er, 2.0f * static_cast<float>(kCMax - kCMin), 256.0f);                   // BT709.h:235, 246
+}
+
+__device__ __forceinline__ EncodeLds stage_encode_tables(unsigned char *lds_raw, const EncodeParams &p) {
+  u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
+  const u32x4 *sb = reinterpret_cast<const u32x4 *>(p.per_byte);
+  const u32x4 *sf = reinterpret_cast<const u32x4 *>(p.from_linear);
+  const uint32_t nb = 3 * 256 * sizeof(EncodeByteEntry) / 16, nf = p.from_linear_bytes / 16;
+  // (The first version staged a uniform 33 KiB BT709_from_linear table here -- ten dependent L2
+  // round trips per workgroup -- and a version that left it in global memory was bound by the
+  // 64-line gathers; the two-resolution table is 6-10 KiB.)
+  for (uint32_t i = threadIdx.x; i < nb + nf; i += blockDim.x) d[i] = i < nb ? sb[i] : sf[i - nb];
+  EncodeLds t;
+  t.r = reinterpret_cast<const EncodeByteEntry *>(lds_raw);
+  t.g = t.r + 256;
+  t.b = t.r + 512;
+  t.fl = reinterpret_cast<const TransferBucket *>(t.r + 768);
+  t.split = p.from_linear_split;
+  t.coarse = p.from_linear_coarse;
+  t.offset = p.from_linear_offset;
+  return t;
 }
 
 }  // namespace
 
+// Consecutive row pairs one workgroup walks (prefetching the next while it encodes the current).
+
+
 __global__ void __launch_bounds__(kBlockThreads)
 encode_bgra_nv12(const EncodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  EncodeByteEntry *bytes = reinterpret_cast<EncodeByteEntry *>(lds_raw);
-  TransferBucket *fl = reinterpret_cast<TransferBucket *>(lds_raw + 256 * sizeof(EncodeByteEntry));
-
   const uint32_t quads = p.width >> 2;
-  const uint32_t rp = blockIdx.y;
+  const uint32_t row_pairs = p.height >> 1;
   const uint32_t q_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t q = min(q_raw, quads - 1);
-  const uint8_t *s0 = p.bgra + static_cast<size_t>(2 * rp) * p.bgra_stride + 16 * static_cast<size_t>(q);
-  const u32x4 top = *reinterpret_cast<const u32x4 *>(s0);
-  const u32x4 bot = *reinterpret_cast<const u32x4 *>(s0 + p.bgra_stride);
+  const uint32_t rp0 = blockIdx.y * p.row_pairs_per_block;
+  const uint32_t rp_end = min(rp0 + p.row_pairs_per_block, row_pairs);
 
-  {  // stage both tables after the loads are in flight
-    u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
-    const u32x4 *sb = reinterpret_cast<const u32x4 *>(p.per_byte);
-    const u32x4 *sf = reinterpret_cast<const u32x4 *>(p.from_linear);
-    const uint32_t nb = 256 * sizeof(EncodeByteEntry) / 16, nf = p.from_linear_bytes / 16;
-    for (uint32_t i = threadIdx.x; i < nb + nf; i += blockDim.x) d[i] = i < nb ? sb[i] : sf[i - nb];
-  }
+  const uint8_t *s0 = p.bgra + static_cast<size_t>(2 * rp0) * p.bgra_stride + 16 * static_cast<size_t>(q);
+  u32x4 top = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0));
+  u32x4 bot = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0 + p.bgra_stride));
+
+  const EncodeLds t = stage_encode_tables(lds_raw, p);  // after the first loads are in flight
   __syncthreads();
+  const float quarter_n = __fmul_rn(0.25f, p.from_linear_scale);
 
-  uint32_t ya[4], yb[4], cb0, cr0, cb1, cr1;
-  {
-    const uint32_t blk[4] = {top.x, top.y, bot.x, bot.y};
-    uint32_t y4[4];
-    encode_block(bytes, fl, p.from_linear_scale, blk, y4, cb0, cr0);
-    ya[0] = y4[0], ya[1] = y4[1], yb[0] = y4[2], yb[1] = y4[3];
-  }
-  {
-    const uint32_t blk[4] = {top.z, top.w, bot.z, bot.w};
-    uint32_t y4[4];
-    encode_block(bytes, fl, p.from_linear_scale, blk, y4, cb1, cr1);
-    ya[2] = y4[0], ya[3] = y4[1], yb[2] = y4[2], yb[3] = y4[3];
-  }
-  if (q_raw < quads) {
-    uint8_t *y0 = p.y + static_cast<size_t>(2 * rp) * p.y_stride + 4 * static_cast<size_t>(q);
-    *reinterpret_cast<uint32_t *>(y0) = ya[0] | (ya[1] << 8) | (ya[2] << 16) | (ya[3] << 24);
-    *reinterpret_cast<uint32_t *>(y0 + p.y_stride) = yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24);
-    *reinterpret_cast<uint32_t *>(p.cbcr + static_cast<size_t>(rp) * p.cbcr_stride + 4 * static_cast<size_t>(q)) =
-        cb0 | (cr0 << 8) | (cb1 << 16) | (cr1 << 24);  // Cb low byte, Cr high (CVPixelBufferUtils.h:358-361)
+  for (uint32_t rp = rp0; rp < rp_end; ++rp) {
+    // prefetch the next row pair (clamped: the last iteration re-reads its own rows) before the arithmetic
+    const uint32_t rn = min(rp + 1, rp_end - 1);
+    const uint8_t *s1 = p.bgra + static_cast<size_t>(2 * rn) * p.bgra_stride + 16 * static_cast<size_t>(q);
+    const u32x4 ntop = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1));
+    const u32x4 nbot = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1 + p.bgra_stride));
+
+    uint32_t ya[4], yb[4], cb0, cr0, cb1, cr1;
+    {
+      const uint32_t blk[4] = {top.x, top.y, bot.x, bot.y};
+      uint32_t y4[4];
+      encode_block(t, quarter_n, blk, y4, cb0, cr0);
+      ya[0] = y4[0], ya[1] = y4[1], yb[0] = y4[2], yb[1] = y4[3];
+    }
+    {
+      const uint32_t blk[4] = {top.z, top.w, bot.z, bot.w};
+      uint32_t y4[4];
+      encode_block(t, quarter_n, blk, y4, cb1, cr1);
+      ya[2] = y4[0], ya[3] = y4[1], yb[2] = y4[2], yb[3] = y4[3];
+    }
+    if (q_raw < quads) {
+      uint8_t *y0 = p.y + static_cast<size_t>(2 * rp) * p.y_stride + 4 * static_cast<size_t>(q);
+      __builtin_nontemporal_store(ya[0] | (ya[1] << 8) | (ya[2] << 16) | (ya[3] << 24),
+                                  reinterpret_cast<uint32_t *>(y0));
+      __builtin_nontemporal_store(yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24),
+                                  reinterpret_cast<uint32_t *>(y0 + p.y_stride));
+      // Cb low byte, Cr high (CVPixelBufferUtils.h:358-361)
+      __builtin_nontemporal_store(
+          cb0 | (cr0 << 8) | (cb1 << 16) | (cr1 << 24),
+          reinterpret_cast<uint32_t *>(p.cbcr + static_cast<size_t>(rp) * p.cbcr_stride + 4 * static_cast<size_t>(q)));
+    }
+    top = ntop;
+    bot = nbot;
   }
 }
 
@@ -136,16 +176,9 @@ encode_bgra_nv12(const EncodeParams p) {
 __global__ void __launch_bounds__(kBlockThreads)
 encode_bgra_nv12_blocks(const EncodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  EncodeByteEntry *bytes = reinterpret_cast<EncodeByteEntry *>(lds_raw);
-  TransferBucket *fl = reinterpret_cast<TransferBucket *>(lds_raw + 256 * sizeof(EncodeByteEntry));
-  {
-    u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
-    const u32x4 *sb = reinterpret_cast<const u32x4 *>(p.per_byte);
-    const u32x4 *sf = reinterpret_cast<const u32x4 *>(p.from_linear);
-    const uint32_t nb = 256 * sizeof(EncodeByteEntry) / 16, nf = p.from_linear_bytes / 16;
-    for (uint32_t i = threadIdx.x; i < nb + nf; i += blockDim.x) d[i] = i < nb ? sb[i] : sf[i - nb];
-  }
+  const EncodeLds t = stage_encode_tables(lds_raw, p);
   __syncthreads();
+  const float quarter_n = __fmul_rn(0.25f, p.from_linear_scale);
   const uint32_t bw = p.width >> 1;
   const uint32_t rp = blockIdx.y;
   for (uint32_t bx = blockIdx.x * blockDim.x + threadIdx.x; bx < bw; bx += gridDim.x * blockDim.x) {
@@ -153,7 +186,7 @@ encode_bgra_nv12_blocks(const EncodeParams p) {
     const uint32_t *r1 = reinterpret_cast<const uint32_t *>(p.bgra + static_cast<size_t>(2 * rp + 1) * p.bgra_stride);
     const uint32_t blk[4] = {r0[2 * bx], r0[2 * bx + 1], r1[2 * bx], r1[2 * bx + 1]};
     uint32_t y4[4], cb, cr;
-    encode_block(bytes, fl, p.from_linear_scale, blk, y4, cb, cr);
+    encode_block(t, quarter_n, blk, y4, cb, cr);
     uint8_t *y0 = p.y + static_cast<size_t>(2 * rp) * p.y_stride;
     uint8_t *y1 = y0 + p.y_stride;
     uint8_t *c = p.cbcr + static_cast<size_t>(rp) * p.cbcr_stride;
@@ -167,10 +200,11 @@ encode_bgra_nv12_blocks(const EncodeParams p) {
 }
 
 const char *launch_encode(const EncodeParams &p, bool fast, hipStream_t stream) {
-  const size_t lds = 256 * sizeof(EncodeByteEntry) + p.from_linear_bytes;
+  const size_t lds = 3 * 256 * sizeof(EncodeByteEntry) + p.from_linear_bytes;
   if (fast) {
     const uint32_t quads = p.width / 4;
-    const dim3 grid((quads + kBlockThreads - 1) / kBlockThreads, p.height / 2, 1);
+    const dim3 grid((quads + kBlockThreads - 1) / kBlockThreads,
+                    (p.height / 2 + p.row_pairs_per_block - 1) / p.row_pairs_per_block, 1);
     hipLaunchKernelGGL(encode_bgra_nv12, grid, dim3(kBlockThreads), lds, stream, p);
     return "encode_bgra_nv12";
   }

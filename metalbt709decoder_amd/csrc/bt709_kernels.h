@@ -31,11 +31,13 @@ struct FramePlanes {
 struct DecodeParams {
   FramePlanes frames[kMaxBatch];
   const void *table;   // TransferBucket[] (decode) or TransferBucketLinear[] (half)
-  const void *table2;  // half only: LINEAR-mode TransferBucket[] used as the sRGB encoder
+  const void *table2;  // half only: two-resolution sRGB-encode table (transfer_tables.h SplitTable)
   uint32_t table_bytes;
   uint32_t table2_bytes;
   float table_scale;   // N of `table`
-  float table2_scale;  // N of `table2`
+  float table2_scale;  // n_fine of `table2`
+  float table2_split, table2_coarse;  // SplitTable index parameters of `table2`
+  uint32_t table2_offset;
   // BT709.h:389-397 matrix entries times table_scale (exact: power-of-two scaling)
   float m_y, m_cr_r, m_cb_g, m_cr_g, m_cb_b;
   uint32_t width;      // luma (source) dimensions
@@ -56,9 +58,13 @@ struct EncodeParams {
   uint8_t *y;
   uint8_t *cbcr;
   const EncodeByteEntry *per_byte;  // 256 entries for the (input gamma, output gamma) pair
-  const TransferBucket *from_linear;  // unit part of the BT709_from_linear(., output gamma) table
+  const TransferBucket *from_linear;  // two-resolution BT709_from_linear(., output gamma) table (SplitTable)
   uint32_t from_linear_bytes;
-  float from_linear_scale;  // its N
+  float from_linear_scale;    // its n_fine
+  float from_linear_split;    // fine buckets below this xs ...
+  float from_linear_coarse;   // ... coarse ones above: q = (uint)(xs * coarse) + offset
+  uint32_t from_linear_offset;
+  uint32_t row_pairs_per_block;  // consecutive row pairs a fast-path workgroup walks (>= 1)
   uint32_t width, height;
   uint32_t bgra_stride, y_stride, cbcr_stride;
 };

@@ -363,8 +363,22 @@ __device__ __forceinline__ float linear_select(const u32x4 &e, float xs) {
   return xs >= __uint_as_float(e.x) ? __uint_as_float(e.z) : __uint_as_float(e.y);
 }
 
+struct SplitIndex {  // transfer_tables.h SplitTable
+  float split, coarse;
+  uint32_t offset;
+};
+
+// two-resolution table: fine buckets below `split`, `1/coarse` times wider ones above
+__device__ __forceinline__ uint32_t lookup_split(const TransferBucket *__restrict__ tbl, const SplitIndex &s, float xs) {
+  const uint32_t qf = static_cast<uint32_t>(xs);
+  const uint32_t qc = static_cast<uint32_t>(__fmul_rn(xs, s.coarse)) + s.offset;  // exact: power of two
+  const TransferBucket e = tbl[xs < s.split ? qf : qc];
+  return e.base + (xs >= e.edge ? 1u : 0u);
+}
+
 __device__ __forceinline__ uint32_t half_px(const TransferBucketLinear *__restrict__ dec, float dn, const Matrix &m,
-                                            const TransferBucket *__restrict__ enc, float en, float y00, float y01,
+                                            const TransferBucket *__restrict__ enc, const SplitIndex &es, float en,
+                                            float y00, float y01,
                                             float y10, float y11, const Chroma &c, uint32_t alpha_word) {
   float x[12];  // r0..r3, g0..g3, b0..b3 of the four source pixels
   pixel_rgbs(m, y00, c, x[0], x[4], x[8]);
@@ -392,9 +406,9 @@ __device__ __forceinline__ uint32_t half_px(const TransferBucketLinear *__restri
   const float mr = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]), k);
   const float mg = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]), k);
   const float mb = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]), k);
-  const uint32_t R = lookup(enc, mr);
-  const uint32_t G = lookup(enc, mg);
-  const uint32_t B = lookup(enc, mb);
+  const uint32_t R = lookup_split(enc, es, mr);
+  const uint32_t G = lookup_split(enc, es, mg);
+  const uint32_t B = lookup_split(enc, es, mb);
   return pack_bgra(R, G, B, alpha_word);
 }
 
@@ -412,6 +426,7 @@ decode_nv12_half(const DecodeParams p) {
   const FramePlanes f = frame_planes(p, blockIdx.z);
   const Matrix m = matrix_of(p);
   const float en = p.table2_scale, dn = p.table_scale;
+  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset};
   const uint32_t out_rows = p.height >> 1;
   const uint32_t orow_raw = blockIdx.y * blockDim.y + threadIdx.y;
   const uint32_t orow = min(orow_raw, out_rows - 1);
@@ -443,9 +458,9 @@ decode_nv12_half(const DecodeParams p) {
       const Chroma c0 = chroma_terms(m, byte_of(cw[u], 0), byte_of(cw[u], 1));
       const Chroma c1 = chroma_terms(m, byte_of(cw[u], 2), byte_of(cw[u], 3));
       u32x2 v;
-      v.x = half_px(dec, dn, m, enc, en, byte_of(ya[u], 0), byte_of(ya[u], 1), byte_of(yb[u], 0), byte_of(yb[u], 1), c0,
+      v.x = half_px(dec, dn, m, enc, es, en, byte_of(ya[u], 0), byte_of(ya[u], 1), byte_of(yb[u], 0), byte_of(yb[u], 1), c0,
                     p.alpha_word);
-      v.y = half_px(dec, dn, m, enc, en, byte_of(ya[u], 2), byte_of(ya[u], 3), byte_of(yb[u], 2), byte_of(yb[u], 3), c1,
+      v.y = half_px(dec, dn, m, enc, es, en, byte_of(ya[u], 2), byte_of(ya[u], 3), byte_of(yb[u], 2), byte_of(yb[u], 3), c1,
                     p.alpha_word);
       if (q < quads && orow_raw < out_rows) store8<NT>(o + 8 * q, v);
     }
@@ -458,7 +473,7 @@ decode_nv12_half(const DecodeParams p) {
          ox += gridDim.x * blockDim.x) {
       const Chroma c = chroma_terms(m, static_cast<float>(cc[2 * ox]), static_cast<float>(cc[2 * ox + 1]));
       reinterpret_cast<uint32_t *>(o)[ox] =
-          half_px(dec, dn, m, enc, en, static_cast<float>(y0[2 * ox]), static_cast<float>(y0[2 * ox + 1]),
+          half_px(dec, dn, m, enc, es, en, static_cast<float>(y0[2 * ox]), static_cast<float>(y0[2 * ox + 1]),
                   static_cast<float>(y1[2 * ox]), static_cast<float>(y1[2 * ox + 1]), c, p.alpha_word);
     }
   }

@@ -26,6 +26,8 @@ struct EncoderTables {  // device copies for one (input gamma, output gamma) pai
   void *d_from_linear = nullptr;
   uint32_t from_linear_bytes = 0;
   uint32_t from_linear_n = 0;
+  float split = 0.0f, coarse_scale = 1.0f;
+  uint32_t coarse_offset = 0;
 };
 
 struct bt709hip_context {
@@ -54,6 +56,8 @@ struct bt709hip_decoder {
   void *d_encode = nullptr;        // LINEAR-mode TransferBucket[] (half-scale encode side)
   uint32_t encode_bytes = 0;
   uint32_t encode_n = 0;
+  float encode_split = 0.0f, encode_coarse = 1.0f;
+  uint32_t encode_offset = 0;
 };
 
 namespace {
@@ -420,16 +424,19 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   if (dec->ready) return BT709HIP_OK;                      // second call is a nop (.m:66-70)
   if (int rc = bind(dec->ctx)) return rc;
 
-  TransferTable t, enc;
-  if (!build_transfer_table(dec->gamma, &t) || !build_transfer_table(kGammaLinear, &enc))
+  TransferTable t;
+  SplitTable enc;  // sRGB encoder of the rescale kernel: two-resolution form (6 KiB instead of 33)
+  if (!build_transfer_table(dec->gamma, &t) || !build_split_table(kGammaLinear, &enc))
     return BT709HIP_ERR_UNSUPPORTED;
   dec->table_n = t.n;
   dec->table_bytes = static_cast<uint32_t>(t.buckets.size() * sizeof(TransferBucket));
   // rescale kernel: unit part only (it clamps), see lookup_linear
   dec->table_linear_bytes = static_cast<uint32_t>(t.unit_entries * sizeof(TransferBucketLinear));
-  dec->encode_n = enc.n;
-  // the encode side of the rescale only ever sees means in [0,1]: upload the unit part only
-  dec->encode_bytes = static_cast<uint32_t>(enc.unit_entries * sizeof(TransferBucket));
+  dec->encode_n = enc.n_fine;
+  dec->encode_split = enc.split;
+  dec->encode_coarse = enc.coarse_scale;
+  dec->encode_offset = enc.coarse_offset;
+  dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
   if (int rc = upload_table(t.buckets.data(), dec->table_bytes, &dec->d_table)) return rc;
   if (int rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &dec->d_table_linear)) return rc;
   if (int rc = upload_table(enc.buckets.data(), dec->encode_bytes, &dec->d_encode)) return rc;
@@ -558,6 +565,9 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   p.table2 = dec->d_encode;
   p.table2_bytes = dec->encode_bytes;
   p.table2_scale = static_cast<float>(dec->encode_n);
+  p.table2_split = dec->encode_split;
+  p.table2_coarse = dec->encode_coarse;
+  p.table2_offset = dec->encode_offset;
   p.width = static_cast<uint32_t>(f0.width);
   p.height = static_cast<uint32_t>(f0.height);
   p.y_stride = static_cast<uint32_t>(f0.y_stride);
@@ -601,11 +611,14 @@ int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt7
     std::lock_guard<std::mutex> lock(ctx->encoder_mutex);
     if (t.d_per_byte == nullptr) {
       EncodeTables host;
-      TransferTable fl;
-      if (!build_encode_tables(input_gamma, output_gamma, &host) || !build_transfer_table(host.from_linear_kind, &fl))
+      SplitTable fl;
+      if (!build_encode_tables(input_gamma, output_gamma, &host) || !build_split_table(host.from_linear_kind, &fl))
         return BT709HIP_ERR_UNSUPPORTED;
-      t.from_linear_n = fl.n;
-      t.from_linear_bytes = static_cast<uint32_t>(fl.unit_entries * sizeof(TransferBucket));  // averages stay in [0,1]
+      t.from_linear_n = fl.n_fine;
+      t.split = fl.split;
+      t.coarse_scale = fl.coarse_scale;
+      t.coarse_offset = fl.coarse_offset;
+      t.from_linear_bytes = static_cast<uint32_t>(fl.buckets.size() * sizeof(TransferBucket));
       if (int rc = upload_table(fl.buckets.data(), t.from_linear_bytes, &t.d_from_linear)) return rc;
       if (int rc = upload_table(host.per_byte, sizeof host.per_byte, &t.d_per_byte)) return rc;
     }
@@ -620,6 +633,11 @@ int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt7
   p.from_linear = static_cast<const TransferBucket *>(t.d_from_linear);
   p.from_linear_bytes = t.from_linear_bytes;
   p.from_linear_scale = static_cast<float>(t.from_linear_n);
+  p.from_linear_split = t.split;
+  p.from_linear_coarse = t.coarse_scale;
+  p.from_linear_offset = t.coarse_offset;
+  p.row_pairs_per_block = static_cast<uint32_t>(env_int("BT709HIP_ENCODE_ROWPAIRS", 3));
+  if (p.row_pairs_per_block < 1) p.row_pairs_per_block = 1;
   p.width = static_cast<uint32_t>(in->width);
   p.height = static_cast<uint32_t>(in->height);
   p.bgra_stride = static_cast<uint32_t>(in->stride);

@@ -149,6 +149,52 @@ bool build_transfer_table(int gamma, TransferTable *out) {
   return false;
 }
 
+bool build_split_table(int kind, SplitTable *out) {
+  if (kind < 0 || kind >= kTableKinds || out == nullptr) return false;
+  float thr[255];
+  for (int k = 1; k <= 255; ++k) thr[k - 1] = find_threshold(kind, k);
+  const float inf = std::numeric_limits<float>::infinity();
+  // candidates, smallest table first; the last one is a plain uniform table
+  const struct { uint32_t n_fine, split, ratio; } cand[] = {
+      {256, 256, 1},   {512, 512, 1},   {1024, 64, 4},  {2048, 128, 4},  {4096, 256, 8},
+      {4096, 256, 4},  {4096, 512, 4},  {8192, 512, 8}, {8192, 1024, 4}, {4096, 4096, 1}, {8192, 8192, 1}};
+  for (const auto &c : cand) {
+    const uint32_t coarse_n = c.n_fine / c.ratio;  // coarse buckets over [0,1]
+    const uint32_t offset = c.split - c.split / c.ratio;
+    const uint32_t total = c.split + (coarse_n - c.split / c.ratio) + 1;  // +1: x == 1.0
+    std::vector<TransferBucket> b(total);
+    bool ok = true;
+    int k = 0;
+    for (uint32_t q = 0; q < total && ok; ++q) {
+      float lo, hi;  // bucket bounds in x
+      if (q < c.split) {
+        lo = static_cast<float>(q) / c.n_fine;
+        hi = static_cast<float>(q + 1) / c.n_fine;
+      } else {
+        const uint32_t j = q - offset;  // coarse bucket index
+        lo = static_cast<float>(j) / coarse_n;
+        hi = static_cast<float>(j + 1) / coarse_n;
+      }
+      while (k < 255 && thr[k] <= lo) ++k;
+      b[q].base = static_cast<uint32_t>(k);
+      b[q].edge = inf;
+      if (k < 255 && thr[k] < hi) {
+        b[q].edge = thr[k] * static_cast<float>(c.n_fine);  // exact: power of two
+        if (k + 1 < 255 && thr[k + 1] < hi) ok = false;
+      }
+    }
+    if (!ok) continue;
+    while ((b.size() * sizeof(TransferBucket)) % 16 != 0) b.push_back(TransferBucket{inf, 255u});
+    out->n_fine = c.n_fine;
+    out->split = static_cast<float>(c.split);
+    out->coarse_scale = 1.0f / static_cast<float>(c.ratio);
+    out->coarse_offset = offset;
+    out->buckets = b;
+    return true;
+  }
+  return false;
+}
+
 bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out) {
   if (out == nullptr) return false;
   auto ok = [](int g) { return g == kGammaApple || g == kGammaSRGB || g == kGammaLinear; };
@@ -160,8 +206,12 @@ bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out) {
     if (in_gamma == kGammaSRGB) lin = srgb_to_linear(n);
     else if (in_gamma == kGammaApple) lin = apple196_to_linear(n);
     const int e = transfer_to_byte(out->from_linear_kind, lin);  // BT709_from_linear(lin, outputGamma)
-    out->per_byte[b].lin = lin;
-    out->per_byte[b].enc_norm = e * (1.0f / 255.0f);  // byteNorm inside sRGB_from_sRGB_convertRGBToYCbCr
+    const float enc_norm = e * (1.0f / 255.0f);  // byteNorm inside sRGB_from_sRGB_convertRGBToYCbCr
+    const float k[3] = {0.2126f, 0.7152f, 0.0722f};  // BT709_Kr, Kg, Kb (BT709.h:40-42)
+    for (int c = 0; c < 3; ++c) {
+      out->per_byte[c][b].lin = lin;
+      out->per_byte[c][b].k_enc = k[c] * enc_norm;  // the float product (BT709_Kx * Xn) of BT709.h:222
+    }
   }
   return true;
 }

@@ -76,14 +76,31 @@ int transfer_to_byte(int gamma, float v);
 // BT709_average_pixel_values (Renderer/CVPixelBufferUtils.h:241-399, Renderer/BT709.h:1349-1509);
 // gammas use this file's ids (kGammaApple / kGammaSRGB / kGammaLinear).
 struct alignas(8) EncodeByteEntry {
-  float lin;       // BT709_tolinearNorm of the byte for the input gamma (BT709.h:1100-1146)
-  float enc_norm;  // byteNorm(BT709_from_linear(lin, output gamma)): the per-pixel value fed to the matrix
+  float lin;    // BT709_tolinearNorm of the byte for the input gamma (BT709.h:1100-1146)
+  float k_enc;  // K_c * byteNorm(BT709_from_linear(lin, output gamma)): this channel's term of Ey (BT709.h:222)
 };
 struct EncodeTables {
-  EncodeByteEntry per_byte[256];
-  int from_linear_kind = 0;  // table kind whose buckets implement BT709_from_linear(., output gamma)
+  EncodeByteEntry per_byte[3][256];  // [R, G, B][byte]; the three differ only in K_c = Kr, Kg, Kb
+  int from_linear_kind = 0;          // table kind whose buckets implement BT709_from_linear(., output gamma)
 };
 bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out);
+
+// Two-resolution bucket table over x in [0,1] for composites whose thresholds crowd near zero
+// (the encoder's BT709_from_linear tables need N = 4096 uniformly, 33 KiB, only because of
+// their first 1/16 of the range).  With xs = n_fine * x:
+//     q = xs < split ? (uint)xs : (uint)(xs * coarse_scale) + coarse_offset
+//     byte = buckets[q].base + (xs >= buckets[q].edge)          // edges stored times n_fine
+// i.e. buckets of width 1/n_fine below split/n_fine and ratio times wider above.
+struct SplitTable {
+  uint32_t n_fine = 0;
+  float split = 0.0f;          // in fine buckets (a multiple of ratio)
+  float coarse_scale = 1.0f;   // 1 / ratio (power of two)
+  uint32_t coarse_offset = 0;  // split - split / ratio
+  std::vector<TransferBucket> buckets;  // padded to a 16-byte multiple
+};
+// Returns false if no (n_fine, split, ratio) among the candidates leaves at most one threshold
+// per bucket.
+bool build_split_table(int kind, SplitTable *out);
 
 // Builds thresholds + buckets.  Returns false if gamma is unknown or the
 // single-threshold-per-bucket property cannot be met with N <= 65536.

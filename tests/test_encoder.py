@@ -147,6 +147,27 @@ def test_gpu_round_trip_on_device(gh, oracle):
 
 
 @pytest.mark.gpu
+def test_constant_division_shortcut_is_exact_for_every_float(gh, tmp_path):
+    """The encoder divides by 1.8556f / 1.5748f as q0 = x*rc, q = fma(fma(-c,q0,x), rc, q0).
+    tools/div_exact.hip compares that with __fdiv_rn for all 2^32 float bit patterns; it must
+    report zero mismatches for 1e-30 <= |x| <= 4 (the encoder's operands are within [-1.1, 1.1])."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "div_exact")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
+                        os.path.join(root, "tools", "div_exact.hip"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300).stdout
+    lines = [l for l in out.splitlines() if l.startswith("c=")]
+    assert len(lines) == 2, out
+    for l in lines:
+        assert l.rstrip().endswith("<=4: 0"), l
+
+
+@pytest.mark.gpu
 def test_gpu_encoder_errors(gh):
     ctx = gh.context()
     tex = ctx.makeBGRATexture((8, 4))
