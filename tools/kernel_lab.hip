@@ -236,6 +236,7 @@ struct Lab {
       p.table = d_table;
       p.table_bytes = uint32_t(tb);
       p.table_scale = float(tt.n);
+      p.m_y = kMY * tt.n; p.m_cr_r = kMCrR * tt.n; p.m_cb_g = kMCbG * tt.n; p.m_cr_g = kMCrG * tt.n; p.m_cb_b = kMCbB * tt.n;
       p.width = W;
       p.height = H;
       p.y_stride = W;
@@ -354,16 +355,6 @@ int main(int argc, char **argv) {
   report("shape_flat<nt>  (4,1080,32)", lab.time([&](int l) { hipLaunchKernelGGL((k_shape_flat<true>), dim3(4, 1080, BATCH), dim3(256), 0, s, lab.params[l]); }), dec_bytes);
   report("shape_flat<plain> (4,1080,32)", lab.time([&](int l) { hipLaunchKernelGGL((k_shape_flat<false>), dim3(4, 1080, BATCH), dim3(256), 0, s, lab.params[l]); }), dec_bytes);
 
-  for (int gx : {64, 128, 256, 540, 1080}) {
-    char nm[96];
-    std::snprintf(nm, sizeof nm, "decode_nv12_quads<nt> t=256 grid.x=%d", gx);
-    report(nm, lab.time([&](int l) { launch_decode(lab.params[l], BATCH, kVariantQuads, false, true, gx, 256, s); }), dec_bytes);
-  }
-  for (int t : {192, 256, 320, 384, 448, 480, 512}) {
-    char nm[96];
-    std::snprintf(nm, sizeof nm, "decode_nv12_quads<nt> grid.x=1080 threads=%d", t);
-    report(nm, lab.time([&](int l) { launch_decode(lab.params[l], BATCH, kVariantQuads, false, true, 1080, t, s); }), dec_bytes);
-  }
-  report("decode_nv12_quads<plain> 1080x480", lab.time([&](int l) { launch_decode(lab.params[l], BATCH, kVariantQuads, false, false, 1080, 480, s); }), dec_bytes);
+  // the production kernels are timed by tools/decode_lab.hip
   return 0;
 }
