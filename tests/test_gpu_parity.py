@@ -117,6 +117,64 @@ def test_ragged_strides_and_fallback_kernel(gh, oracle, strides):
         assert "quads" in name
 
 
+def test_fuzzed_geometry(gh, oracle):
+    """Seeded fuzz over what CoreVideo may hand the decoder: any even size, any plane pitch
+    >= width, any byte alignment of the plane bases, 4-byte aligned output with any pitch that is
+    a multiple of 4; every gamma; with and without an alpha plane.  Whatever kernel the shim
+    picks, the bytes must equal the oracle's and nothing outside the rows may be written."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    lib, h = ctx.lib, ctx.handle
+    rng = np.random.default_rng(20261002)
+    decs = {}
+    for case in range(60):
+        w = 2 * int(rng.integers(1, 200))
+        hgt = 2 * int(rng.integers(1, 24))
+        gamma = int(rng.integers(0, 4))
+        use_alpha = bool(rng.integers(0, 4) == 0)
+        aligned = bool(rng.integers(0, 2))
+        ys = w + (int(rng.integers(0, 5)) * 4 if aligned else int(rng.integers(0, 37)))
+        cs = w + (int(rng.integers(0, 5)) * 4 if aligned else int(rng.integers(0, 37)))
+        os_ = 4 * w + (int(rng.integers(0, 3)) * 16 if aligned else 4 * int(rng.integers(0, 9)))
+        oy, oc, oa = (0, 0, 0) if aligned else (int(rng.integers(0, 16)) for _ in range(3))
+        oo = 0 if aligned else 4 * int(rng.integers(0, 4))
+        key = (gamma, use_alpha)
+        if key not in decs:
+            decs[key] = gh.make_decoder(gamma, has_alpha=use_alpha)
+        dec = decs[key]
+        y, c = gh.random_nv12(w, hgt, seed=1000 + case)
+        a = rng.integers(0, 256, (hgt, w), dtype=np.uint8) if use_alpha else None
+
+        def plane(arr, pitch, off):
+            buf = DeviceBuffer(ctx, pitch * arr.shape[0] + off + 64)
+            ctx._upload(buf.ptr + off, pitch, np.ascontiguousarray(arr), None)
+            return buf, buf.ptr + off
+
+        by, py = plane(y, ys, oy)
+        bc, pc = plane(c, cs, oc)
+        src = mb.CVPixelBuffer(ctx, w, hgt, ys, cs, planes=(py, pc))
+        src.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2)
+        src.setAttachment("TransferFunction", gh.TRANSFER_FOR_GAMMA[dec.gamma])
+        abuf = None
+        if use_alpha:
+            ba, pa = plane(a, ys, oa)
+            abuf = mb.CVPixelBuffer(ctx, w, hgt, ys, cs, planes=(pa, pc))
+            abuf.setAttachment("TransferFunction", mb.kCVImageBufferTransferFunction_Linear)
+        out_bytes = os_ * hgt + oo + 64
+        bo = DeviceBuffer(ctx, out_bytes)
+        _capi.check(lib.bt709hip_memset(h, bo.ptr, 0x5A, out_bytes, None))
+        ctx._sync(None)
+        tex = mb.BGRATexture(ctx, w, hgt, os_, ptr=bo.ptr + oo)
+        assert dec.decodeBT709(src, abuf, tex, None, None, w, hgt, True), (case, dec.lastStatus)
+        raw = np.empty(out_bytes, np.uint8)
+        _capi.check(lib.bt709hip_download(h, raw.ctypes.data, out_bytes, bo.ptr, out_bytes, out_bytes, 1, None))
+        ctx._sync(None)
+        rows = raw[oo:oo + os_ * hgt].reshape(hgt, os_)
+        want = oracle.decode_nv12(dec.gamma, y, c, alpha=a)
+        assert np.array_equal(rows[:, :4 * w], want), (case, w, hgt, gamma, use_alpha, ys, cs, os_, oy, oc, oo)
+        assert (rows[:, 4 * w:] == 0x5A).all() and (raw[:oo] == 0x5A).all() and (raw[oo + os_ * hgt:] == 0x5A).all()
+
+
 def test_video_legal_range(gh, oracle):
     y, c = gh.random_nv12(640, 360, seed=9, legal=True)
     for gamma in GAMMAS:
