@@ -217,6 +217,14 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count,
                                const bt709hip_frame *frames, const bt709hip_surface *outs,
                                void *stream, int wait_until_completed);
 
+/* Pass 1 + pass 2 fused for ANY output size (view-fit): out->width x out->height need not be
+ * related to the frame size (down- or up-scaling).  Bilinear in linear light over the decoded
+ * 8-bit sRGB values, texel-centre sampling, clamp-to-edge; for an exact 2:1 ratio the result is
+ * bit-identical to bt709hip_decode_half.  The reference leaves this arithmetic to the sampler
+ * hardware (AAPLShaders.metal:73-85), so the definition is ours ("rescale"). */
+int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
+                           void *stream, int wait_until_completed);
+
 /* ------------------------------------------------------------------ encoder */
 /* The step before the decode path, on the GPU: 8-bit BGRA -> NV12 BT.709 video range with
  * the reference's linear-light 2x2 chroma averaging.  Replaces

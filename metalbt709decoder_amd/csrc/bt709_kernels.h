@@ -47,6 +47,9 @@ struct DecodeParams {
   uint32_t alpha_stride;
   uint32_t out_stride;
   uint32_t alpha_word;  // alpha_fill << 24
+  // decode_nv12_scaled only: output size and source-per-output-pixel ratios W/OW, H/OH (float)
+  uint32_t out_width, out_height;
+  float scale_x, scale_y;
   // uniform != 0: frame i = frames[0] + i * step_* (bytes); lets one launch cover any number of frames
   uint32_t uniform;
   int64_t step_y, step_cbcr, step_alpha, step_out;
@@ -91,6 +94,9 @@ const char *launch_decode(const DecodeParams &p, int frames, int variant, bool h
 // half: grid = (grid_x, H/2 output rows, frames) x block_threads.
 const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
                                uint32_t block_threads, hipStream_t stream);
+
+// scaled: grid = (ceil(OW / kBlockThreads), OH, frames) x kBlockThreads.
+const char *launch_decode_scaled(const DecodeParams &p, int frames, hipStream_t stream);
 
 // Fast-path launch geometry for a frame width: tiles (workgroups) per row pair and the
 // workgroup size -- ceil(quads per tile / kQuadsPerLane) rounded up to a whole wave.

@@ -480,6 +480,69 @@ decode_nv12_half(const DecodeParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Fused decode + bilinear rescale to ANY output size (pass 1 + MetalScaleRenderContext
+// -renderScaled:, AAPLShaders.metal:73-85, for a view that is not an exact 2:1 of the frame).
+// Two-pass-equivalent definition ("rescale"; parity unpinned by the reference):
+//   sx = (ox + 0.5f) * (W / OW) - 0.5f,  x0 = floor(sx), fx = sx - x0, taps clamped to the edge
+//   (same in y); each tap is decoded to its 8-bit sRGB value and linearised as the sRGB8 sampler
+//   does; v = (((w00*l00 + w01*l01) + w10*l10) + w11*l11) with w00 = (1-fx)(1-fy), ...;
+//   sRGB-encode, quantise.  For an exact 2:1 ratio every weight is 0.25 and this is bit for bit
+//   the decode_nv12_half result.
+// One lane per output pixel, byte gathers (cached), 4-byte coalesced stores; grid =
+// (ceil(OW / blockDim), OH, frames).  Not a bandwidth kernel: 12 LDS bucket lookups per pixel.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlockThreads)
+decode_nv12_scaled(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  TransferBucketLinear *dec = reinterpret_cast<TransferBucketLinear *>(lds_raw);
+  TransferBucket *enc = reinterpret_cast<TransferBucket *>(lds_raw + p.table_bytes);
+  stage_table(dec, p.table, p.table_bytes);
+  stage_table(enc, p.table2, p.table2_bytes);
+  __syncthreads();
+
+  const FramePlanes f = frame_planes(p, blockIdx.z);
+  const Matrix m = matrix_of(p);
+  const float en = p.table2_scale, dn = p.table_scale;
+  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset};
+  const uint32_t oy = blockIdx.y;
+  const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ox >= p.out_width) return;
+
+  const float sx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ox), 0.5f), p.scale_x), -0.5f);
+  const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy), 0.5f), p.scale_y), -0.5f);
+  const float x0f = __builtin_floorf(sx), y0f = __builtin_floorf(sy);
+  const float fx = __fadd_rn(sx, -x0f), fy = __fadd_rn(sy, -y0f);
+  const int wmax = static_cast<int>(p.width) - 1, hmax = static_cast<int>(p.height) - 1;
+  const int xi = static_cast<int>(x0f), yi = static_cast<int>(y0f);
+  const int xs[2] = {min(max(xi, 0), wmax), min(max(xi + 1, 0), wmax)};
+  const int ys[2] = {min(max(yi, 0), hmax), min(max(yi + 1, 0), hmax)};
+  const float gx = __fadd_rn(1.0f, -fx), gy = __fadd_rn(1.0f, -fy);
+  const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int x = xs[t & 1], y = ys[t >> 1];
+    const float yb = static_cast<float>(f.y[static_cast<size_t>(y) * p.y_stride + x]);
+    const uint8_t *c = f.cbcr + static_cast<size_t>(y >> 1) * p.cbcr_stride + 2 * (x >> 1);
+    const Chroma ch = chroma_terms(m, static_cast<float>(c[0]), static_cast<float>(c[1]));
+    float v[3];
+    pixel_rgbs(m, yb, ch, v[0], v[1], v[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t q = linear_index(dn, v[k]);
+      const u32x4 e = linear_fetch(dec, q);
+      const float term = __fmul_rn(w[t], linear_select(e, v[k]));
+      acc[k] = t ? __fadd_rn(acc[k], term) : term;
+    }
+  }
+  const uint32_t R = lookup_split(enc, es, __fmul_rn(acc[0], en));
+  const uint32_t G = lookup_split(enc, es, __fmul_rn(acc[1], en));
+  const uint32_t B = lookup_split(enc, es, __fmul_rn(acc[2], en));
+  reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, p.alpha_word);
+}
+
+// ---------------------------------------------------------------------------
 // host-callable launchers (no HIP types in the signature beyond hipStream_t)
 // ---------------------------------------------------------------------------
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
@@ -522,6 +585,7 @@ hipError_t prepare_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_half<true, true>),
       reinterpret_cast<const void *>(&decode_nv12_half<false, true>),
       reinterpret_cast<const void *>(&decode_nv12_half<false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled),
       reinterpret_cast<const void *>(&decode_nv12_quads<true, true>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, true>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false>),
@@ -548,6 +612,13 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
   }
   hipLaunchKernelGGL((decode_nv12_half<false, false>), grid, block, lds, stream, p);
   return "decode_nv12_half<narrow>";
+}
+
+const char *launch_decode_scaled(const DecodeParams &p, int frames, hipStream_t stream) {
+  const dim3 grid((p.out_width + kBlockThreads - 1) / kBlockThreads, p.out_height, static_cast<uint32_t>(frames));
+  const size_t lds = static_cast<size_t>(p.table_bytes) + p.table2_bytes;
+  hipLaunchKernelGGL(decode_nv12_scaled, grid, dim3(kBlockThreads), lds, stream, p);
+  return "decode_nv12_scaled";
 }
 
 }  // namespace bt709

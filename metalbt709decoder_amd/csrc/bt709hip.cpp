@@ -585,6 +585,47 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   return BT709HIP_OK;
 }
 
+int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
+                           void *stream, int wait_until_completed) {
+  if (dec == nullptr || frame == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;
+  if (int rc = bt709hip_decoder_setup(dec)) return rc;
+  if (out->width < 0 || out->height < 0) return BT709HIP_ERR_INVALID_ARG;
+  // the frame is validated like any decode input; the surface may have any size
+  if (int rc = validate(dec, frame, nullptr, out, out->width, out->height, out->width, out->height)) return rc;
+  if (frame->width == 0 || frame->height == 0 || out->width == 0 || out->height == 0) return BT709HIP_OK;
+  if (int rc = bind(dec->ctx)) return rc;
+  DecodeParams p;
+  std::memset(&p, 0, sizeof p);
+  p.frames[0].y = static_cast<const uint8_t *>(frame->y);
+  p.frames[0].cbcr = static_cast<const uint8_t *>(frame->cbcr);
+  p.frames[0].out = static_cast<uint8_t *>(out->bgra);
+  p.table = dec->d_table_linear;
+  p.table_bytes = dec->table_linear_bytes;
+  set_matrix(&p, dec->table_n);
+  p.table2 = dec->d_encode;
+  p.table2_bytes = dec->encode_bytes;
+  p.table2_scale = static_cast<float>(dec->encode_n);
+  p.table2_split = dec->encode_split;
+  p.table2_coarse = dec->encode_coarse;
+  p.table2_offset = dec->encode_offset;
+  p.width = static_cast<uint32_t>(frame->width);
+  p.height = static_cast<uint32_t>(frame->height);
+  p.y_stride = static_cast<uint32_t>(frame->y_stride);
+  p.cbcr_stride = static_cast<uint32_t>(frame->cbcr_stride);
+  p.out_stride = static_cast<uint32_t>(out->stride);
+  p.out_width = static_cast<uint32_t>(out->width);
+  p.out_height = static_cast<uint32_t>(out->height);
+  p.scale_x = static_cast<float>(frame->width) / static_cast<float>(out->width);
+  p.scale_y = static_cast<float>(frame->height) / static_cast<float>(out->height);
+  p.alpha_word = dec->alpha_fill << 24;
+  hipStream_t s = pick(dec->ctx, stream);
+  tl_kernel_name = launch_decode_scaled(p, 1, s);
+  HIP_TRY(hipGetLastError());
+  if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
+  return BT709HIP_OK;
+}
+
 int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
                          void *stream, int wait_until_completed) {
   return bt709hip_decode_half_batch(dec, 1, frame, out, stream, wait_until_completed);

@@ -374,13 +374,17 @@ class MetalBT709Decoder:
 
     def decodeBT709Scaled(self, yCbCrInputTexture, bgraSRGBTexture, commandBuffer=None, waitUntilCompleted=False):
         """-decodeBT709 into an intermediate + MetalScaleRenderContext -renderScaled:
-        (AAPLRenderer.m:940-977), fused, for the exact 2:1 ratio."""
+        (AAPLRenderer.m:940-977), fused: the tuned kernel for the exact 2:1 ratio, the general
+        bilinear kernel for any other view size (bit-identical where both apply)."""
         if not self.setupMetal():
             return False
         frame, surf = yCbCrInputTexture.frame(), bgraSRGBTexture.surface()
         stream = commandBuffer.stream if commandBuffer is not None else None
-        rc = self.metalRenderContext.lib.bt709hip_decode_half(self._handle, C.byref(frame), C.byref(surf), stream,
-                                                              int(bool(waitUntilCompleted)))
+        lib = self.metalRenderContext.lib
+        exact_half = (2 * surf.width == frame.width and 2 * surf.height == frame.height
+                      and frame.width % 4 == 0 and frame.height % 4 == 0)
+        fn = lib.bt709hip_decode_half if exact_half else lib.bt709hip_decode_scaled  # any view size
+        rc = fn(self._handle, C.byref(frame), C.byref(surf), stream, int(bool(waitUntilCompleted)))
         if rc != _capi.OK:
             return self._fail(rc, "decodeBT709Scaled")
         self.lastStatus = _capi.OK

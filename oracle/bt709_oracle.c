@@ -288,6 +288,51 @@ int bt709o_decode_nv12_half(int gamma,
   return 0;
 }
 
+int bt709o_decode_nv12_scaled(int gamma,
+                              const uint8_t *y, size_t y_stride,
+                              const uint8_t *uv, size_t uv_stride,
+                              int width, int height,
+                              uint8_t *bgra, size_t bgra_stride,
+                              int out_width, int out_height, int alpha_fill) {
+  if ((width & 1) || (height & 1) || width <= 0 || height <= 0 || out_width <= 0 || out_height <= 0) return -1;
+  float lin[256];
+  for (int b = 0; b < 256; b++) lin[b] = bt709o_srgb_to_linear(byte_norm(b));
+  const float scale_x = (float)width / (float)out_width;
+  const float scale_y = (float)height / (float)out_height;
+  for (int oy = 0; oy < out_height; oy++) {
+    const float sy = ((float)oy + 0.5f) * scale_y - 0.5f; /* texel-centre sampling */
+    const float y0f = floorf(sy), fy = sy - y0f, gy = 1.0f - fy;
+    int ys[2] = {(int)y0f, (int)y0f + 1};
+    for (int i = 0; i < 2; i++) ys[i] = ys[i] < 0 ? 0 : (ys[i] > height - 1 ? height - 1 : ys[i]); /* clamp to edge */
+    uint8_t *out = bgra + (size_t)oy * bgra_stride;
+    for (int ox = 0; ox < out_width; ox++) {
+      const float sx = ((float)ox + 0.5f) * scale_x - 0.5f;
+      const float x0f = floorf(sx), fx = sx - x0f, gx = 1.0f - fx;
+      int xs[2] = {(int)x0f, (int)x0f + 1};
+      for (int i = 0; i < 2; i++) xs[i] = xs[i] < 0 ? 0 : (xs[i] > width - 1 ? width - 1 : xs[i]);
+      const float w[4] = {gx * gy, fx * gy, gx * fy, fx * fy};
+      float acc[3] = {0.0f, 0.0f, 0.0f};
+      for (int t = 0; t < 4; t++) {
+        const int xx = xs[t & 1], yy = ys[t >> 1];
+        const uint8_t *c = uv + (size_t)(yy / 2) * uv_stride + 2 * (xx / 2);
+        int p[3];
+        bt709o_decode_pixel(gamma, y[(size_t)yy * y_stride + xx], c[0], c[1], p);
+        for (int k = 0; k < 3; k++) {
+          const float term = w[t] * lin[p[k]];
+          acc[k] = t ? acc[k] + term : term; /* (((w00*a + w01*b) + w10*c) + w11*d) */
+        }
+      }
+      int q[3];
+      for (int k = 0; k < 3; k++) q[k] = bt709o_quantize(bt709o_linear_to_srgb(acc[k]));
+      out[4 * ox + 0] = (uint8_t)q[2];
+      out[4 * ox + 1] = (uint8_t)q[1];
+      out[4 * ox + 2] = (uint8_t)q[0];
+      out[4 * ox + 3] = (uint8_t)alpha_fill;
+    }
+  }
+  return 0;
+}
+
 int bt709o_unconvert_packed(int gamma, const uint32_t *ycbcr, uint32_t *bgra,
                             int width, int height) {
   if ((width & 1) || (height & 1)) return -1;

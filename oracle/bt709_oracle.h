@@ -140,6 +140,21 @@ int bt709o_decode_nv12_half(int gamma,
                             uint8_t *bgra, size_t bgra_stride,
                             int alpha_fill);
 
+/* Decode + bilinear rescale to any output size (pass 1 + MetalScaleRenderContext
+ * -renderScaled: with its linear-filter sampler, AAPLShaders.metal:73-85).
+ * PARITY UNPINNED (no CPU twin, no test, sampler arithmetic is hardware's); our
+ * definition: texel-centre sampling sx = (ox+0.5f)*(W/OW) - 0.5f, clamp to edge,
+ * taps decoded to 8-bit sRGB and linearised like bt709o_decode_nv12_half, weights
+ * w00 = (1-fx)(1-fy) ..., v = (((w00*a + w01*b) + w10*c) + w11*d), sRGB-encode,
+ * quantise.  At an exact 2:1 ratio all weights are 0.25 and the result equals
+ * bt709o_decode_nv12_half bit for bit. */
+int bt709o_decode_nv12_scaled(int gamma,
+                              const uint8_t *y, size_t y_stride,
+                              const uint8_t *uv, size_t uv_stride,
+                              int width, int height,
+                              uint8_t *bgra, size_t bgra_stride,
+                              int out_width, int out_height, int alpha_fill);
+
 /* unconvertSoftware (BGRAToBT709Converter.m:146-198): packed
  * (Cr<<16)|(Cb<<8)|Y words -> (R<<16)|(G<<8)|B words, alpha byte 0. */
 int bt709o_unconvert_packed(int gamma, const uint32_t *ycbcr, uint32_t *bgra,

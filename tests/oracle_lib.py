@@ -148,6 +148,19 @@ class Oracle:
             width, height, _ptr(out, _u8p), out.shape[1], alpha_fill)
         return out if rc == 0 else None
 
+    def decode_nv12_scaled(self, gamma, y, uv, out_width, out_height, alpha_fill=0xFF):
+        y, width = _plane(y)
+        uv, _ = _plane(uv)
+        height = y.shape[0]
+        out = np.zeros((out_height, out_width * 4), dtype=np.uint8)
+        fn = self.lib.bt709o_decode_nv12_scaled
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t,
+                       C.c_int, C.c_int, C.c_int]
+        rc = fn(gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1], width, height,
+                _ptr(out, _u8p), out.shape[1], out_width, out_height, alpha_fill)
+        return out if rc == 0 else None
+
     def unconvert_packed(self, gamma, ycbcr, width, height):
         ycbcr = np.ascontiguousarray(ycbcr, dtype=np.uint32)
         out = np.zeros(width * height, dtype=np.uint32)

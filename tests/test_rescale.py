@@ -1,0 +1,92 @@
+"""Fused decode + rescale to any view size (reference pass 2 =
+Renderer/MetalScaleRenderContext.m:55-105 + AAPLShaders.metal:73-85).  The reference leaves the
+filtering arithmetic to the sampler hardware and has no test of it: PARITY UNPINNED, the oracle
+holds our definition and the GPU is checked against it bit for bit."""
+import numpy as np
+import pytest
+
+import metalbt709decoder_amd as mb
+from metalbt709decoder_amd import _capi
+
+
+def _frame(w, h, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (h // 2, w), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ CPU (definition)
+
+def test_scaled_equals_half_at_exact_2_to_1(oracle):
+    """Every weight is exactly 0.25 at a 2:1 ratio, so the general definition reproduces the
+    2:1 kernel's (((a+b)+c)+d)*0.25f bit for bit."""
+    for gamma in range(4):
+        y, c = _frame(48, 24, 3 + gamma)
+        assert np.array_equal(oracle.decode_nv12_scaled(gamma, y, c, 24, 12), oracle.decode_nv12_half(gamma, y, c))
+
+
+def test_scaled_identity_is_plain_decode(oracle):
+    """1:1: every sample falls on a texel centre (fx = fy = 0): linearise, re-encode = the byte itself."""
+    y, c = _frame(32, 16, 9)
+    for gamma in range(4):
+        assert np.array_equal(oracle.decode_nv12_scaled(gamma, y, c, 32, 16), oracle.decode_nv12(gamma, y, c))
+
+
+def test_scaled_flat_frame_any_ratio(oracle):
+    y = np.full((20, 36), 150, np.uint8)
+    c = np.full((10, 36), 128, np.uint8)
+    px = oracle.decode_nv12(0, y, c).reshape(-1, 4)[0]
+    for ow, oh in [(7, 5), (36, 20), (50, 33), (1, 1), (100, 3)]:
+        out = oracle.decode_nv12_scaled(0, y, c, ow, oh).reshape(-1, 4)
+        # weights sum to 1 only up to float rounding; a flat field may move by at most one code
+        assert (np.abs(out.astype(int) - px.astype(int)) <= 1).all()
+
+
+# ------------------------------------------------------------------ GPU
+
+@pytest.fixture(scope="module")
+def gh():
+    import gpu_helpers
+    gpu_helpers.context()
+    return gpu_helpers
+
+
+def gpu_scaled(gh, y, c, ow, oh, gamma):
+    ctx = gh.context()
+    dec = gh.make_decoder(gamma)
+    buf = gh.make_buffer(y, c, dec.gamma)
+    tex = ctx.makeBGRATexture((ow, oh))
+    assert dec.decodeBT709Scaled(buf, tex, ctx.commandQueue.commandBuffer(), True), dec.lastStatus
+    return ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(oh, ow * 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [((64, 32), (40, 20)), ((64, 32), (17, 9)), ((30, 18), (64, 40)), ((1920, 64), (1280, 43)),
+                                   ((50, 22), (1, 1)), ((48, 24), (24, 12)), ((32, 16), (32, 16))])
+def test_gpu_scaled_matches_oracle(gh, oracle, gamma, shape):
+    (w, h), (ow, oh) = shape
+    y, c = _frame(w, h, w + h + ow + gamma)
+    got = gpu_scaled(gh, y, c, ow, oh, gamma)
+    assert np.array_equal(got, oracle.decode_nv12_scaled(gamma, y, c, ow, oh))
+
+
+@pytest.mark.gpu
+def test_gpu_view_fit_like_the_renderer(gh, oracle):
+    """AAPLRenderer's case: a 1920x1080 frame into a view of another aspect and size
+    (AAPLRenderer.m:891-977 takes the 2-pass route whenever the sizes differ)."""
+    y, c = _frame(1920, 1080, 77)
+    got = gpu_scaled(gh, y, c, 1366, 768, mb.MetalBT709GammaApple)
+    assert np.array_equal(got, oracle.decode_nv12_scaled(0, y, c, 1366, 768))
+
+
+@pytest.mark.gpu
+def test_gpu_scaled_rejects_alpha_decoder_and_bad_tags(gh):
+    ctx = gh.context()
+    y, c = _frame(16, 8, 1)
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    srgb_tagged = gh.make_buffer(y, c, mb.MetalBT709GammaSRGB)
+    assert not dec.decodeBT709Scaled(srgb_tagged, ctx.makeBGRATexture((5, 3)), None, True)
+    assert dec.lastStatus == _capi.ERR_TRANSFER
+    da = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
+    assert not da.decodeBT709Scaled(srgb_tagged, ctx.makeBGRATexture((5, 3)), None, True)
+    assert da.lastStatus == _capi.ERR_UNSUPPORTED
