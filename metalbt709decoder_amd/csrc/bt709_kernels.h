@@ -10,8 +10,15 @@
 namespace bt709 {
 
 constexpr int kBlockThreads = 256;     // general-path workgroup: 4 waves of 64
-constexpr int kMaxBlockThreads = 512;  // fast-path workgroup is sized per frame width, up to 8 waves
-constexpr int kQuadsPerLane = 2;       // 4x2-pixel quads a fast-path lane owns per row pair
+// (tools/decode_lab overrides these two with -D to A/B other tile shapes)
+#ifndef BT709_MAX_BLOCK_THREADS
+#define BT709_MAX_BLOCK_THREADS 512
+#endif
+#ifndef BT709_QUADS_PER_LANE
+#define BT709_QUADS_PER_LANE 2
+#endif
+constexpr int kMaxBlockThreads = BT709_MAX_BLOCK_THREADS;  // fast-path workgroup is sized per frame width, up to 8 waves
+constexpr int kQuadsPerLane = BT709_QUADS_PER_LANE;        // 4x2-pixel quads a fast-path lane owns per row pair
 constexpr int kMaxBatch = 32;          // == BT709HIP_MAX_BATCH: frames in the kernarg table
 constexpr int kMaxUniformBatch = 65535;  // evenly spaced frames per launch (grid.z limit)
 

@@ -118,13 +118,14 @@ int main(int argc, char **argv) {
   hipStream_t s = r.s;
   std::vector<Variant> vs;
   auto add = [&](const std::string &n, std::function<void(int)> f) { vs.push_back({n, f, {}}); };
-  for (int t : {448, 480, 512})
-    add("quads<nt> grid=(1,1080,32) threads=" + std::to_string(t),
-        [&r, s, t](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, true, 1, t, s); });
-  add("quads<plain> grid=(1,1080,32) threads=480",
-      [&r, s](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, false, 1, 480, s); });
-  add("quads<nt> grid=(2,1080,32) threads=256",
-      [&r, s](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, true, 2, 256, s); });
+  // tile shapes that cover a 960-quad row pair exactly with kQuadsPerLane quads per lane
+  for (int tiles : {1, 2, 3, 4}) {
+    const int per_tile = (960 + tiles - 1) / tiles;
+    int t = ((per_tile + kQuadsPerLane - 1) / kQuadsPerLane + 63) / 64 * 64;
+    if (t > kMaxBlockThreads) continue;
+    add("quads<nt> qpl=" + std::to_string(kQuadsPerLane) + " tiles=" + std::to_string(tiles) + " threads=" + std::to_string(t),
+        [&r, s, t, tiles](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, true, tiles, t, s); });
+  }
 
   // warm the clocks
   for (int i = 0; i < 3; ++i)
