@@ -239,6 +239,15 @@ int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, c
 int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_frame *out,
                     int input_gamma, int output_gamma, void *stream, int wait_until_completed);
 
+/* `count` same-sized pictures in ONE launch (the app encodes its frames one call at a time,
+ * BGRAToBT709Converter.m:532-569; a 4K frame is a ~12 us kernel, too short to fill the chip).
+ * Same limits as bt709hip_decode_batch: up to BT709HIP_MAX_BATCH arbitrary buffers, or any
+ * number up to 65535 when picture i sits at picture 0 + i * (picture 1 - picture 0) in all
+ * three planes.  All pictures share size and strides (else BT709HIP_ERR_SIZE_MISMATCH). */
+int bt709hip_encode_batch(bt709hip_context *ctx, int count, const bt709hip_surface *ins,
+                          const bt709hip_frame *outs, int input_gamma, int output_gamma, void *stream,
+                          int wait_until_completed);
+
 /* ------------------------------------------------------------ plane layouts */
 /* The reference's on-disk 4:2:0 format is YUV4MPEG2 "C420jpeg": planar Y, then U (Cb), then V
  * (Cr) per frame (Renderer/y4m_writer.h:194-241).  These move the two chroma planes to / from

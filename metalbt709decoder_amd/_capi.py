@@ -83,6 +83,7 @@ SYMBOLS = {
     "bt709hip_decode_half_batch": (_I, [_P, _I, _FP, _SP, _P, _I]),
     "bt709hip_decode_scaled": (_I, [_P, _FP, _SP, _P, _I]),
     "bt709hip_encode": (_I, [_P, _SP, _FP, _I, _I, _P, _I]),
+    "bt709hip_encode_batch": (_I, [_P, _I, _SP, _FP, _I, _I, _P, _I]),
     "bt709hip_interleave_cbcr": (_I, [_P, _P, _Z, _P, _Z, _P, _Z, _I, _I, _P, _I]),
     "bt709hip_deinterleave_cbcr": (_I, [_P, _P, _Z, _P, _Z, _P, _Z, _I, _I, _P, _I]),
     "bt709hip_strerror": (C.c_char_p, [_I]),

@@ -25,7 +25,7 @@
 //     doubling is folded into the constants (power of two: exact).
 //
 // A lane owns a 4x2-pixel quad (two blocks): two 16-byte loads, three 4-byte stores; lanes
-// of a wave are consecutive quads of one row pair; grid = (tiles, row pairs / 2, 1).  LDS holds
+// of a wave are consecutive quads of one row pair; grid = (tiles, row-pair groups, frames).  LDS holds
 // the three 2 KiB per-byte tables and the two-resolution BT709_from_linear table.
 #include <hip/hip_runtime.h>
 
@@ -113,14 +113,23 @@ __device__ __forceinline__ EncodeLds stage_encode_tables(unsigned char *lds_raw,
   return t;
 }
 
+__device__ __forceinline__ EncodeFrame encode_frame(const EncodeParams &p, uint32_t i) {
+  if (!p.uniform) return p.frames[i];
+  EncodeFrame f = p.frames[0];
+  f.bgra += static_cast<int64_t>(i) * p.step_bgra;
+  f.y += static_cast<int64_t>(i) * p.step_y;
+  f.cbcr += static_cast<int64_t>(i) * p.step_cbcr;
+  return f;
+}
+
 }  // namespace
 
-// Consecutive row pairs one workgroup walks (prefetching the next while it encodes the current).
-
-
-__global__ void __launch_bounds__(kBlockThreads)
+// grid = (tiles, row-pair groups, frames); a workgroup walks row_pairs_per_block consecutive row
+// pairs of one frame, prefetching the next pair while it encodes the current one.
+__global__ void __launch_bounds__(kMaxBlockThreads)
 encode_bgra_nv12(const EncodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const EncodeFrame f = encode_frame(p, blockIdx.z);
   const uint32_t quads = p.width >> 2;
   const uint32_t row_pairs = p.height >> 1;
   const uint32_t q_raw = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,7 +137,7 @@ encode_bgra_nv12(const EncodeParams p) {
   const uint32_t rp0 = blockIdx.y * p.row_pairs_per_block;
   const uint32_t rp_end = min(rp0 + p.row_pairs_per_block, row_pairs);
 
-  const uint8_t *s0 = p.bgra + static_cast<size_t>(2 * rp0) * p.bgra_stride + 16 * static_cast<size_t>(q);
+  const uint8_t *s0 = f.bgra + static_cast<size_t>(2 * rp0) * p.bgra_stride + 16 * static_cast<size_t>(q);
   u32x4 top = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0));
   u32x4 bot = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0 + p.bgra_stride));
 
@@ -139,7 +148,7 @@ encode_bgra_nv12(const EncodeParams p) {
   for (uint32_t rp = rp0; rp < rp_end; ++rp) {
     // prefetch the next row pair (clamped: the last iteration re-reads its own rows) before the arithmetic
     const uint32_t rn = min(rp + 1, rp_end - 1);
-    const uint8_t *s1 = p.bgra + static_cast<size_t>(2 * rn) * p.bgra_stride + 16 * static_cast<size_t>(q);
+    const uint8_t *s1 = f.bgra + static_cast<size_t>(2 * rn) * p.bgra_stride + 16 * static_cast<size_t>(q);
     const u32x4 ntop = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1));
     const u32x4 nbot = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1 + p.bgra_stride));
 
@@ -157,7 +166,7 @@ encode_bgra_nv12(const EncodeParams p) {
       ya[2] = y4[0], ya[3] = y4[1], yb[2] = y4[2], yb[3] = y4[3];
     }
     if (q_raw < quads) {
-      uint8_t *y0 = p.y + static_cast<size_t>(2 * rp) * p.y_stride + 4 * static_cast<size_t>(q);
+      uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride + 4 * static_cast<size_t>(q);
       __builtin_nontemporal_store(ya[0] | (ya[1] << 8) | (ya[2] << 16) | (ya[3] << 24),
                                   reinterpret_cast<uint32_t *>(y0));
       __builtin_nontemporal_store(yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24),
@@ -165,7 +174,7 @@ encode_bgra_nv12(const EncodeParams p) {
       // Cb low byte, Cr high (CVPixelBufferUtils.h:358-361)
       __builtin_nontemporal_store(
           cb0 | (cr0 << 8) | (cb1 << 16) | (cr1 << 24),
-          reinterpret_cast<uint32_t *>(p.cbcr + static_cast<size_t>(rp) * p.cbcr_stride + 4 * static_cast<size_t>(q)));
+          reinterpret_cast<uint32_t *>(f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride + 4 * static_cast<size_t>(q)));
     }
     top = ntop;
     bot = nbot;
@@ -178,18 +187,19 @@ encode_bgra_nv12_blocks(const EncodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const EncodeLds t = stage_encode_tables(lds_raw, p);
   __syncthreads();
+  const EncodeFrame f = encode_frame(p, blockIdx.z);
   const float quarter_n = __fmul_rn(0.25f, p.from_linear_scale);
   const uint32_t bw = p.width >> 1;
   const uint32_t rp = blockIdx.y;
   for (uint32_t bx = blockIdx.x * blockDim.x + threadIdx.x; bx < bw; bx += gridDim.x * blockDim.x) {
-    const uint32_t *r0 = reinterpret_cast<const uint32_t *>(p.bgra + static_cast<size_t>(2 * rp) * p.bgra_stride);
-    const uint32_t *r1 = reinterpret_cast<const uint32_t *>(p.bgra + static_cast<size_t>(2 * rp + 1) * p.bgra_stride);
+    const uint32_t *r0 = reinterpret_cast<const uint32_t *>(f.bgra + static_cast<size_t>(2 * rp) * p.bgra_stride);
+    const uint32_t *r1 = reinterpret_cast<const uint32_t *>(f.bgra + static_cast<size_t>(2 * rp + 1) * p.bgra_stride);
     const uint32_t blk[4] = {r0[2 * bx], r0[2 * bx + 1], r1[2 * bx], r1[2 * bx + 1]};
     uint32_t y4[4], cb, cr;
     encode_block(t, quarter_n, blk, y4, cb, cr);
-    uint8_t *y0 = p.y + static_cast<size_t>(2 * rp) * p.y_stride;
+    uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
     uint8_t *y1 = y0 + p.y_stride;
-    uint8_t *c = p.cbcr + static_cast<size_t>(rp) * p.cbcr_stride;
+    uint8_t *c = f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride;
     y0[2 * bx] = static_cast<uint8_t>(y4[0]);
     y0[2 * bx + 1] = static_cast<uint8_t>(y4[1]);
     y1[2 * bx] = static_cast<uint8_t>(y4[2]);
@@ -199,16 +209,20 @@ encode_bgra_nv12_blocks(const EncodeParams p) {
   }
 }
 
-const char *launch_encode(const EncodeParams &p, bool fast, hipStream_t stream) {
+const char *launch_encode(const EncodeParams &params, int frames, bool fast, hipStream_t stream) {
+  EncodeParams p = params;
+  if (p.row_pairs_per_block == 0) p.row_pairs_per_block = encode_row_pairs_per_block(p.width, p.height, frames);
   const size_t lds = 3 * 256 * sizeof(EncodeByteEntry) + p.from_linear_bytes;
   if (fast) {
     const uint32_t quads = p.width / 4;
-    const dim3 grid((quads + kBlockThreads - 1) / kBlockThreads,
-                    (p.height / 2 + p.row_pairs_per_block - 1) / p.row_pairs_per_block, 1);
-    hipLaunchKernelGGL(encode_bgra_nv12, grid, dim3(kBlockThreads), lds, stream, p);
+    uint32_t threads = p.block_threads ? p.block_threads : encode_block_threads(p.width);
+    if (threads > static_cast<uint32_t>(kMaxBlockThreads)) threads = kMaxBlockThreads;
+    const dim3 grid((quads + threads - 1) / threads,
+                    (p.height / 2 + p.row_pairs_per_block - 1) / p.row_pairs_per_block, frames);
+    hipLaunchKernelGGL(encode_bgra_nv12, grid, dim3(threads), lds, stream, p);
     return "encode_bgra_nv12";
   }
-  const dim3 grid((p.width / 2 + kBlockThreads - 1) / kBlockThreads, p.height / 2, 1);
+  const dim3 grid((p.width / 2 + kBlockThreads - 1) / kBlockThreads, p.height / 2, frames);
   hipLaunchKernelGGL(encode_bgra_nv12_blocks, grid, dim3(kBlockThreads), lds, stream, p);
   return "encode_bgra_nv12_blocks";
 }

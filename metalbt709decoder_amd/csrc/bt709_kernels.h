@@ -63,10 +63,16 @@ struct DecodeParams {
 };
 
 // BGRA -> NV12 encoder (bt709_encode.hip).  One frame per launch.
-struct EncodeParams {
+struct EncodeFrame {
   const uint8_t *bgra;  // W x H words (A<<24)|(R<<16)|(G<<8)|B, alpha ignored
   uint8_t *y;
   uint8_t *cbcr;
+};
+struct EncodeParams {
+  EncodeFrame frames[kMaxBatch];
+  // uniform != 0: frame i = frames[0] + i * step_* (bytes), as in DecodeParams
+  uint32_t uniform;
+  int64_t step_bgra, step_y, step_cbcr;
   const EncodeByteEntry *per_byte;  // 256 entries for the (input gamma, output gamma) pair
   const TransferBucket *from_linear;  // two-resolution BT709_from_linear(., output gamma) table (SplitTable)
   uint32_t from_linear_bytes;
@@ -74,12 +80,28 @@ struct EncodeParams {
   float from_linear_split;    // fine buckets below this xs ...
   float from_linear_coarse;   // ... coarse ones above: q = (uint)(xs * coarse) + offset
   uint32_t from_linear_offset;
-  uint32_t row_pairs_per_block;  // consecutive row pairs a fast-path workgroup walks (>= 1)
+  uint32_t row_pairs_per_block;  // consecutive row pairs a fast-path workgroup walks; 0 = encode_row_pairs_per_block()
+  uint32_t block_threads;        // fast-path workgroup size (one quad per lane); 0 = encode_block_threads(width)
   uint32_t width, height;
   uint32_t bgra_stride, y_stride, cbcr_stride;
 };
-const char *launch_encode(const EncodeParams &p, bool fast, hipStream_t stream);
-hipError_t prepare_encode_kernels();
+const char *launch_encode(const EncodeParams &p, int frames, bool fast, hipStream_t stream);
+// Encoder fast-path geometry, measured on 4K (tools/bench_encode.py sweeps):
+// one quad per lane, equal tiles of <= 320 lanes rounded up to whole waves (3840 -> 3 x 320,
+// 1920 -> 2 x 256); a workgroup walks up to 9 consecutive row pairs (amortising its 12 KiB of
+// table staging) as long as the launch keeps >= 1024 workgroups.
+inline uint32_t encode_block_threads(uint32_t width) {
+  const uint32_t quads = width / 4, tiles = quads == 0 ? 1 : (quads + 319) / 320;
+  uint32_t t = ((quads + tiles - 1) / tiles + 63) / 64 * 64;
+  return t < 64 ? 64 : t;
+}
+inline uint32_t encode_row_pairs_per_block(uint32_t width, uint32_t height, uint32_t frames) {
+  const uint32_t threads = encode_block_threads(width);
+  const uint64_t tiles = (width / 4 + threads - 1) / threads;
+  for (uint32_t rp = 9; rp > 1; --rp)
+    if (tiles * ((height / 2 + rp - 1) / rp) * frames >= 1024) return rp;
+  return 1;
+}
 
 // Planar U,V <-> interleaved CbCr (bt709_planes.hip).  The kernel that reads a plane never writes it.
 struct PlaneParams {

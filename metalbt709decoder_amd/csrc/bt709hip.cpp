@@ -633,18 +633,45 @@ int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame, con
 
 // ------------------------------------------------------------------ encoder
 
-int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_frame *out, int input_gamma,
-                    int output_gamma, void *stream, int wait_until_completed) {
-  if (ctx == nullptr || in == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+int bt709hip_encode_batch(bt709hip_context *ctx, int count, const bt709hip_surface *ins, const bt709hip_frame *outs,
+                          int input_gamma, int output_gamma, void *stream, int wait_until_completed) {
+  if (ctx == nullptr || ins == nullptr || outs == nullptr || count < 0) return BT709HIP_ERR_INVALID_ARG;
   if (input_gamma < 0 || input_gamma > 2 || output_gamma < 0 || output_gamma > 2) return BT709HIP_ERR_INVALID_ARG;
-  if (in->width < 0 || in->height < 0) return BT709HIP_ERR_INVALID_ARG;
-  if (in->width != out->width || in->height != out->height) return BT709HIP_ERR_SIZE_MISMATCH;
-  if ((in->width & 1) || (in->height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;  // BGRAToBT709Converter.m:540-541
-  if (in->width == 0 || in->height == 0) return BT709HIP_OK;
-  if (in->bgra == nullptr || out->y == nullptr || out->cbcr == nullptr) return BT709HIP_ERR_INVALID_ARG;
-  const size_t w = static_cast<size_t>(in->width);
-  if (in->stride < 4 * w || (in->stride & 3) || !aligned(in->bgra, 4) || out->y_stride < w || out->cbcr_stride < w)
-    return BT709HIP_ERR_STRIDE;
+  if (count == 0) return BT709HIP_OK;
+  const bt709hip_surface &in0 = ins[0];
+  const bt709hip_frame &out0 = outs[0];
+  bool uniform = count > 1;
+  bool fast = (in0.width % 4) == 0 && (in0.stride % 16) == 0 && (out0.y_stride % 4) == 0 && (out0.cbcr_stride % 4) == 0;
+  EncodeParams p;
+  std::memset(&p, 0, sizeof p);
+  for (int i = 0; i < count; ++i) {
+    const bt709hip_surface &in = ins[i];
+    const bt709hip_frame &out = outs[i];
+    if (in.width < 0 || in.height < 0) return BT709HIP_ERR_INVALID_ARG;
+    if (in.width != out.width || in.height != out.height) return BT709HIP_ERR_SIZE_MISMATCH;
+    if ((in.width & 1) || (in.height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;  // BGRAToBT709Converter.m:540-541
+    if (in.width != in0.width || in.height != in0.height || in.stride != in0.stride || out.y_stride != out0.y_stride ||
+        out.cbcr_stride != out0.cbcr_stride)
+      return BT709HIP_ERR_SIZE_MISMATCH;
+    if (in.width == 0 || in.height == 0) continue;
+    if (in.bgra == nullptr || out.y == nullptr || out.cbcr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+    const size_t w = static_cast<size_t>(in.width);
+    if (in.stride < 4 * w || (in.stride & 3) || !aligned(in.bgra, 4) || out.y_stride < w || out.cbcr_stride < w)
+      return BT709HIP_ERR_STRIDE;
+    if (in.stride > 0xffffffffu || out.y_stride > 0xffffffffu || out.cbcr_stride > 0xffffffffu) return BT709HIP_ERR_STRIDE;
+    fast = fast && aligned(in.bgra, 16) && aligned(out.y, 4) && aligned(out.cbcr, 4);
+    if (i >= 2)
+      uniform = uniform && byte_step(ins[0].bgra, in.bgra) == byte_step(ins[0].bgra, ins[1].bgra) * i &&
+                byte_step(outs[0].y, out.y) == byte_step(outs[0].y, outs[1].y) * i &&
+                byte_step(outs[0].cbcr, out.cbcr) == byte_step(outs[0].cbcr, outs[1].cbcr) * i;
+    if (i < kMaxBatch) {
+      p.frames[i].bgra = static_cast<const uint8_t *>(in.bgra);
+      p.frames[i].y = static_cast<uint8_t *>(const_cast<void *>(out.y));
+      p.frames[i].cbcr = static_cast<uint8_t *>(const_cast<void *>(out.cbcr));
+    }
+  }
+  if (count > (uniform ? kMaxUniformBatch : kMaxBatch)) return BT709HIP_ERR_UNSUPPORTED;
+  if (in0.width == 0 || in0.height == 0) return BT709HIP_OK;
   if (int rc = bind(ctx)) return rc;
 
   EncoderTables &t = ctx->encoders[input_gamma][output_gamma];
@@ -665,11 +692,12 @@ int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt7
     }
   }
 
-  EncodeParams p;
-  std::memset(&p, 0, sizeof p);
-  p.bgra = static_cast<const uint8_t *>(in->bgra);
-  p.y = static_cast<uint8_t *>(const_cast<void *>(out->y));
-  p.cbcr = static_cast<uint8_t *>(const_cast<void *>(out->cbcr));
+  if (uniform) {
+    p.uniform = 1;
+    p.step_bgra = byte_step(ins[0].bgra, ins[1].bgra);
+    p.step_y = byte_step(outs[0].y, outs[1].y);
+    p.step_cbcr = byte_step(outs[0].cbcr, outs[1].cbcr);
+  }
   p.per_byte = static_cast<const EncodeByteEntry *>(t.d_per_byte);
   p.from_linear = static_cast<const TransferBucket *>(t.d_from_linear);
   p.from_linear_bytes = t.from_linear_bytes;
@@ -677,20 +705,24 @@ int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt7
   p.from_linear_split = t.split;
   p.from_linear_coarse = t.coarse_scale;
   p.from_linear_offset = t.coarse_offset;
-  p.row_pairs_per_block = static_cast<uint32_t>(env_int("BT709HIP_ENCODE_ROWPAIRS", 3));
-  if (p.row_pairs_per_block < 1) p.row_pairs_per_block = 1;
-  p.width = static_cast<uint32_t>(in->width);
-  p.height = static_cast<uint32_t>(in->height);
-  p.bgra_stride = static_cast<uint32_t>(in->stride);
-  p.y_stride = static_cast<uint32_t>(out->y_stride);
-  p.cbcr_stride = static_cast<uint32_t>(out->cbcr_stride);
-  const bool fast = (p.width % 4) == 0 && (in->stride % 16) == 0 && aligned(in->bgra, 16) && (out->y_stride % 4) == 0 &&
-                    (out->cbcr_stride % 4) == 0 && aligned(out->y, 4) && aligned(out->cbcr, 4);
+  p.row_pairs_per_block = static_cast<uint32_t>(env_int("BT709HIP_ENCODE_ROWPAIRS", 0));  // 0: sized per launch
+  p.block_threads = static_cast<uint32_t>(env_int("BT709HIP_ENCODE_THREADS", 0)) / 64 * 64;
+  p.width = static_cast<uint32_t>(in0.width);
+  p.height = static_cast<uint32_t>(in0.height);
+  p.bgra_stride = static_cast<uint32_t>(in0.stride);
+  p.y_stride = static_cast<uint32_t>(out0.y_stride);
+  p.cbcr_stride = static_cast<uint32_t>(out0.cbcr_stride);
   hipStream_t s = pick(ctx, stream);
-  tl_kernel_name = launch_encode(p, fast, s);
+  tl_kernel_name = launch_encode(p, count, fast, s);
   HIP_TRY(hipGetLastError());
   if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;
+}
+
+int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_frame *out, int input_gamma,
+                    int output_gamma, void *stream, int wait_until_completed) {
+  if (in == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  return bt709hip_encode_batch(ctx, 1, in, out, input_gamma, output_gamma, stream, wait_until_completed);
 }
 
 // ------------------------------------------------------------ plane layouts

@@ -274,6 +274,27 @@ class BGRAToBT709Converter:
         return True
 
     @staticmethod
+    def convertIntoCoreVideoBuffers(bgraTextures, cvPixelBuffers, inputGamma, outputGamma, commandBuffer=None,
+                                    waitUntilCompleted=True):
+        """`count` same-sized pictures in one launch (no reference twin: the app converts one
+        CGImage per call, BGRAToBT709Converter.m:532-569)."""
+        n = len(bgraTextures)
+        if n != len(cvPixelBuffers):
+            raise ValueError("one output buffer per input texture")
+        if n == 0:
+            return True
+        ctx = bgraTextures[0].ctx
+        surfs = (Surface * n)(*[t.surface() for t in bgraTextures])
+        frames = (Frame * n)(*[b.frame() for b in cvPixelBuffers])
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = ctx.lib.bt709hip_encode_batch(ctx.handle, n, surfs, frames, int(inputGamma), int(outputGamma), stream,
+                                           int(bool(waitUntilCompleted)))
+        if rc != _capi.OK:
+            log.error("convertIntoCoreVideoBuffers: %s", _capi.strerror(rc))
+            return False
+        return True
+
+    @staticmethod
     def copyBT709ToCoreVideo(inBT709Pixels, cvPixelBuffer):
         """Packed (Cr<<16)|(Cb<<8)|Y words -> NV12 planes (BGRAToBT709Converter.m:1042-1099):
         Y of every pixel; CbCr of every even column, every row writing into row/2, so the

@@ -176,3 +176,46 @@ def test_gpu_encoder_errors(gh):
     odd = ctx.makeBGRATexture((7, 4))
     assert not mb.BGRAToBT709Converter.convertIntoCoreVideoBuffer(odd, mb.CVPixelBuffer(ctx, 7, 4), 1, 0)
     assert mb.BGRAToBT709Converter.convertIntoCoreVideoBuffer(ctx.makeBGRATexture((0, 0)), mb.CVPixelBuffer(ctx, 0, 0), 1, 0)
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_batch_matches_single(gh, oracle):
+    """bt709hip_encode_batch: separately allocated pictures (pointer table) and a ring carved
+    from one allocation (evenly spaced, beyond the table limit) give the single-call bytes."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    w, h = 64, 12
+    rng = np.random.default_rng(41)
+    # pointer table
+    pics = [rng.integers(0, 1 << 32, w * h, dtype=np.uint32) for _ in range(5)]
+    texs = [ctx.makeBGRATexture((w, h), pixels=p) for p in pics]
+    bufs = [mb.BGRAToBT709Converter.createCoreVideoYCbCrBuffer(ctx, (w, h)) for _ in pics]
+    assert mb.BGRAToBT709Converter.convertIntoCoreVideoBuffers(texs, bufs, 1, 0)
+    for p, b in zip(pics, bufs):
+        want = oracle.encode_nv12(p & 0xFFFFFF, w, h, 1, 0)
+        got = b.download_planes()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # evenly spaced ring, more pictures than BT709HIP_MAX_BATCH
+    n = _capi.MAX_BATCH + 9
+    in_pitch, out_pitch = w * h * 4, w * h * 3 // 2
+    slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
+    pics = [rng.integers(0, 1 << 32, w * h, dtype=np.uint32) for _ in range(n)]
+    texs, bufs = [], []
+    for i, p in enumerate(pics):
+        t = mb.BGRATexture(ctx, w, h, w * 4, ptr=slab_in.ptr + i * in_pitch)
+        ctx.fillBGRATexture(t, p)
+        texs.append(t)
+        base = slab_out.ptr + i * out_pitch
+        bufs.append(mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h)))
+    assert mb.BGRAToBT709Converter.convertIntoCoreVideoBuffers(texs, bufs, 1, 0)
+    for p, b in zip(pics, bufs):
+        want = oracle.encode_nv12(p & 0xFFFFFF, w, h, 1, 0)
+        got = b.download_planes()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # shuffled: not evenly spaced any more -> the table limit applies; mixed sizes are refused
+    order = list(range(n))
+    order[2], order[5] = order[5], order[2]
+    assert not mb.BGRAToBT709Converter.convertIntoCoreVideoBuffers([texs[i] for i in order], [bufs[i] for i in order], 1, 0)
+    other = ctx.makeBGRATexture((w, h + 2))
+    assert not mb.BGRAToBT709Converter.convertIntoCoreVideoBuffers(
+        [texs[0], other], [bufs[0], mb.CVPixelBuffer(ctx, w, h + 2)], 1, 0)
