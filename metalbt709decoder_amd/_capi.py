@@ -110,8 +110,8 @@ def load():
     path = _build.LIB
     if _build.is_stale():
         try:
-            _build.build()
-        except Exception as exc:  # no hipcc here: accept a prebuilt library if one shipped
+            _build.build()  # a compile error propagates: never run a library older than its sources
+        except OSError as exc:  # no hipcc on this machine: accept a prebuilt library if one shipped
             if not os.path.exists(path):
                 raise ImportError("libbt709hip.so is missing and could not be built: %s" % exc)
     lib = C.CDLL(path)

@@ -86,10 +86,11 @@ struct EncodeParams {
   uint32_t bgra_stride, y_stride, cbcr_stride;
 };
 const char *launch_encode(const EncodeParams &p, int frames, bool fast, hipStream_t stream);
+hipError_t prepare_encode_kernels();
 // Encoder fast-path geometry, measured on 4K (tools/bench_encode.py sweeps):
 // one quad per lane, equal tiles of <= 320 lanes rounded up to whole waves (3840 -> 3 x 320,
-// 1920 -> 2 x 256); a workgroup walks up to 9 consecutive row pairs (amortising its 12 KiB of
-// table staging) as long as the launch keeps >= 1024 workgroups.
+// 1920 -> 2 x 256); a workgroup walks 3 to 9 consecutive row pairs (amortising its 12 KiB of
+// table staging): the most that still leaves the launch >= 4096 workgroups.
 inline uint32_t encode_block_threads(uint32_t width) {
   const uint32_t quads = width / 4, tiles = quads == 0 ? 1 : (quads + 319) / 320;
   uint32_t t = ((quads + tiles - 1) / tiles + 63) / 64 * 64;
@@ -98,9 +99,9 @@ inline uint32_t encode_block_threads(uint32_t width) {
 inline uint32_t encode_row_pairs_per_block(uint32_t width, uint32_t height, uint32_t frames) {
   const uint32_t threads = encode_block_threads(width);
   const uint64_t tiles = (width / 4 + threads - 1) / threads;
-  for (uint32_t rp = 9; rp > 1; --rp)
-    if (tiles * ((height / 2 + rp - 1) / rp) * frames >= 1024) return rp;
-  return 1;
+  for (uint32_t rp = 9; rp > 3; --rp)
+    if (tiles * ((height / 2 + rp - 1) / rp) * frames >= 4096) return rp;
+  return 3;
 }
 
 // Planar U,V <-> interleaved CbCr (bt709_planes.hip).  The kernel that reads a plane never writes it.

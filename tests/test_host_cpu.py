@@ -26,6 +26,11 @@ def lib():
     return mb.load_library()
 
 
+def test_library_is_not_older_than_its_sources(lib):
+    """A failed rebuild must not leave tests running against a stale library."""
+    assert not build.is_stale(), "libbt709hip.so is older than csrc/ or include/: the build failed or was skipped"
+
+
 def test_library_exports_every_declared_symbol(lib):
     header = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ring", type=int, default=32)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=0, help="extra untimed steps after the 0.4 s pre-warm")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--frames-per-launch", type=int, default=1,
@@ -62,6 +63,8 @@ def main():
     while time.perf_counter() < t_end:
         step()
         _capi.check(lib.bt709hip_stream_synchronize(h, None))
+    for _ in range(args.warmup):
+        step()
     e0, e1 = C.c_void_p(), C.c_void_p()
     lib.bt709hip_event_create(h, C.byref(e0))
     lib.bt709hip_event_create(h, C.byref(e1))

@@ -5,13 +5,15 @@
 #      FETCH_SIZE | WRITE_SIZE | SQ LDS/VALU counters | SQ wait counters | TCC hit/miss
 # into gpurun_out/prof_<tag>/.  tools/pmc_summary.py turns those into profiles/*.
 # usage: tools/profile_gpu.sh <tag> [bench.py args...]
+#        PROFILE_PROG=tools/bench_encode.py tools/profile_gpu.sh encode [its args...]   (any program
+#        that takes --steps/--warmup)
 set -u
 TAG=${1:-4k}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --no-cpu-baseline $*"
+if [ -n "${PROFILE_PROG:-}" ]; then BENCH="python3 $REPO/$PROFILE_PROG $*"; else BENCH="python3 $REPO/bench.py --no-cpu-baseline $*"; fi
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 100 --warmup 10 > "$OUT/trace.log" 2>&1
 
