@@ -60,6 +60,13 @@ struct DecodeParams {
   // uniform != 0: frame i = frames[0] + i * step_* (bytes); lets one launch cover any number of frames
   uint32_t uniform;
   int64_t step_y, step_cbcr, step_alpha, step_out;
+  // decode_nv12_half_rep only (persistent workgroups, replicated LDS tables): `table` is held in
+  // 2^rep_dec_log2 interleaved copies (<= 16: one per lane of a ds_read_b128 lane group), `table2` in
+  // 2^rep_enc_log2; a tile row is one tile of one row pair of one frame, tile_rows of them in the
+  // launch, walked gridDim.x at a time; cursor_* = gridDim.x decomposed into (tiles, row pairs, frames).
+  uint32_t rep_dec_log2, rep_enc_log2;
+  uint32_t tiles_x, tile_rows;
+  uint32_t cursor_tx, cursor_rp, cursor_f;
 };
 
 // BGRA -> NV12 encoder (bt709_encode.hip).  One frame per launch.
@@ -124,6 +131,14 @@ const char *launch_decode(const DecodeParams &p, int frames, int variant, bool h
 // half: grid = (grid_x, H/2 output rows, frames) x block_threads.
 const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
                                uint32_t block_threads, hipStream_t stream);
+
+// half, conflict-free form: grid = workgroups (<= compute units, one resident per CU) x block_threads,
+// each walking tile rows workgroup, workgroup + grid, ...; fills the rep_*, tiles_x, tile_rows and cursor_*
+// fields of its copy of `p`.  Returns nullptr when the tables do not fit LDS (caller falls back).
+const char *launch_decode_half_rep(const DecodeParams &p, int frames, bool nontemporal, uint32_t workgroups,
+                                   hipStream_t stream);
+constexpr int kRepBlockThreads = 1024;      // one workgroup per CU: 16 waves
+constexpr uint32_t kRepLdsBytes = 160 * 1024;
 
 // scaled: grid = (ceil(OW / kBlockThreads), OH, frames) x kBlockThreads.
 const char *launch_decode_scaled(const DecodeParams &p, int frames, hipStream_t stream);

@@ -59,8 +59,25 @@ namespace {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// VALU budget (tools/valu_ops.hip, gfx950, waves of 64): v_add_f32 / v_mul_f32 / v_mov_b32 occupy a
+// SIMD for 2 cycles, every other VALU instruction these kernels use (converts, compares, selects,
+// integer and bit ops, SDWA forms) for 4.  At ~27 instructions per pixel the 1:1 kernel keeps the
+// VALU ~65 % busy at 6 TB/s, so instruction count is run time here, not just memory.
+#ifndef BT709_OPT_UBYTE
+#define BT709_OPT_UBYTE 1
+#endif
+#ifndef BT709_OPT_SDWA
+#define BT709_OPT_SDWA 0  // measured: -1 % (decode_lab, same call) -- kept for the lab
+#endif
+
 __device__ __forceinline__ float byte_of(uint32_t w, int i) {
-  return static_cast<float>((w >> (8 * i)) & 0xffu);  // -> v_cvt_f32_ubyte{i} / sdwa
+  float f = static_cast<float>((w >> (8 * i)) & 0xffu);  // v_cvt_f32_ubyte{i}: 4 cycles
+#if BT709_OPT_UBYTE
+  // Opaque to the optimiser: otherwise (float)(byte) + (-16.0f) is rewritten as an integer SDWA
+  // add plus v_cvt_f32_i32 (4 + 4 cycles) instead of this convert plus a 2-cycle v_add_f32.
+  asm("" : "+v"(f));
+#endif
+  return f;
 }
 
 // (v - off) * (1/255f): integer-valued floats subtract exactly, so this equals the
@@ -117,14 +134,46 @@ __device__ __forceinline__ void pixel_rgbs(const Matrix &m, float ybyte, const C
   b = __fadd_rn(yv, c.cb_b);
 }
 
+// word.byte[LANE] = bucket.base + (xs >= bucket.edge): the compare's carry goes straight into byte
+// LANE of the output word (SDWA destination select, other bytes preserved), so B, G, R (and a
+// decoded alpha) need no pack instructions at all.
+template <int LANE>
+__device__ __forceinline__ void lookup_into(uint32_t &word, const TransferBucket *__restrict__ tbl, float xs,
+                                            uint32_t zero) {
+  const uint32_t q = static_cast<uint32_t>(xs);
+  const TransferBucket e = tbl[q];
+  static_assert(LANE >= 0 && LANE < 4, "byte lane");
+  if (LANE == 0)
+    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32_sdwa %0, vcc, %3, %4, vcc dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(word) : "v"(xs), "v"(e.edge), "v"(e.base), "v"(zero) : "vcc");
+  else if (LANE == 1)
+    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32_sdwa %0, vcc, %3, %4, vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(word) : "v"(xs), "v"(e.edge), "v"(e.base), "v"(zero) : "vcc");
+  else if (LANE == 2)
+    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32_sdwa %0, vcc, %3, %4, vcc dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(word) : "v"(xs), "v"(e.edge), "v"(e.base), "v"(zero) : "vcc");
+  else
+    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32_sdwa %0, vcc, %3, %4, vcc dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(word) : "v"(xs), "v"(e.edge), "v"(e.base), "v"(zero) : "vcc");
+}
+
 __device__ __forceinline__ uint32_t decode_px(const TransferBucket *__restrict__ tbl, const Matrix &m, float ybyte,
                                               const Chroma &c, uint32_t alpha_word) {
   float r, g, b;
   pixel_rgbs(m, ybyte, c, r, g, b);
+#if BT709_OPT_SDWA
+  uint32_t word = alpha_word, zero = 0;
+  asm("" : "+v"(zero));  // one VGPR of zeros (an SDWA source operand cannot be an inline constant)
+  lookup_into<2>(word, tbl, r, zero);
+  lookup_into<1>(word, tbl, g, zero);
+  lookup_into<0>(word, tbl, b, zero);
+  return word;
+#else
   const uint32_t R = lookup(tbl, r);
   const uint32_t G = lookup(tbl, g);
   const uint32_t B = lookup(tbl, b);
   return pack_bgra(R, G, B, alpha_word);
+#endif
 }
 
 // linear alpha sample -> byte: R channel of the matrix with Cb=Cr=128, then plain
@@ -198,7 +247,10 @@ decode_nv12_quads(const DecodeParams p) {
   const uint32_t row_pairs = p.height >> 1;
   // blockDim.y > 1 only for narrow frames: a workgroup then covers blockDim.y consecutive row
   // pairs so that it still has ~8 waves (1920-wide: 256 x 2)
-  const uint32_t rp_raw = blockIdx.y * blockDim.y + threadIdx.y;
+  // blockDim.x is a whole number of waves, so threadIdx.y is the same in every lane of a wave:
+  // taking it from the first lane makes the row pointers scalar (SGPR base + per-lane offset
+  // addressing, no 64-bit VALU address arithmetic).
+  const uint32_t rp_raw = blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
   const uint32_t rp = min(rp_raw, row_pairs - 1);
   const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
 
@@ -480,6 +532,221 @@ decode_nv12_half(const DecodeParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Fused decode + exact 2:1 downscale, CONFLICT-FREE form: same arithmetic and the same bytes out
+// as decode_nv12_half<*, WIDE>, which is LDS-bound (12 + 3 random bucket lookups per output
+// pixel; on random content ~2.4 LDS cycles per conflict-free one).  Here the decode-side table
+// sits in LDS in R = 16 interleaved copies, entry q of copy c at byte (q * R + c) * 16, and lane
+// l reads copy l & 15: the 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...:
+// MI355X_MICROARCH.md, LDS) then hit 16 different 16-byte bank groups whatever their q, so each
+// lookup costs its 4 LDS cycles and no more.  The sRGB-encode table gets the copies that still
+// fit (4 for the default gamma: 131 + 24 KiB of the CU's 160).  One workgroup per CU can hold
+// that, so workgroups are PERSISTENT: the tables are staged once per launch, then workgroup w
+// walks tile rows w, w + G, w + 2G, ... (G = gridDim.x; at any moment the CUs work on
+// neighbouring row pairs, i.e. the DRAM stream stays address-ordered) with the loads of the
+// next PF tile rows already in flight.  A tile row = blockDim.x quads of one row pair; the
+// cursor (tile, row pair, frame) advances by G decomposed on the host: no division in the loop.
+//
+// Index arithmetic: with S = 16 R the matrix constants are scaled by N * S (power of two, so
+// every product and sum is exactly S times the N-scaled value), (uint)xs & ~(S - 1) IS the byte
+// offset of entry q = floor(xs / S), and the lane's copy offset is OR-ed in: v_min_f32,
+// v_cvt_u32_f32, v_and_or_b32 per lookup.  Bucket edges are scaled by S while staging.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct RepLookup {
+  float dec_max;       // N * S
+  uint32_t dec_mask;   // ~(S - 1)
+  uint32_t dec_lane;   // (lane & (R - 1)) * 16
+  uint32_t enc_shift;  // log2(8 * copies of table2)
+  uint32_t enc_lane;   // LDS offset of table2 + (lane & (copies - 1)) * 8
+};
+
+struct TileCursor {
+  uint32_t tx, rp, f;
+};
+
+struct QuadIn {
+  uint32_t ya, yb, cw;
+};
+
+__device__ __forceinline__ void advance(TileCursor &c, const DecodeParams &p, uint32_t row_pairs) {
+  c.tx += p.cursor_tx;  // < tiles_x
+  c.rp += p.cursor_rp;  // < row_pairs
+  c.f += p.cursor_f;
+  if (c.tx >= p.tiles_x) {
+    c.tx -= p.tiles_x;
+    ++c.rp;
+  }
+  if (c.rp >= row_pairs) {
+    c.rp -= row_pairs;
+    ++c.f;
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ QuadIn load_quad(const DecodeParams &p, const TileCursor &c, uint32_t quads) {
+  const FramePlanes f = frame_planes(p, c.f);
+  const uint8_t *y0 = f.y + static_cast<size_t>(2 * c.rp) * p.y_stride;
+  const uint8_t *cc = f.cbcr + static_cast<size_t>(c.rp) * p.cbcr_stride;
+  const uint32_t q = min(c.tx * blockDim.x + threadIdx.x, quads - 1);  // clamped load, predicated store
+  QuadIn in;
+  in.ya = load32<NT>(y0 + 4 * q);
+  in.yb = load32<NT>(y0 + p.y_stride + 4 * q);
+  in.cw = load32<NT>(cc + 4 * q);
+  return in;
+}
+
+__device__ __forceinline__ uint32_t rep_address(const RepLookup &r, float &xs) {
+  xs = __builtin_fminf(xs, r.dec_max);
+  return (static_cast<uint32_t>(xs) & r.dec_mask) | r.dec_lane;
+}
+
+__device__ __forceinline__ uint32_t lookup_split_rep(const unsigned char *lds, const RepLookup &r, const SplitIndex &s,
+                                                     float xs) {
+  const uint32_t qf = static_cast<uint32_t>(xs);
+  const uint32_t qc = static_cast<uint32_t>(__fmul_rn(xs, s.coarse)) + s.offset;
+  const uint32_t q = xs < s.split ? qf : qc;
+  const TransferBucket e = *reinterpret_cast<const TransferBucket *>(lds + ((q << r.enc_shift) + r.enc_lane));
+  return e.base + (xs >= e.edge ? 1u : 0u);
+}
+
+__device__ __forceinline__ uint32_t half_px_rep(const unsigned char *lds, const RepLookup &r, const Matrix &m,
+                                                const SplitIndex &es, float en, float y00, float y01, float y10,
+                                                float y11, const Chroma &c, uint32_t alpha_word) {
+  float x[12];  // r0..r3, g0..g3, b0..b3 of the four source pixels
+  pixel_rgbs(m, y00, c, x[0], x[4], x[8]);
+  pixel_rgbs(m, y01, c, x[1], x[5], x[9]);
+  pixel_rgbs(m, y10, c, x[2], x[6], x[10]);
+  pixel_rgbs(m, y11, c, x[3], x[7], x[11]);
+  uint32_t a[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) a[i] = rep_address(r, x[i]);
+  float lin[12];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u32x4 e[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[i] = *reinterpret_cast<const u32x4 *>(lds + a[6 * h + i]);
+    asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait per batch
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lin[6 * h + i] = linear_select(e[i], x[6 * h + i]);
+  }
+  const float *lr = lin, *lg = lin + 4, *lb = lin + 8;
+  const float k = __fmul_rn(0.25f, en);
+  const float mr = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]), k);
+  const float mg = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]), k);
+  const float mb = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]), k);
+  const uint32_t R = lookup_split_rep(lds, r, es, mr);
+  const uint32_t G = lookup_split_rep(lds, r, es, mg);
+  const uint32_t B = lookup_split_rep(lds, r, es, mb);
+  return pack_bgra(R, G, B, alpha_word);
+}
+
+}  // namespace
+
+template <bool NT, int U>
+__global__ void __launch_bounds__(kRepBlockThreads)
+decode_nv12_half_rep(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t row_pairs = p.height >> 1, quads = p.width >> 2;
+  const uint32_t G = gridDim.x;
+
+  uint32_t t = blockIdx.x;  // < tile_rows (the launcher never starts more workgroups than tile rows)
+  TileCursor pre;
+  pre.tx = t % p.tiles_x;
+  pre.rp = (t / p.tiles_x) % row_pairs;
+  pre.f = (t / p.tiles_x) / row_pairs;
+  TileCursor cur = pre;
+
+  // A step is U tile rows t, t + G, ...: their loads are issued one whole step ahead (first ones:
+  // before the tables are staged).  Past the end of the launch a slot repeats the step's first tile
+  // row -- same loads, same result, same store -- so every step is exactly 3U loads and U stores.
+  QuadIn in[U];
+  {
+    const TileCursor first = pre;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool have = t + u * G < p.tile_rows;
+      const TileCursor c = {have ? pre.tx : first.tx, have ? pre.rp : first.rp, have ? pre.f : first.f};
+      in[u] = load_quad<NT>(p, c, quads);
+      advance(pre, p, row_pairs);
+    }
+  }
+
+  const uint32_t r1 = p.rep_dec_log2, r2 = p.rep_enc_log2;
+  const float S = static_cast<float>(16u << r1);
+  {
+    u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(p.table);
+    const uint32_t n = (p.table_bytes / 16) << r1;
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+      u32x4 e = src[i >> r1];
+      e.x = __float_as_uint(__fmul_rn(__uint_as_float(e.x), S));  // edge into the S-scaled domain (inf stays inf)
+      d[i] = e;
+    }
+    u32x2 *d2 = reinterpret_cast<u32x2 *>(lds_raw + (static_cast<size_t>(p.table_bytes) << r1));
+    const u32x2 *src2 = reinterpret_cast<const u32x2 *>(p.table2);
+    const uint32_t n2 = (p.table2_bytes / 8) << r2;
+    for (uint32_t i = tid; i < n2; i += blockDim.x) d2[i] = src2[i >> r2];
+  }
+  __syncthreads();
+
+  RepLookup r;
+  r.dec_max = __fmul_rn(p.table_scale, S);
+  r.dec_mask = ~((16u << r1) - 1u);
+  r.dec_lane = (tid & ((1u << r1) - 1u)) * 16u;
+  r.enc_shift = 3u + r2;
+  r.enc_lane = (p.table_bytes << r1) + (tid & ((1u << r2) - 1u)) * 8u;
+  Matrix m = matrix_of(p);
+  m.y = __fmul_rn(m.y, S);
+  m.cr_r = __fmul_rn(m.cr_r, S);
+  m.cb_g = __fmul_rn(m.cb_g, S);
+  m.cr_g = __fmul_rn(m.cr_g, S);
+  m.cb_b = __fmul_rn(m.cb_b, S);
+  const float en = p.table2_scale;
+  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset};
+
+  for (; t < p.tile_rows; t += U * G) {
+    // next step's loads first: they have this step's arithmetic (and the other waves') to arrive
+    QuadIn nx[U];
+    {
+      const TileCursor first = pre;  // valid or not: only dereferenced when t + U * G < tile_rows
+      const bool any = t + U * G < p.tile_rows;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool have = t + (U + u) * G < p.tile_rows;
+        const TileCursor a = have ? pre : first;
+        const TileCursor c = {any ? a.tx : cur.tx, any ? a.rp : cur.rp, any ? a.f : cur.f};
+        nx[u] = load_quad<NT>(p, c, quads);
+        advance(pre, p, row_pairs);
+      }
+    }
+    const TileCursor first = cur;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool have = t + u * G < p.tile_rows;
+      const TileCursor c = {have ? cur.tx : first.tx, have ? cur.rp : first.rp, have ? cur.f : first.f};
+      const Chroma c0 = chroma_terms(m, byte_of(in[u].cw, 0), byte_of(in[u].cw, 1));
+      const Chroma c1 = chroma_terms(m, byte_of(in[u].cw, 2), byte_of(in[u].cw, 3));
+      u32x2 v;
+      v.x = half_px_rep(lds_raw, r, m, es, en, byte_of(in[u].ya, 0), byte_of(in[u].ya, 1), byte_of(in[u].yb, 0),
+                        byte_of(in[u].yb, 1), c0, p.alpha_word);
+      v.y = half_px_rep(lds_raw, r, m, es, en, byte_of(in[u].ya, 2), byte_of(in[u].ya, 3), byte_of(in[u].yb, 2),
+                        byte_of(in[u].yb, 3), c1, p.alpha_word);
+      const FramePlanes f = frame_planes(p, c.f);
+      uint8_t *o = f.out + static_cast<size_t>(c.rp) * p.out_stride;
+      // lanes past the row's end loaded the last quad (clamp), hold its result and store it again
+      const uint32_t q = min(c.tx * blockDim.x + tid, quads - 1);
+      store8<NT>(o + 8 * q, v);
+      advance(cur, p, row_pairs);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) in[u] = nx[u];  // hipcc waits here for the loads issued at the top (not for the stores)
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Fused decode + bilinear rescale to ANY output size (pass 1 + MetalScaleRenderContext
 // -renderScaled:, AAPLShaders.metal:73-85, for a view that is not an exact 2:1 of the frame).
 // Two-pass-equivalent definition ("rescale"; parity unpinned by the reference):
@@ -545,6 +812,10 @@ decode_nv12_scaled(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 // host-callable launchers (no HIP types in the signature beyond hipStream_t)
 // ---------------------------------------------------------------------------
+#ifndef BT709_REP_PREFETCH
+#define BT709_REP_PREFETCH 2  // tile rows per step of the persistent rescale kernel (loads run one step ahead)
+#endif
+
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
 #if defined(BT709_LAB_LDS_CHROMA)
@@ -586,6 +857,8 @@ hipError_t prepare_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_half<false, true>),
       reinterpret_cast<const void *>(&decode_nv12_half<false, false>),
       reinterpret_cast<const void *>(&decode_nv12_scaled),
+      reinterpret_cast<const void *>(&decode_nv12_half_rep<true, BT709_REP_PREFETCH>),
+      reinterpret_cast<const void *>(&decode_nv12_half_rep<false, BT709_REP_PREFETCH>),
       reinterpret_cast<const void *>(&decode_nv12_quads<true, true>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, true>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false>),
@@ -612,6 +885,37 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
   }
   hipLaunchKernelGGL((decode_nv12_half<false, false>), grid, block, lds, stream, p);
   return "decode_nv12_half<narrow>";
+}
+
+const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool nontemporal, uint32_t workgroups,
+                                   hipStream_t stream) {
+  DecodeParams p = p_in;
+  // copies: as many as fit the CU's LDS, decode side first (12 of the 15 lookups per output pixel)
+  uint32_t r1 = 4, r2 = 0;
+  while (r1 > 0 && (static_cast<uint64_t>(p.table_bytes) << r1) + p.table2_bytes > kRepLdsBytes) --r1;
+  if ((static_cast<uint64_t>(p.table_bytes) << r1) + p.table2_bytes > kRepLdsBytes) return nullptr;
+  while (r2 < 5 && (static_cast<uint64_t>(p.table_bytes) << r1) + (static_cast<uint64_t>(p.table2_bytes) << (r2 + 1)) <=
+                       kRepLdsBytes)
+    ++r2;
+  p.rep_dec_log2 = r1;
+  p.rep_enc_log2 = r2;
+  const uint32_t quads = p.width / 4, row_pairs = p.height / 2;
+  p.tiles_x = (quads + kRepBlockThreads - 1) / kRepBlockThreads;
+  uint32_t threads = ((quads + p.tiles_x - 1) / p.tiles_x + 63) / 64 * 64;
+  const uint64_t total = static_cast<uint64_t>(p.tiles_x) * row_pairs * static_cast<uint32_t>(frames);
+  if (total == 0 || total > 0x7fffffffu) return nullptr;
+  p.tile_rows = static_cast<uint32_t>(total);
+  if (workgroups > p.tile_rows) workgroups = p.tile_rows;
+  if (workgroups == 0) workgroups = 1;
+  p.cursor_tx = workgroups % p.tiles_x;
+  p.cursor_rp = (workgroups / p.tiles_x) % row_pairs;
+  p.cursor_f = (workgroups / p.tiles_x) / row_pairs;
+  const size_t lds = (static_cast<size_t>(p.table_bytes) << r1) + (static_cast<size_t>(p.table2_bytes) << r2);
+  if (nontemporal)
+    hipLaunchKernelGGL((decode_nv12_half_rep<true, BT709_REP_PREFETCH>), dim3(workgroups), dim3(threads), lds, stream, p);
+  else
+    hipLaunchKernelGGL((decode_nv12_half_rep<false, BT709_REP_PREFETCH>), dim3(workgroups), dim3(threads), lds, stream, p);
+  return "decode_nv12_half_rep";
 }
 
 const char *launch_decode_scaled(const DecodeParams &p, int frames, hipStream_t stream) {

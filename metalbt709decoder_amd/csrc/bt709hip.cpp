@@ -45,6 +45,7 @@ struct bt709hip_decoder {
   int has_alpha = 0;
   uint32_t alpha_fill = 0xFF;
   bool nontemporal = true;
+  int half_rep = -1;  // persistent conflict-free rescale kernel: -1 = when the launch is large enough, 0 never, 1 always
   std::mutex setup_mutex;
   bool ready = false;
   // device copies
@@ -384,6 +385,7 @@ int bt709hip_decoder_create(bt709hip_context *ctx, int gamma, int has_alpha, bt7
   // RGBA render supports only the sRGB gamma function (MetalBT709Decoder.m:165-169)
   dec->gamma = has_alpha ? BT709HIP_GAMMA_SRGB : gamma;
   dec->nontemporal = env_int("BT709HIP_NONTEMPORAL", 1) != 0;
+  dec->half_rep = env_int("BT709HIP_HALF_REP", -1);
   *out = dec;
   return BT709HIP_OK;
 }
@@ -579,7 +581,16 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   // wide: same tiling as the 1:1 kernel over the source width; narrow: 256 output pixels per workgroup
   const uint32_t gx = wide ? quads_tiles(p.width) : (p.width / 2 + kBlockThreads - 1) / kBlockThreads;
   const uint32_t threads = wide ? quads_block_threads(p.width) : kBlockThreads;
-  tl_kernel_name = launch_decode_half(p, count, wide, dec->nontemporal, gx, threads, s);
+  // Large launches: persistent workgroups with bank-conflict-free (replicated) LDS tables, one per CU.
+  // Staging ~150 KiB of LDS per workgroup pays once a CU has a few dozen tile rows to walk.
+  const uint32_t cus = static_cast<uint32_t>(dec->ctx->props.multiProcessorCount);
+  const uint64_t tile_rows = static_cast<uint64_t>((p.width / 4 + kRepBlockThreads - 1) / kRepBlockThreads) *
+                             (p.height / 2) * static_cast<uint32_t>(count);
+  const bool rep = wide && dec->half_rep != 0 && (dec->half_rep > 0 || tile_rows >= 32ull * cus);
+  const char *name = rep ? launch_decode_half_rep(p, count, dec->nontemporal,
+                                                  static_cast<uint32_t>(env_int("BT709HIP_REP_WORKGROUPS", static_cast<int>(cus))), s)
+                         : nullptr;
+  tl_kernel_name = name ? name : launch_decode_half(p, count, wide, dec->nontemporal, gx, threads, s);
   HIP_TRY(hipGetLastError());
   if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;

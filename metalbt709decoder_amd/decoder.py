@@ -411,6 +411,22 @@ class MetalBT709Decoder:
         self.lastStatus = _capi.OK
         return True
 
+    def decodeBT709ScaledBatch(self, pixelBuffers, textures, commandBuffer=None, waitUntilCompleted=False):
+        """Exact 2:1 fused decode + rescale of `count` same-geometry frames in one launch (no
+        reference twin).  Large launches run the persistent conflict-free kernel."""
+        if not self.setupMetal():
+            return False
+        n = len(pixelBuffers)
+        frames = (Frame * n)(*[b.frame() for b in pixelBuffers])
+        surfs = (Surface * n)(*[t.surface() for t in textures])
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = self.metalRenderContext.lib.bt709hip_decode_half_batch(self._handle, n, frames, surfs, stream,
+                                                                    int(bool(waitUntilCompleted)))
+        if rc != _capi.OK:
+            return self._fail(rc, "decodeBT709ScaledBatch")
+        self.lastStatus = _capi.OK
+        return True
+
     def release(self):
         ctx = self.metalRenderContext
         if self._handle and ctx is not None and ctx.handle:  # a destroyed context took the device with it

@@ -360,6 +360,41 @@ def test_half_scale(gh, oracle, gamma, size):
     assert np.array_equal(out, oracle.decode_nv12_half(gamma, y, c))
 
 
+@pytest.mark.parametrize("workgroups", [1, 3, 256])
+@pytest.mark.parametrize("gamma", GAMMAS)
+@pytest.mark.parametrize("size", [(4, 4), (40, 12), (256, 64), (1920, 1080 - 1080 % 4), (4104, 8), (8200, 12)])
+def test_half_scale_persistent_kernel(gh, oracle, monkeypatch, gamma, size, workgroups):
+    """The persistent conflict-free form of the 2:1 kernel (replicated LDS tables, one workgroup per
+    CU walking tile rows) forced on frames of every shape: rows narrower than a workgroup, rows
+    of 2 and 3 tiles, more / fewer workgroups than tile rows, odd tile-row counts."""
+    monkeypatch.setenv("BT709HIP_HALF_REP", "1")
+    monkeypatch.setenv("BT709HIP_REP_WORKGROUPS", str(workgroups))
+    w, h = size
+    y, c = gh.random_nv12(w, h, seed=w + h + gamma)
+    dec = gh.make_decoder(gamma)
+    out = gh.gpu_decode_half(y, c, gamma, decoder=dec)
+    assert gh.context().lib.bt709hip_last_kernel_name() == b"decode_nv12_half_rep"
+    assert np.array_equal(out, oracle.decode_nv12_half(gamma, y, c))
+
+
+@pytest.mark.parametrize("rep", [0, 1])
+@pytest.mark.parametrize("count", [2, 5])
+def test_half_scale_batch(gh, oracle, monkeypatch, rep, count):
+    """Several frames per launch (pointer table; the persistent kernel's cursor crosses frames)."""
+    monkeypatch.setenv("BT709HIP_HALF_REP", str(rep))
+    monkeypatch.setenv("BT709HIP_REP_WORKGROUPS", "7")
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    w, h = 72, 20
+    frames = [gh.random_nv12(w, h, seed=900 + i) for i in range(count)]
+    bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
+    texs = [ctx.makeBGRATexture((w // 2, h // 2)) for _ in range(count)]
+    assert dec.decodeBT709ScaledBatch(bufs, texs, ctx.commandQueue.commandBuffer(), True), dec.lastStatus
+    for (y, c), tex in zip(frames, texs):
+        got = ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(h // 2, (w // 2) * 4)
+        assert np.array_equal(got, oracle.decode_nv12_half(0, y, c))
+
+
 def test_half_scale_flat_frame_is_identity(gh):
     y = np.full((64, 64), 180, np.uint8)
     c = np.full((32, 64), 128, np.uint8)
