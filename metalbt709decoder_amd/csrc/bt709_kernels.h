@@ -38,6 +38,9 @@ struct FramePlanes {
 struct DecodeParams {
   FramePlanes frames[kMaxBatch];
   const void *table;   // TransferBucket[] (decode) or TransferBucketLinear[] (half)
+  const void *table_unit;  // fast 1:1 kernel: TransferBucket[N + 1], edges NOT scaled (transfer_tables.h buckets_unit)
+  uint32_t table_unit_bytes;
+  float unit_magic;        // 2^23 / N (filled by launch_decode): floats in [M, 2M) have ulp 1/N
   const void *table2;  // half only: two-resolution sRGB-encode table (transfer_tables.h SplitTable)
   uint32_t table_bytes;
   uint32_t table2_bytes;

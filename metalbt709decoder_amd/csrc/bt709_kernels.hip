@@ -184,6 +184,100 @@ __device__ __forceinline__ uint32_t decode_alpha(const TransferBucket *__restric
   return lookup(ident, __fmul_rn(centre_norm(abyte, 16.0f), m.y)) << 24;
 }
 
+#ifndef BT709_OPT_UNIT
+#define BT709_OPT_UNIT 1
+#endif
+
+// ---------------------------------------------------------------------------
+// UNIT-DOMAIN lookups of the fast kernel.  R, G, B are formed exactly as the reference forms
+// them (unscaled matrix, BT709.h:389-426) and saturated for free by the clamp bit of the add
+// that produces them (BT709.h:444-446), so the table needs only its N + 1 unit entries.  The
+// bucket index costs one 2-cycle add instead of a 4-cycle convert: with M = 2^23 / N a float in
+// [M, 2M) has ulp 1/N, so x + M rounded TOWARD ZERO is M + floor(x N) / N and its bit pattern
+// is bits(M) + floor(x N).  v_lshl_add_u32 turns that into the LDS byte address (the constant
+// term cancels bits(M) << 3).  The round-toward-zero adds sit in one asm statement between two
+// s_setreg of MODE.fp_round's single-precision field; everything else rounds to nearest even.
+// ---------------------------------------------------------------------------
+struct UnitLookup {
+  float magic;      // M = 2^23 / N
+  uint32_t offset;  // LDS address of the table - (bits(M) << 3)
+};
+
+__device__ __forceinline__ float add_sat(float a, float b) {
+  float r;
+  asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// t[i] = bits(x[i] + M), rounded toward zero, 12 at a time (an asm statement takes 30 operands)
+__device__ __forceinline__ void magic_floor12(const float *x, uint32_t *t, float magic) {
+  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_add_f32 %0, %24, %12\n\tv_add_f32 %1, %24, %13\n\tv_add_f32 %2, %24, %14\n\tv_add_f32 %3, %24, %15\n\t"
+      "v_add_f32 %4, %24, %16\n\tv_add_f32 %5, %24, %17\n\tv_add_f32 %6, %24, %18\n\tv_add_f32 %7, %24, %19\n\t"
+      "v_add_f32 %8, %24, %20\n\tv_add_f32 %9, %24, %21\n\tv_add_f32 %10, %24, %22\n\tv_add_f32 %11, %24, %23\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+        "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
+        "v"(x[10]), "v"(x[11]), "s"(magic));
+}
+
+typedef __attribute__((address_space(3))) const u32x2 *LdsBucketPtr;  // {edge bits, base}: one ds_read_b64, no base add
+
+// One 4x2 quad: 8 pixels x (R, G, B) = 24 lookups.  x[3 * p + c], pixel p = 0..3 top row, 4..7 bottom.
+template <bool HAS_ALPHA>
+__device__ __forceinline__ void quad_unit(const UnitLookup &u, uint32_t ya, uint32_t yb, uint32_t cw, uint32_t aa,
+                                          uint32_t ab, uint32_t alpha_word, u32x4 &top, u32x4 &bot) {
+  const Matrix m = {kMY, kMCrR, kMCbG, kMCrG, kMCbB};
+  const Chroma c0 = chroma_terms(m, byte_of(cw, 0), byte_of(cw, 1));
+  const Chroma c1 = chroma_terms(m, byte_of(cw, 2), byte_of(cw, 3));
+  float x[24];
+#pragma unroll
+  for (int px = 0; px < 8; ++px) {
+    const uint32_t w = px < 4 ? ya : yb;
+    const Chroma &c = (px & 2) ? c1 : c0;
+    const float yv = __fmul_rn(centre_norm(byte_of(w, px & 3), 16.0f), m.y);
+    x[3 * px + 0] = add_sat(yv, c.cr_r);
+    x[3 * px + 1] = add_sat(__fadd_rn(yv, c.cb_g), c.cr_g);
+    x[3 * px + 2] = add_sat(yv, c.cb_b);
+  }
+  uint32_t t[24];
+  magic_floor12(x, t, u.magic);
+  magic_floor12(x + 12, t + 12, u.magic);
+  uint32_t byte[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    const u32x2 e = *reinterpret_cast<LdsBucketPtr>((t[i] << 3) + u.offset);
+    byte[i] = e.y + (x[i] >= __uint_as_float(e.x) ? 1u : 0u);
+  }
+  uint32_t al[8];
+#pragma unroll
+  for (int px = 0; px < 8; ++px) al[px] = alpha_word;
+  if (HAS_ALPHA) {
+    float a[12];
+    uint32_t ta[12];
+#pragma unroll
+    for (int px = 0; px < 8; ++px)
+      a[px] = add_sat(__fmul_rn(centre_norm(byte_of(px < 4 ? aa : ab, px & 3), 16.0f), m.y), 0.0f);
+#pragma unroll
+    for (int i = 8; i < 12; ++i) a[i] = 0.0f;
+    magic_floor12(a, ta, u.magic);
+#pragma unroll
+    for (int px = 0; px < 8; ++px) {
+      const u32x2 e = *reinterpret_cast<LdsBucketPtr>((ta[px] << 3) + u.offset);
+      al[px] = (e.y + (a[px] >= __uint_as_float(e.x) ? 1u : 0u)) << 24;
+    }
+  }
+  top.x = pack_bgra(byte[0], byte[1], byte[2], al[0]);
+  top.y = pack_bgra(byte[3], byte[4], byte[5], al[1]);
+  top.z = pack_bgra(byte[6], byte[7], byte[8], al[2]);
+  top.w = pack_bgra(byte[9], byte[10], byte[11], al[3]);
+  bot.x = pack_bgra(byte[12], byte[13], byte[14], al[4]);
+  bot.y = pack_bgra(byte[15], byte[16], byte[17], al[5]);
+  bot.z = pack_bgra(byte[18], byte[19], byte[20], al[6]);
+  bot.w = pack_bgra(byte[21], byte[22], byte[23], al[7]);
+}
+
 __device__ __forceinline__ void stage_table(void *lds, const void *src, uint32_t bytes) {
   u32x4 *d = reinterpret_cast<u32x4 *>(lds);
   const u32x4 *s = reinterpret_cast<const u32x4 *>(src);
@@ -293,7 +387,11 @@ decode_nv12_quads(const DecodeParams p) {
     }
   }
 #endif
+#if BT709_OPT_UNIT
+  stage_table(tbl, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
+#else
   stage_table(tbl, p.table, p.table_bytes);  // after the tile's loads are in flight
+#endif
   __syncthreads();
 #if defined(BT709_LAB_LDS_CHROMA)
 #pragma unroll
@@ -308,12 +406,21 @@ decode_nv12_quads(const DecodeParams p) {
     if (HAS_ALPHA) asm volatile("" : "+v"(aa[u]), "+v"(ab[u]));
   }
 
+#if BT709_OPT_UNIT
+  UnitLookup ul;
+  ul.magic = p.unit_magic;
+  ul.offset = static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)lds_raw)) -
+              (__float_as_uint(ul.magic) << 3);
+#endif
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = q0 + u * blockDim.x;
+    u32x4 top, bot;
+#if BT709_OPT_UNIT
+    quad_unit<HAS_ALPHA>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top, bot);
+#else
     const Chroma c0 = chroma_terms(m, byte_of(cw[u], 0), byte_of(cw[u], 1));
     const Chroma c1 = chroma_terms(m, byte_of(cw[u], 2), byte_of(cw[u], 3));
-    u32x4 top, bot;
     uint32_t al[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -328,6 +435,7 @@ decode_nv12_quads(const DecodeParams p) {
     bot.y = decode_px(tbl, m, byte_of(yb[u], 1), c0, al[5]);
     bot.z = decode_px(tbl, m, byte_of(yb[u], 2), c1, al[6]);
     bot.w = decode_px(tbl, m, byte_of(yb[u], 3), c1, al[7]);
+#endif
     if (q < quads && rp_raw < row_pairs) {
       store16<NT>(o0 + 16 * q, top);
       store16<NT>(o1 + 16 * q, bot);
@@ -418,13 +526,15 @@ __device__ __forceinline__ float linear_select(const u32x4 &e, float xs) {
 struct SplitIndex {  // transfer_tables.h SplitTable
   float split, coarse;
   uint32_t offset;
+  uint32_t coarse_shift;  // log2(1 / coarse)
 };
 
 // two-resolution table: fine buckets below `split`, `1/coarse` times wider ones above
 __device__ __forceinline__ uint32_t lookup_split(const TransferBucket *__restrict__ tbl, const SplitIndex &s, float xs) {
+  // the fine and the coarse index functions cross exactly at the split and the fine one grows
+  // faster, so the smaller of the two is the right one (4 VALU instructions instead of 6)
   const uint32_t qf = static_cast<uint32_t>(xs);
-  const uint32_t qc = static_cast<uint32_t>(__fmul_rn(xs, s.coarse)) + s.offset;  // exact: power of two
-  const TransferBucket e = tbl[xs < s.split ? qf : qc];
+  const TransferBucket e = tbl[min(qf, (qf >> s.coarse_shift) + s.offset)];
   return e.base + (xs >= e.edge ? 1u : 0u);
 }
 
@@ -478,7 +588,7 @@ decode_nv12_half(const DecodeParams p) {
   const FramePlanes f = frame_planes(p, blockIdx.z);
   const Matrix m = matrix_of(p);
   const float en = p.table2_scale, dn = p.table_scale;
-  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset};
+  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset, 127u - (__float_as_uint(p.table2_coarse) >> 23)};
   const uint32_t out_rows = p.height >> 1;
   const uint32_t orow_raw = blockIdx.y * blockDim.y + threadIdx.y;
   const uint32_t orow = min(orow_raw, out_rows - 1);
@@ -546,17 +656,19 @@ decode_nv12_half(const DecodeParams p) {
 // next PF tile rows already in flight.  A tile row = blockDim.x quads of one row pair; the
 // cursor (tile, row pair, frame) advances by G decomposed on the host: no division in the loop.
 //
-// Index arithmetic: with S = 16 R the matrix constants are scaled by N * S (power of two, so
-// every product and sum is exactly S times the N-scaled value), (uint)xs & ~(S - 1) IS the byte
-// offset of entry q = floor(xs / S), and the lane's copy offset is OR-ed in: v_min_f32,
-// v_cvt_u32_f32, v_and_or_b32 per lookup.  Bucket edges are scaled by S while staging.
+// Index arithmetic (this kernel is VALU-bound once the conflicts are gone, so it is counted in
+// cycles, see the VALU budget note at the top): R, G, B in x units, saturated by the clamp bit of
+// their last add; one round-toward-zero add of M = 2^23 / N gives bits(M) + floor(x N)
+// (magic_floor12); v_lshl_add_u32 scales that to the entry's byte offset, adds the lane's copy
+// offset and cancels bits(M): 2 + 4 cycles per index instead of min + convert + and-or + add
+// (16).  Bucket edges are brought back to x units while staging.
 // ---------------------------------------------------------------------------
 namespace {
 
 struct RepLookup {
-  float dec_max;       // N * S
-  uint32_t dec_mask;   // ~(S - 1)
-  uint32_t dec_lane;   // (lane & (R - 1)) * 16
+  float magic;         // 2^23 / N: x + magic, rounded toward zero, has bit pattern bits(magic) + floor(x N)
+  uint32_t dec_shift;  // log2(16 R)
+  uint32_t dec_off;    // (lane & (R - 1)) * 16 - (bits(magic) << dec_shift): cancels the constant term
   uint32_t enc_shift;  // log2(8 * copies of table2)
   uint32_t enc_lane;   // LDS offset of table2 + (lane & (copies - 1)) * 8
 };
@@ -596,37 +708,43 @@ __device__ __forceinline__ QuadIn load_quad(const DecodeParams &p, const TileCur
   return in;
 }
 
-__device__ __forceinline__ uint32_t rep_address(const RepLookup &r, float &xs) {
-  xs = __builtin_fminf(xs, r.dec_max);
-  return (static_cast<uint32_t>(xs) & r.dec_mask) | r.dec_lane;
-}
-
 __device__ __forceinline__ uint32_t lookup_split_rep(const unsigned char *lds, const RepLookup &r, const SplitIndex &s,
                                                      float xs) {
+  // fine index below the split, coarse above: the two index functions cross exactly at the split
+  // (fine grows ratio times faster), so the smaller one is always the right one: 4 VALU
+  // instructions instead of convert, multiply, convert, add, compare, select
   const uint32_t qf = static_cast<uint32_t>(xs);
-  const uint32_t qc = static_cast<uint32_t>(__fmul_rn(xs, s.coarse)) + s.offset;
-  const uint32_t q = xs < s.split ? qf : qc;
-  const TransferBucket e = *reinterpret_cast<const TransferBucket *>(lds + ((q << r.enc_shift) + r.enc_lane));
-  return e.base + (xs >= e.edge ? 1u : 0u);
+  const uint32_t q = min(qf, (qf >> s.coarse_shift) + s.offset);
+  const u32x2 e = *reinterpret_cast<LdsBucketPtr>((q << r.enc_shift) + r.enc_lane);
+  return e.y + (xs >= __uint_as_float(e.x) ? 1u : 0u);
+}
+
+typedef __attribute__((address_space(3))) const u32x4 *LdsLinearPtr;
+
+// x = saturate(yv + chroma terms) in x units, exactly the reference's value (BT709.h:424-446)
+__device__ __forceinline__ void pixel_rgb_sat(const Matrix &m, float ybyte, const Chroma &c, float &r, float &g, float &b) {
+  const float yv = __fmul_rn(centre_norm(ybyte, 16.0f), m.y);
+  r = add_sat(yv, c.cr_r);
+  g = add_sat(__fadd_rn(yv, c.cb_g), c.cr_g);
+  b = add_sat(yv, c.cb_b);
 }
 
 __device__ __forceinline__ uint32_t half_px_rep(const unsigned char *lds, const RepLookup &r, const Matrix &m,
                                                 const SplitIndex &es, float en, float y00, float y01, float y10,
                                                 float y11, const Chroma &c, uint32_t alpha_word) {
-  float x[12];  // r0..r3, g0..g3, b0..b3 of the four source pixels
-  pixel_rgbs(m, y00, c, x[0], x[4], x[8]);
-  pixel_rgbs(m, y01, c, x[1], x[5], x[9]);
-  pixel_rgbs(m, y10, c, x[2], x[6], x[10]);
-  pixel_rgbs(m, y11, c, x[3], x[7], x[11]);
-  uint32_t a[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) a[i] = rep_address(r, x[i]);
+  float x[12];  // r0..r3, g0..g3, b0..b3 of the four source pixels, saturated, in x units
+  pixel_rgb_sat(m, y00, c, x[0], x[4], x[8]);
+  pixel_rgb_sat(m, y01, c, x[1], x[5], x[9]);
+  pixel_rgb_sat(m, y10, c, x[2], x[6], x[10]);
+  pixel_rgb_sat(m, y11, c, x[3], x[7], x[11]);
+  uint32_t t[12];
+  magic_floor12(x, t, r.magic);
   float lin[12];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     u32x4 e[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) e[i] = *reinterpret_cast<const u32x4 *>(lds + a[6 * h + i]);
+    for (int i = 0; i < 6; ++i) e[i] = *reinterpret_cast<LdsLinearPtr>((t[6 * h + i] << r.dec_shift) + r.dec_off);
     asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait per batch
 #pragma unroll
     for (int i = 0; i < 6; ++i) lin[6 * h + i] = linear_select(e[i], x[6 * h + i]);
@@ -675,14 +793,14 @@ decode_nv12_half_rep(const DecodeParams p) {
   }
 
   const uint32_t r1 = p.rep_dec_log2, r2 = p.rep_enc_log2;
-  const float S = static_cast<float>(16u << r1);
+  const float inv_n = __uint_as_float(0x7f000000u - __float_as_uint(p.table_scale));  // 1 / N for N = 2^k, no division
   {
     u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
     const u32x4 *src = reinterpret_cast<const u32x4 *>(p.table);
     const uint32_t n = (p.table_bytes / 16) << r1;
     for (uint32_t i = tid; i < n; i += blockDim.x) {
       u32x4 e = src[i >> r1];
-      e.x = __float_as_uint(__fmul_rn(__uint_as_float(e.x), S));  // edge into the S-scaled domain (inf stays inf)
+      e.x = __float_as_uint(__fmul_rn(__uint_as_float(e.x), inv_n));  // edge back into x units (inf stays inf)
       d[i] = e;
     }
     u32x2 *d2 = reinterpret_cast<u32x2 *>(lds_raw + (static_cast<size_t>(p.table_bytes) << r1));
@@ -692,20 +810,17 @@ decode_nv12_half_rep(const DecodeParams p) {
   }
   __syncthreads();
 
+  const uint32_t lds_base =
+      static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)lds_raw));
   RepLookup r;
-  r.dec_max = __fmul_rn(p.table_scale, S);
-  r.dec_mask = ~((16u << r1) - 1u);
-  r.dec_lane = (tid & ((1u << r1) - 1u)) * 16u;
+  r.magic = p.unit_magic;
+  r.dec_shift = 4u + r1;
+  r.dec_off = lds_base + (tid & ((1u << r1) - 1u)) * 16u - (__float_as_uint(r.magic) << r.dec_shift);
   r.enc_shift = 3u + r2;
-  r.enc_lane = (p.table_bytes << r1) + (tid & ((1u << r2) - 1u)) * 8u;
-  Matrix m = matrix_of(p);
-  m.y = __fmul_rn(m.y, S);
-  m.cr_r = __fmul_rn(m.cr_r, S);
-  m.cb_g = __fmul_rn(m.cb_g, S);
-  m.cr_g = __fmul_rn(m.cr_g, S);
-  m.cb_b = __fmul_rn(m.cb_b, S);
+  r.enc_lane = lds_base + (p.table_bytes << r1) + (tid & ((1u << r2) - 1u)) * 8u;
+  const Matrix m = {kMY, kMCrR, kMCbG, kMCrG, kMCbB};
   const float en = p.table2_scale;
-  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset};
+  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset, 127u - (__float_as_uint(p.table2_coarse) >> 23)};
 
   for (; t < p.tile_rows; t += U * G) {
     // next step's loads first: they have this step's arithmetic (and the other waves') to arrive
@@ -770,7 +885,7 @@ decode_nv12_scaled(const DecodeParams p) {
   const FramePlanes f = frame_planes(p, blockIdx.z);
   const Matrix m = matrix_of(p);
   const float en = p.table2_scale, dn = p.table_scale;
-  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset};
+  const SplitIndex es = {p.table2_split, p.table2_coarse, p.table2_offset, 127u - (__float_as_uint(p.table2_coarse) >> 23)};
   const uint32_t oy = blockIdx.y;
   const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
   if (ox >= p.out_width) return;
@@ -816,12 +931,14 @@ decode_nv12_scaled(const DecodeParams p) {
 #define BT709_REP_PREFETCH 2  // tile rows per step of the persistent rescale kernel (loads run one step ahead)
 #endif
 
-const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
+const char *launch_decode(const DecodeParams &p_in, int frames, int variant, bool has_alpha, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
+  DecodeParams p = p_in;
+  p.unit_magic = 8388608.0f / p.table_scale;  // 2^23 / N, exact: N is a power of two
 #if defined(BT709_LAB_LDS_CHROMA)
   const size_t lds = p.table_bytes + 4 * block_threads * kQuadsPerLane;  // + the staged CbCr segment
 #else
-  const size_t lds = p.table_bytes;
+  const size_t lds = (variant == kVariantQuads && BT709_OPT_UNIT) ? p.table_unit_bytes : p.table_bytes;
 #endif
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
@@ -890,6 +1007,7 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
 const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool nontemporal, uint32_t workgroups,
                                    hipStream_t stream) {
   DecodeParams p = p_in;
+  p.unit_magic = 8388608.0f / p.table_scale;  // 2^23 / N, exact
   // copies: as many as fit the CU's LDS, decode side first (12 of the 15 lookups per output pixel)
   uint32_t r1 = 4, r2 = 0;
   while (r1 > 0 && (static_cast<uint64_t>(p.table_bytes) << r1) + p.table2_bytes > kRepLdsBytes) --r1;

@@ -52,6 +52,8 @@ struct bt709hip_decoder {
   void *d_table = nullptr;         // TransferBucket[n+1(+pad)]
   uint32_t table_bytes = 0;
   uint32_t table_n = 0;
+  void *d_table_unit = nullptr;    // TransferBucket[n+1], unscaled edges (fast 1:1 kernel)
+  uint32_t table_unit_bytes = 0;
   void *d_table_linear = nullptr;  // TransferBucketLinear[n+1] (half-scale decode side)
   uint32_t table_linear_bytes = 0;
   void *d_encode = nullptr;        // LINEAR-mode TransferBucket[] (half-scale encode side)
@@ -394,6 +396,7 @@ int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
   if (dec == nullptr) return BT709HIP_OK;
   if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) {
     if (dec->d_table) (void)hipFree(dec->d_table);
+    if (dec->d_table_unit) (void)hipFree(dec->d_table_unit);
     if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
     if (dec->d_encode) (void)hipFree(dec->d_encode);
   }
@@ -440,6 +443,8 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   dec->encode_offset = enc.coarse_offset;
   dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
   if (int rc = upload_table(t.buckets.data(), dec->table_bytes, &dec->d_table)) return rc;
+  dec->table_unit_bytes = static_cast<uint32_t>(t.buckets_unit.size() * sizeof(TransferBucket));
+  if (int rc = upload_table(t.buckets_unit.data(), dec->table_unit_bytes, &dec->d_table_unit)) return rc;
   if (int rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &dec->d_table_linear)) return rc;
   if (int rc = upload_table(enc.buckets.data(), dec->encode_bytes, &dec->d_encode)) return rc;
   dec->ready = true;
@@ -490,6 +495,8 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
   }
   p.table = dec->d_table;
   p.table_bytes = dec->table_bytes;
+  p.table_unit = dec->d_table_unit;
+  p.table_unit_bytes = dec->table_unit_bytes;
   set_matrix(&p, dec->table_n);
   p.width = static_cast<uint32_t>(f0.width);
   p.height = static_cast<uint32_t>(f0.height);

@@ -125,6 +125,8 @@ bool build_transfer_table(int gamma, TransferTable *out) {
     }
     if (!ok) continue;
     out->n = n;
+    out->buckets_unit.assign(b.begin(), b.begin() + n + 1);
+    while ((out->buckets_unit.size() * sizeof(TransferBucket)) % 16 != 0) out->buckets_unit.push_back(TransferBucket{inf, 255u});
     // Scaled domain: the kernels index with xs = N*x, so edges are stored times N (exact,
     // power of two).  Unsaturated inputs reach ~2.15: extend with "answer 255" buckets up to
     // kTableReach*N so that no clamp is needed; negative xs convert to bucket 0.

@@ -59,6 +59,9 @@ struct TransferTable {
   uint32_t unit_entries = 0;             // entries covering x in [0,1] (N + 1, padded to 16 bytes)
   std::vector<TransferBucket> buckets;   // kTableReach * N + 2 entries (+ padding to a 16-byte multiple)
   std::vector<TransferBucketLinear> buckets_linear;  // same buckets, linearised outputs
+  // buckets 0..N with the edge left in x units (the fast kernel saturates x to [0,1] before the
+  // lookup and compares in x units), padded to a 16-byte multiple
+  std::vector<TransferBucket> buckets_unit;
 };
 
 // Scalar transfer functions, float in / float out, C semantics of the reference.

@@ -37,7 +37,7 @@ struct Ring {
   int W, H, ring, batch;
   size_t yb, cb, ob, in_stride, out_stride;
   uint8_t *d_in = nullptr, *d_out = nullptr;
-  void *d_table = nullptr;
+  void *d_table = nullptr, *d_table_unit = nullptr;
   TransferTable tt;
   std::vector<DecodeParams> params;
   hipStream_t s;
@@ -71,6 +71,9 @@ struct Ring {
     const size_t tb = tt.buckets.size() * sizeof(TransferBucket);
     CK(hipMalloc(&d_table, tb));
     CK(hipMemcpy(d_table, tt.buckets.data(), tb, hipMemcpyHostToDevice));
+    const size_t tub = tt.buckets_unit.size() * sizeof(TransferBucket);
+    CK(hipMalloc(&d_table_unit, tub));
+    CK(hipMemcpy(d_table_unit, tt.buckets_unit.data(), tub, hipMemcpyHostToDevice));
     params.resize(ring / batch);
     for (int l = 0; l < ring / batch; ++l) {
       DecodeParams &p = params[l];
@@ -81,6 +84,8 @@ struct Ring {
       }
       p.table = d_table;
       p.table_bytes = uint32_t(tb);
+      p.table_unit = d_table_unit;
+      p.table_unit_bytes = uint32_t(tub);
       p.table_scale = float(tt.n);
       p.m_y = kMY * tt.n; p.m_cr_r = kMCrR * tt.n; p.m_cb_g = kMCbG * tt.n; p.m_cr_g = kMCrG * tt.n; p.m_cb_b = kMCbB * tt.n;
       p.width = W;
