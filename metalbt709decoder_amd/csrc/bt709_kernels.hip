@@ -49,6 +49,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "bt709_constants.h"
 #include "bt709_kernels.h"
@@ -938,7 +939,10 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
 #if defined(BT709_LAB_LDS_CHROMA)
   const size_t lds = p.table_bytes + 4 * block_threads * kQuadsPerLane;  // + the staged CbCr segment
 #else
-  const size_t lds = (variant == kVariantQuads && BT709_OPT_UNIT) ? p.table_unit_bytes : p.table_bytes;
+  size_t lds = (variant == kVariantQuads && BT709_OPT_UNIT) ? p.table_unit_bytes : p.table_bytes;
+#endif
+#if defined(BT709_LAB_LDS_PAD)  // tools/decode_lab only: unused LDS to cap the workgroups resident per CU
+  if (const char *pad = std::getenv("BT709_LAB_LDS_PAD")) lds += static_cast<size_t>(std::atoi(pad)) * 1024;
 #endif
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
