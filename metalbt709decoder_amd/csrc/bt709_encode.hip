@@ -21,8 +21,17 @@
 //     tests/test_encoder.py); operands here are in [-1.1, 1.1], and a zero operand only differs in
 //     the sign of zero, which the following "+ 128" erases.  These two FMAs are the division's own
 //     error-correction steps, not a contracted multiply-add of the reference's expression;
-//   * round() of a positive float v is ((uint)(2v) + 1) >> 1 (floor(v + 1/2) in integers); the
-//     doubling is folded into the constants (power of two: exact).
+//   * round() of a positive float v < 256 is trunc(v + 0.5f), and v + 0.5f is exact there (a sum
+//     that moves into the next binade lands in [2^m, 2^m + 1/2), where rounding cannot reach the
+//     next integer).  v_cvt_pk_u8_f32 converts AND places the byte in its lane of the output word;
+//     it rounds to nearest even by default (so 209 / 193 / 283 of the 2^24 Y / Cb / Cr inputs, the
+//     exact ties, would come out one low) but honours MODE.fp_round (tools/cvt_probe.hip), so the
+//     twelve conversions of a quad sit in one asm statement under round-toward-zero.
+//
+// VALU budget (tools/valu_ops.hip): only v_add/mul/mov_f32 are 2-cycle instructions on gfx950,
+// everything else this kernel uses costs 4, and at 1 Tpixel/s the VALU is ~70 % busy: the byte
+// -> LUT address is one SDWA shift (byte select + << 3, table bases in the ds_read offset field)
+// instead of bfe + shift-add, the split-table index is a min() of the two index functions.
 //
 // A lane owns a 4x2-pixel quad (two blocks): two 16-byte loads, three 4-byte stores; lanes
 // of a wave are consecutive quads of one row pair; grid = (tiles, row-pair groups, frames).  LDS holds
@@ -47,40 +56,60 @@ __device__ __forceinline__ float div_const(float x, float c, float rc) {
   return __fmaf_rn(__fmaf_rn(-c, q0, x), rc, q0);
 }
 
-// (int)round((double)(e * scale + offset)) for a positive result, via the doubled value
-__device__ __forceinline__ uint32_t quant2(float e, float scale2, float offset2) {
-  const uint32_t t2 = static_cast<uint32_t>(__fadd_rn(__fmul_rn(e, scale2), offset2));  // floor(2v)
-  return (t2 + 1u) >> 1;
-}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2 *LdsPairPtr;  // one ds_read_b64, base in the offset field
 
 struct EncodeLds {
-  const EncodeByteEntry *r, *g, *b;
-  const TransferBucket *fl;  // two-resolution table (transfer_tables.h SplitTable)
-  float split, coarse;
-  uint32_t offset;
+  // The per-byte tables sit at LDS address 0 (R), 2048 (G), 4096 (B): these kernels have no static
+  // LDS, so the dynamic segment starts at 0 -- stage_encode_tables traps if that ever changes.
+  uint32_t fl;     // ... of the two-resolution BT709_from_linear table (transfer_tables.h SplitTable)
+  uint32_t offset, coarse_shift;
+  uint32_t three;  // VGPR holding 3: SDWA operands cannot be inline constants
 };
 
-__device__ __forceinline__ uint32_t from_linear(const EncodeLds &t, float xs) {
-  const uint32_t qf = static_cast<uint32_t>(xs);
-  const uint32_t qc = static_cast<uint32_t>(__fmul_rn(xs, t.coarse)) + t.offset;  // exact: power of two
-  const TransferBucket e = t.fl[xs < t.split ? qf : qc];
-  return e.base + (xs >= e.edge ? 1u : 0u);
+// {lin, k_enc} of byte LANE of a BGRA word: v_lshlrev_b32_sdwa selects the byte and scales it to
+// the 8-byte entry in one instruction
+template <int LANE, int TABLE>
+__device__ __forceinline__ u32x2 byte_entry(const EncodeLds &t, uint32_t word) {
+  uint32_t a;
+  if (LANE == 0)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(t.three), "v"(word));
+  else if (LANE == 1)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(t.three), "v"(word));
+  else
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(t.three), "v"(word));
+  return *reinterpret_cast<LdsPairPtr>(a + 2048u * TABLE);  // constant lands in the ds_read offset field
 }
 
-// one 2x2 block: p = {top-left, top-right, bottom-left, bottom-right} BGRA words
-__device__ __forceinline__ void encode_block(const EncodeLds &t, float fl_quarter_n, const uint32_t p[4], uint32_t y[4],
-                                             uint32_t &cb, uint32_t &cr) {
+__device__ __forceinline__ uint32_t from_linear(const EncodeLds &t, float xs) {
+  // fine index below the split, coarse above; the two index functions cross at the split and the
+  // fine one grows faster, so the smaller is the right one
+  const uint32_t qf = static_cast<uint32_t>(xs);
+  const uint32_t q = min(qf, (qf >> t.coarse_shift) + t.offset);
+  const u32x2 e = *reinterpret_cast<LdsPairPtr>((q << 3) + t.fl);
+  return e.y + (xs >= __uint_as_float(e.x) ? 1u : 0u);
+}
+
+// v = e * scale + offset as the reference's float expression, plus the exact 0.5f: trunc(result)
+// is (int)round(v)
+__device__ __forceinline__ float quant_arg(float e, float scale, float offset) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(e, scale), offset), 0.5f);
+}
+
+// one 2x2 block: p = {top-left, top-right, bottom-left, bottom-right} BGRA words;
+// v = {Y tl, Y tr, Y bl, Y br, Cb, Cr} ready for truncation
+__device__ __forceinline__ void encode_block(const EncodeLds &t, float fl_quarter_n, const uint32_t p[4], float v[6]) {
   float sr = 0.f, sg = 0.f, sb = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const EncodeByteEntry r = t.r[(p[i] >> 16) & 0xff];
-    const EncodeByteEntry g = t.g[(p[i] >> 8) & 0xff];
-    const EncodeByteEntry b = t.b[p[i] & 0xff];
-    sr = i ? __fadd_rn(sr, r.lin) : r.lin;
-    sg = i ? __fadd_rn(sg, g.lin) : g.lin;
-    sb = i ? __fadd_rn(sb, b.lin) : b.lin;
-    const float ey = __fadd_rn(__fadd_rn(r.k_enc, g.k_enc), b.k_enc);                 // BT709.h:222
-    y[i] = quant2(ey, 2.0f * static_cast<float>(kYMax - kYMin), 32.0f);               // BT709.h:233, 244
+    const u32x2 r = byte_entry<2, 0>(t, p[i]);
+    const u32x2 g = byte_entry<1, 1>(t, p[i]);
+    const u32x2 b = byte_entry<0, 2>(t, p[i]);
+    sr = i ? __fadd_rn(sr, __uint_as_float(r.x)) : __uint_as_float(r.x);
+    sg = i ? __fadd_rn(sg, __uint_as_float(g.x)) : __uint_as_float(g.x);
+    sb = i ? __fadd_rn(sb, __uint_as_float(b.x)) : __uint_as_float(b.x);
+    const float ey = __fadd_rn(__fadd_rn(__uint_as_float(r.y), __uint_as_float(g.y)), __uint_as_float(b.y));  // BT709.h:222
+    v[i] = quant_arg(ey, static_cast<float>(kYMax - kYMin), 16.0f);                                            // BT709.h:233, 244
   }
   // ave = sum / 4.0f, then scaled into the table's domain: sum * (0.25 * N), both powers of two
   const float rn = __fmul_rn(static_cast<float>(from_linear(t, __fmul_rn(sr, fl_quarter_n))), kInv255);
@@ -89,8 +118,39 @@ __device__ __forceinline__ void encode_block(const EncodeLds &t, float fl_quarte
   const float ey = __fadd_rn(__fadd_rn(__fmul_rn(kKr, rn), __fmul_rn(kKg, gn)), __fmul_rn(kKb, bn));
   const float eb = div_const(__fadd_rn(bn, -ey), kCbSpan, kRcCb);                      // BT709.h:223
   const float er = div_const(__fadd_rn(rn, -ey), kCrSpan, kRcCr);                      // BT709.h:224
-  cb = quant2(eb, 2.0f * static_cast<float>(kCMax - kCMin), 256.0f);                   // BT709.h:234, 245
-  cr = quant2(er, 2.0f * static_cast<float>(kCMax - kCMin), 256.0f);                   // BT709.h:235, 246
+  v[4] = quant_arg(eb, static_cast<float>(kCMax - kCMin), 128.0f);                     // BT709.h:234, 245
+  v[5] = quant_arg(er, static_cast<float>(kCMax - kCMin), 128.0f);                     // BT709.h:235, 246
+}
+
+// Truncate the twelve values of a quad (two blocks) and place them: Y rows top / bottom, CbCr with
+// Cb in the low byte (CVPixelBufferUtils.h:358-361).  One asm statement: the conversions must not
+// be separated from the mode switch around them.
+__device__ __forceinline__ void quantize_quad(const float a[6], const float b[6], uint32_t &ytop, uint32_t &ybot,
+                                              uint32_t &cbcr) {
+  ytop = ybot = cbcr = 0;
+  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_cvt_pk_u8_f32 %0, %3, 0, %0\n\tv_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %5, 0, %1\n\tv_cvt_pk_u8_f32 %1, %6, 1, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %7, 0, %2\n\tv_cvt_pk_u8_f32 %2, %8, 1, %2\n\t"
+      "v_cvt_pk_u8_f32 %0, %9, 2, %0\n\tv_cvt_pk_u8_f32 %0, %10, 3, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %11, 2, %1\n\tv_cvt_pk_u8_f32 %1, %12, 3, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %13, 2, %2\n\tv_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "+v"(ytop), "+v"(ybot), "+v"(cbcr)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+        "v"(b[4]), "v"(b[5]));
+}
+
+// one block (general kernel): bytes 0,1 of each word
+__device__ __forceinline__ void quantize_block(const float a[6], uint32_t &ytop, uint32_t &ybot, uint32_t &cbcr) {
+  ytop = ybot = cbcr = 0;
+  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_cvt_pk_u8_f32 %0, %3, 0, %0\n\tv_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %5, 0, %1\n\tv_cvt_pk_u8_f32 %1, %6, 1, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %7, 0, %2\n\tv_cvt_pk_u8_f32 %2, %8, 1, %2\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "+v"(ytop), "+v"(ybot), "+v"(cbcr)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]));
 }
 
 __device__ __forceinline__ EncodeLds stage_encode_tables(unsigned char *lds_raw, const EncodeParams &p) {
@@ -103,13 +163,13 @@ __device__ __forceinline__ EncodeLds stage_encode_tables(unsigned char *lds_raw,
   // 64-line gathers; the two-resolution table is 6-10 KiB.)
   for (uint32_t i = threadIdx.x; i < nb + nf; i += blockDim.x) d[i] = i < nb ? sb[i] : sf[i - nb];
   EncodeLds t;
-  t.r = reinterpret_cast<const EncodeByteEntry *>(lds_raw);
-  t.g = t.r + 256;
-  t.b = t.r + 512;
-  t.fl = reinterpret_cast<const TransferBucket *>(t.r + 768);
-  t.split = p.from_linear_split;
-  t.coarse = p.from_linear_coarse;
+  if (static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)lds_raw)) != 0u)
+    __builtin_trap();
+  t.fl = 3u * 256u * static_cast<uint32_t>(sizeof(EncodeByteEntry));
   t.offset = p.from_linear_offset;
+  t.coarse_shift = 127u - (__float_as_uint(p.from_linear_coarse) >> 23);  // log2(1 / coarse), coarse = 2^-k
+  t.three = 3u;
+  asm("" : "+v"(t.three));
   return t;
 }
 
@@ -137,44 +197,43 @@ encode_bgra_nv12(const EncodeParams p) {
   const uint32_t rp0 = blockIdx.y * p.row_pairs_per_block;
   const uint32_t rp_end = min(rp0 + p.row_pairs_per_block, row_pairs);
 
-  const uint8_t *s0 = f.bgra + static_cast<size_t>(2 * rp0) * p.bgra_stride + 16 * static_cast<size_t>(q);
-  u32x4 top = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0));
-  u32x4 bot = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0 + p.bgra_stride));
+  // row pointers are uniform (SGPR base), the lane adds a 32-bit offset: no 64-bit VALU address arithmetic
+  const uint8_t *s0 = f.bgra + static_cast<size_t>(2 * rp0) * p.bgra_stride;
+  u32x4 top = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0 + 16u * q));
+  u32x4 bot = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0 + p.bgra_stride + 16u * q));
 
   const EncodeLds t = stage_encode_tables(lds_raw, p);  // after the first loads are in flight
   __syncthreads();
   const float quarter_n = __fmul_rn(0.25f, p.from_linear_scale);
 
   for (uint32_t rp = rp0; rp < rp_end; ++rp) {
-    // prefetch the next row pair (clamped: the last iteration re-reads its own rows) before the arithmetic
-    const uint32_t rn = min(rp + 1, rp_end - 1);
-    const uint8_t *s1 = f.bgra + static_cast<size_t>(2 * rn) * p.bgra_stride + 16 * static_cast<size_t>(q);
-    const u32x4 ntop = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1));
-    const u32x4 nbot = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1 + p.bgra_stride));
+    // prefetch the next row pair before the arithmetic; nothing on the workgroup's last pair (a
+    // clamped re-read of the own rows cost 8 % extra HBM reads at 9 row pairs per workgroup:
+    // non-temporal loads do not stay in L2)
+    u32x4 ntop = top, nbot = bot;
+    if (rp + 1 < rp_end) {
+      const uint8_t *s1 = f.bgra + static_cast<size_t>(2 * (rp + 1)) * p.bgra_stride;
+      ntop = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1 + 16u * q));
+      nbot = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1 + p.bgra_stride + 16u * q));
+    }
 
-    uint32_t ya[4], yb[4], cb0, cr0, cb1, cr1;
+    float va[6], vb[6];
     {
       const uint32_t blk[4] = {top.x, top.y, bot.x, bot.y};
-      uint32_t y4[4];
-      encode_block(t, quarter_n, blk, y4, cb0, cr0);
-      ya[0] = y4[0], ya[1] = y4[1], yb[0] = y4[2], yb[1] = y4[3];
+      encode_block(t, quarter_n, blk, va);
     }
     {
       const uint32_t blk[4] = {top.z, top.w, bot.z, bot.w};
-      uint32_t y4[4];
-      encode_block(t, quarter_n, blk, y4, cb1, cr1);
-      ya[2] = y4[0], ya[3] = y4[1], yb[2] = y4[2], yb[3] = y4[3];
+      encode_block(t, quarter_n, blk, vb);
     }
+    uint32_t ytop, ybot, cbcr;
+    quantize_quad(va, vb, ytop, ybot, cbcr);
     if (q_raw < quads) {
-      uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride + 4 * static_cast<size_t>(q);
-      __builtin_nontemporal_store(ya[0] | (ya[1] << 8) | (ya[2] << 16) | (ya[3] << 24),
-                                  reinterpret_cast<uint32_t *>(y0));
-      __builtin_nontemporal_store(yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24),
-                                  reinterpret_cast<uint32_t *>(y0 + p.y_stride));
-      // Cb low byte, Cr high (CVPixelBufferUtils.h:358-361)
+      uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
+      __builtin_nontemporal_store(ytop, reinterpret_cast<uint32_t *>(y0 + 4u * q));
+      __builtin_nontemporal_store(ybot, reinterpret_cast<uint32_t *>(y0 + p.y_stride + 4u * q));
       __builtin_nontemporal_store(
-          cb0 | (cr0 << 8) | (cb1 << 16) | (cr1 << 24),
-          reinterpret_cast<uint32_t *>(f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride + 4 * static_cast<size_t>(q)));
+          cbcr, reinterpret_cast<uint32_t *>(f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride + 4u * q));
     }
     top = ntop;
     bot = nbot;
@@ -195,17 +254,19 @@ encode_bgra_nv12_blocks(const EncodeParams p) {
     const uint32_t *r0 = reinterpret_cast<const uint32_t *>(f.bgra + static_cast<size_t>(2 * rp) * p.bgra_stride);
     const uint32_t *r1 = reinterpret_cast<const uint32_t *>(f.bgra + static_cast<size_t>(2 * rp + 1) * p.bgra_stride);
     const uint32_t blk[4] = {r0[2 * bx], r0[2 * bx + 1], r1[2 * bx], r1[2 * bx + 1]};
-    uint32_t y4[4], cb, cr;
-    encode_block(t, quarter_n, blk, y4, cb, cr);
+    float v[6];
+    encode_block(t, quarter_n, blk, v);
+    uint32_t ytop, ybot, cbcr;
+    quantize_block(v, ytop, ybot, cbcr);
     uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
     uint8_t *y1 = y0 + p.y_stride;
     uint8_t *c = f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride;
-    y0[2 * bx] = static_cast<uint8_t>(y4[0]);
-    y0[2 * bx + 1] = static_cast<uint8_t>(y4[1]);
-    y1[2 * bx] = static_cast<uint8_t>(y4[2]);
-    y1[2 * bx + 1] = static_cast<uint8_t>(y4[3]);
-    c[2 * bx] = static_cast<uint8_t>(cb);
-    c[2 * bx + 1] = static_cast<uint8_t>(cr);
+    y0[2 * bx] = static_cast<uint8_t>(ytop);
+    y0[2 * bx + 1] = static_cast<uint8_t>(ytop >> 8);
+    y1[2 * bx] = static_cast<uint8_t>(ybot);
+    y1[2 * bx + 1] = static_cast<uint8_t>(ybot >> 8);
+    c[2 * bx] = static_cast<uint8_t>(cbcr);
+    c[2 * bx + 1] = static_cast<uint8_t>(cbcr >> 8);
   }
 }
 
