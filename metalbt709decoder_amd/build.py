@@ -14,9 +14,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbt709hip.so")
-ASM = os.path.join(HERE, "build", "bt709_kernels.s")
-SOURCES = ["bt709_kernels.hip", "bt709_encode.hip", "bt709_planes.hip", "bt709hip.cpp", "transfer_tables.cpp"]
-HEADERS = ["bt709_kernels.h", "bt709_constants.h", "transfer_tables.h"]
+ASM = os.path.join(HERE, "build", "bt709_kernels.s")  # decode + rescale + encode kernels, concatenated
+SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_encode.hip", "bt709_planes.hip", "bt709hip.cpp",
+           "transfer_tables.cpp"]
+KERNEL_SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_encode.hip"]
+HEADERS = ["bt709_kernels.h", "bt709_device.h", "bt709_constants.h", "transfer_tables.h"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: hipcc otherwise pairs scalar f32 multiplies/adds into v_pk_* ops, which run
 # at half rate on gfx950 and need v_mov shuffles to build their operand pairs (measured: 458 VALU
@@ -65,11 +67,19 @@ def emit_asm(force=False):
     if not force and os.path.exists(ASM) and not is_stale(ASM):
         return ASM
     os.makedirs(os.path.dirname(ASM), exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, *[f for f in FLAGS if f != "-fPIC"], "-S",
-           "--cuda-device-only", os.path.join(CSRC, "bt709_kernels.hip"), "-o", ASM]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc -S failed:\n" + r.stdout + r.stderr)
+    parts = []
+    for src in KERNEL_SOURCES:
+        out = ASM + "." + src
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, *[f for f in FLAGS if f != "-fPIC"], "-S",
+               "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc -S failed:\n" + r.stdout + r.stderr)
+        parts.append(open(out).read())
+        os.remove(out)
+    with open(ASM + ".tmp", "w") as f:
+        f.write("\n".join(parts))
+    os.replace(ASM + ".tmp", ASM)
     return ASM
 
 

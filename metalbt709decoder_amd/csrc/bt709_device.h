@@ -1,0 +1,182 @@
+// Device-side building blocks shared by the decode (bt709_kernels.hip) and the fused
+// decode + rescale kernels (bt709_rescale.hip).  gfx950 only.
+//
+// Arithmetic follows the reference's CPU path (Renderer/BT709.h:466-513, 348-460, 821-908),
+// which is what the 8-bit output is checked against:
+//
+//   Yn  = (Y  -  16) * (1/255f)          BT709.h:494
+//   Cbn = (Cb - 128) * (1/255f)          BT709.h:499
+//   Crn = (Cr - 128) * (1/255f)          BT709.h:500
+//   R = ((Yn*My) + (Cbn*0))     + (Crn*Mcr_r)      BT709.h:424
+//   G = ((Yn*My) + (Cbn*Mcb_g)) + (Crn*Mcr_g)      BT709.h:425
+//   B = ((Yn*My) + (Cbn*Mcb_b)) + (Crn*0)          BT709.h:426
+//   saturate, transfer curve(s), (int)round(v*255f)  BT709.h:444-446, 856-883
+//
+// Adding the +-0 products of the zero matrix entries never changes a sum's value (only possibly
+// the sign of an exact zero, which saturates to the same bucket), so they are not computed.
+// Every multiply and add is a separate IEEE binary32 operation: the files are compiled with
+// -ffp-contract=off and the arithmetic goes through __fmul_rn/__fadd_rn so no FMA can form (a
+// CPU test greps the ISA).
+//
+// VALU BUDGET (tools/valu_ops.hip, waves of 64): v_add_f32, v_mul_f32 and v_mov_b32 occupy a
+// SIMD for 2 cycles; every other VALU instruction these kernels use -- converts, compares,
+// selects, integer and bit operations, SDWA forms -- for 4.  The 1:1 kernel runs the VALU ~60 %
+// busy at 6 TB/s and the rescale kernels are VALU-bound outright, so the helpers below are
+// written by cycle count:
+//   * byte -> float is v_cvt_f32_ubyteN (4) and the centring a float add (2); left alone, hipcc
+//     rewrites (float)(byte) - 16.0f as an integer SDWA add plus v_cvt_f32_i32 (4 + 4);
+//   * R, G, B are saturated for free by the clamp bit of the add that produces them;
+//   * the bucket index of a saturated x is ONE 2-cycle add (magic_floor12) instead of a 4-cycle
+//     convert: with M = 2^23 / N a float in [M, 2M) has ulp 1/N, so x + M rounded TOWARD ZERO is
+//     M + floor(x N) / N and its bit pattern is bits(M) + floor(x N); a v_lshl_add_u32 turns
+//     that into the LDS byte address (its addend cancels bits(M) << shift).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bt709_constants.h"
+#include "bt709_kernels.h"
+
+namespace bt709 {
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// LDS reads through integer byte addresses (address space 3): no base-pointer add per lookup
+typedef __attribute__((address_space(3))) const u32x2 *LdsPairPtr;  // ds_read_b64
+typedef __attribute__((address_space(3))) const u32x4 *LdsQuadPtr;  // ds_read_b128
+
+__device__ __forceinline__ uint32_t lds_address(const void *p) {
+  return static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const unsigned char *)p));
+}
+
+__device__ __forceinline__ float byte_of(uint32_t w, int i) {
+  float f = static_cast<float>((w >> (8 * i)) & 0xffu);  // v_cvt_f32_ubyte{i}
+  asm("" : "+v"(f));  // opaque: keeps the centring a float add (see VALU BUDGET)
+  return f;
+}
+
+__device__ __forceinline__ float byte_value(uint8_t b) {
+  float f = static_cast<float>(b);
+  asm("" : "+v"(f));
+  return f;
+}
+
+// (v - off) * (1/255f): integer-valued floats subtract exactly, so this equals the
+// reference's int subtract followed by int->float conversion.
+__device__ __forceinline__ float centre_norm(float v, float off) {
+  return __fmul_rn(__fadd_rn(v, -off), kInv255);
+}
+
+// a + b saturated to [0, 1] (BT709.h:444-446 `saturatef`) by the add's own clamp bit
+__device__ __forceinline__ float add_sat(float a, float b) {
+  float r;
+  asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+struct Chroma {  // the four Cb/Cr products of one 2x2 block (BT709.h:389-397 matrix entries)
+  float cr_r, cb_g, cr_g, cb_b;
+};
+
+__device__ __forceinline__ Chroma chroma_terms(float cb, float cr) {
+  const float cbn = centre_norm(cb, 128.0f);
+  const float crn = centre_norm(cr, 128.0f);
+  Chroma c;
+  c.cr_r = __fmul_rn(crn, kMCrR);
+  c.cb_g = __fmul_rn(cbn, kMCbG);
+  c.cr_g = __fmul_rn(crn, kMCrG);
+  c.cb_b = __fmul_rn(cbn, kMCbB);
+  return c;
+}
+
+// saturated non-linear R, G, B of one pixel: exactly the reference's floats
+__device__ __forceinline__ void pixel_rgb(float ybyte, const Chroma &c, float &r, float &g, float &b) {
+  const float yv = __fmul_rn(centre_norm(ybyte, 16.0f), kMY);
+  r = add_sat(yv, c.cr_r);
+  g = add_sat(__fadd_rn(yv, c.cb_g), c.cr_g);
+  b = add_sat(yv, c.cb_b);
+}
+
+// linear alpha sample: the luma term alone (AAPLShaders.metal:249-271; CPU twin BT709.h:466-513)
+__device__ __forceinline__ float alpha_value(float abyte) {
+  return add_sat(__fmul_rn(centre_norm(abyte, 16.0f), kMY), 0.0f);
+}
+
+// t[i] = bits(x[i] + magic) with the add rounded toward zero, for x in [0, 1]: bits(magic) +
+// floor(x N).  One asm statement, so nothing can be scheduled between the two writes of
+// MODE.fp_round's single-precision field (everything else rounds to nearest even); 12 values
+// because an asm statement takes at most 30 operands.
+__device__ __forceinline__ void magic_floor12(const float *x, uint32_t *t, float magic) {
+  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_add_f32 %0, %24, %12\n\tv_add_f32 %1, %24, %13\n\tv_add_f32 %2, %24, %14\n\tv_add_f32 %3, %24, %15\n\t"
+      "v_add_f32 %4, %24, %16\n\tv_add_f32 %5, %24, %17\n\tv_add_f32 %6, %24, %18\n\tv_add_f32 %7, %24, %19\n\t"
+      "v_add_f32 %8, %24, %20\n\tv_add_f32 %9, %24, %21\n\tv_add_f32 %10, %24, %22\n\tv_add_f32 %11, %24, %23\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+        "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
+        "v"(x[10]), "v"(x[11]), "s"(magic));
+}
+
+__device__ __forceinline__ void magic_floor4(const float *x, uint32_t *t, float magic) {
+  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_add_f32 %0, %8, %4\n\tv_add_f32 %1, %8, %5\n\tv_add_f32 %2, %8, %6\n\tv_add_f32 %3, %8, %7\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(magic));
+}
+
+// (A<<24)|(R<<16)|(G<<8)|B in two VALU ops: v_perm_b32 places R and G (bytes 2 and 1, zeros
+// elsewhere), v_or3_b32 merges B and the alpha word.  (Writing each byte straight into its lane
+// with an SDWA v_addc, no pack at all, measured 1 % slower.)
+__device__ __forceinline__ uint32_t pack_bgra(uint32_t R, uint32_t G, uint32_t B, uint32_t alpha_word) {
+  // selector bytes, MSB first: 0x0c -> 0x00, 0x04 -> byte 0 of the first operand (R),
+  // 0x00 -> byte 0 of the second operand (G), 0x0c -> 0x00
+  const uint32_t rg = __builtin_amdgcn_perm(R, G, 0x0c04000cu);
+  return rg | B | alpha_word;
+}
+
+__device__ __forceinline__ void stage_table(void *lds, const void *src, uint32_t bytes) {
+  u32x4 *d = reinterpret_cast<u32x4 *>(lds);
+  const u32x4 *s = reinterpret_cast<const u32x4 *>(src);
+  const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
+  for (uint32_t i = tid; i < bytes / 16; i += nthreads) d[i] = s[i];
+}
+
+// Frame bytes are touched exactly once: stream them past the caches (measured +1.3 % on 4K)
+template <bool NT>
+__device__ __forceinline__ uint32_t load32(const uint8_t *p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
+  return *reinterpret_cast<const uint32_t *>(p);
+}
+
+template <bool NT>
+__device__ __forceinline__ void store16(uint8_t *p, u32x4 v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+  else *reinterpret_cast<u32x4 *>(p) = v;
+}
+
+template <bool NT>
+__device__ __forceinline__ void store8(uint8_t *p, u32x2 v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p));
+  else *reinterpret_cast<u32x2 *>(p) = v;
+}
+
+// Frame i of the launch: from the kernarg table, or -- when the caller's frames are evenly
+// spaced in memory (a ring / pool) -- frame 0 plus i times the spacing, which lifts the
+// 32-frame limit of the table.
+__device__ __forceinline__ FramePlanes frame_planes(const DecodeParams &p, uint32_t i) {
+  if (!p.uniform) return p.frames[i];
+  FramePlanes f = p.frames[0];
+  f.y += static_cast<int64_t>(i) * p.step_y;
+  f.cbcr += static_cast<int64_t>(i) * p.step_cbcr;
+  if (f.alpha) f.alpha += static_cast<int64_t>(i) * p.step_alpha;
+  f.out += static_cast<int64_t>(i) * p.step_out;
+  return f;
+}
+
+}  // namespace
+}  // namespace bt709

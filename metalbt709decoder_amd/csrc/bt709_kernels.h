@@ -34,22 +34,21 @@ struct FramePlanes {
   uint8_t *out;
 };
 
-// Passed by value in the kernarg segment (32 frames x 32 B + 64 B).
+// Passed by value in the kernarg segment (32 frames x 32 B + ~150 B).
 struct DecodeParams {
   FramePlanes frames[kMaxBatch];
-  const void *table;   // TransferBucket[] (decode) or TransferBucketLinear[] (half)
-  const void *table_unit;  // fast 1:1 kernel: TransferBucket[N + 1], edges NOT scaled (transfer_tables.h buckets_unit)
+  // decode kernels: TransferBucket[N + 1], edges in x units (transfer_tables.h buckets_unit)
+  const void *table_unit;
+  // rescale kernels: TransferBucketLinear[N + 1] (edges in x units) and the two-resolution
+  // sRGB-encode table (transfer_tables.h SplitTable): q = min(qf, (qf >> encode_shift) + encode_offset)
+  const void *table_linear;
+  const void *table_encode;
   uint32_t table_unit_bytes;
-  float unit_magic;        // 2^23 / N (filled by launch_decode): floats in [M, 2M) have ulp 1/N
-  const void *table2;  // half only: two-resolution sRGB-encode table (transfer_tables.h SplitTable)
-  uint32_t table_bytes;
-  uint32_t table2_bytes;
-  float table_scale;   // N of `table`
-  float table2_scale;  // n_fine of `table2`
-  float table2_split, table2_coarse;  // SplitTable index parameters of `table2`
-  uint32_t table2_offset;
-  // BT709.h:389-397 matrix entries times table_scale (exact: power-of-two scaling)
-  float m_y, m_cr_r, m_cb_g, m_cr_g, m_cb_b;
+  uint32_t table_linear_bytes;
+  uint32_t table_encode_bytes;
+  float encode_scale;  // n_fine of table_encode
+  uint32_t encode_offset, encode_shift;
+  float unit_magic;    // 2^23 / N: floats in [M, 2M) have ulp 1/N (bt709_device.h magic_floor12)
   uint32_t width;      // luma (source) dimensions
   uint32_t height;
   uint32_t y_stride;
@@ -63,10 +62,11 @@ struct DecodeParams {
   // uniform != 0: frame i = frames[0] + i * step_* (bytes); lets one launch cover any number of frames
   uint32_t uniform;
   int64_t step_y, step_cbcr, step_alpha, step_out;
-  // decode_nv12_half_rep only (persistent workgroups, replicated LDS tables): `table` is held in
-  // 2^rep_dec_log2 interleaved copies (<= 16: one per lane of a ds_read_b128 lane group), `table2` in
-  // 2^rep_enc_log2; a tile row is one tile of one row pair of one frame, tile_rows of them in the
-  // launch, walked gridDim.x at a time; cursor_* = gridDim.x decomposed into (tiles, row pairs, frames).
+  // decode_nv12_half_rep only (persistent workgroups, replicated LDS tables): table_linear is held
+  // in 2^rep_dec_log2 interleaved copies (<= 16: one per lane of a ds_read_b128 lane group),
+  // table_encode in 2^rep_enc_log2; a tile row is one tile of one row pair of one frame, tile_rows
+  // of them in the launch, walked gridDim.x at a time; cursor_* = gridDim.x decomposed into
+  // (tiles, row pairs, frames).  Filled by launch_decode_half_rep.
   uint32_t rep_dec_log2, rep_enc_log2;
   uint32_t tiles_x, tile_rows;
   uint32_t cursor_tx, cursor_rp, cursor_f;
@@ -171,7 +171,8 @@ inline uint32_t quads_rows_per_block(uint32_t block_threads, uint32_t tiles) {
   return by < 1 ? 1 : by;
 }
 
-// Raises the dynamic-LDS cap of the kernels (tables can exceed the 64 KiB default).
-hipError_t prepare_kernels();
+// Raise the dynamic-LDS cap of the kernels (tables can exceed the 64 KiB default).
+hipError_t prepare_kernels();          // bt709_kernels.hip
+hipError_t prepare_rescale_kernels();  // bt709_rescale.hip
 
 }  // namespace bt709

@@ -1,0 +1,440 @@
+// CDNA4 (gfx950) kernels of the FUSED decode + rescale: what the reference does in two Metal
+// passes -- BT709ToLinearSRGBKernel into an sRGB8 intermediate (Renderer/AAPLShaders.metal:
+// 336-407), then MetalScaleRenderContext -renderScaled: / samplingShader (73-85) when the view
+// is smaller than the frame -- is ONE kernel here: the 132.7 MB 8K intermediate is never written.
+//
+// Two-pass-equivalent arithmetic ("rescale"; the reference has no CPU twin of pass 2,
+// so parity is against the oracle's restatement of this definition): each source pixel is
+// decoded to its 8-bit sRGB value and linearised as the sRGB8 sampler would -- the decode-side
+// table returns that linear float directly, {edge, lin(base), lin(base + 1)} in one 16-byte
+// bucket -- the taps are combined in linear light, and the result is sRGB-encoded and quantised
+// through the LINEAR-mode composite, held as a two-resolution bucket table (transfer_tables.h
+// SplitTable).
+//
+// All three kernels are VALU-bound (12 decode-side + 3 encode-side lookups per output pixel), so
+// everything is counted in cycles (bt709_device.h, VALU BUDGET): per decode-side lookup
+// 2 (saturating add) + 2 (magic add) + 4 (address) + 4 + 4 (compare, select).
+//
+//   decode_nv12_half       exact 2:1, one short-lived workgroup per tile of an output row
+//   decode_nv12_half_rep   exact 2:1, persistent workgroups, bank-conflict-free LDS tables
+//   decode_nv12_scaled     any output size, bilinear taps, one lane per output pixel
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bt709_device.h"
+
+namespace bt709 {
+namespace {
+
+// LDS image of the two tables and the constants of a lookup.  Entry q of copy c of the decode
+// side sits at byte (q * R + c) * 16 (R = 2^r1 copies), of the encode side at (q * R2 + c) * 8
+// behind it; a lane reads copy lane & (R - 1).
+struct RescaleLookup {
+  float magic;         // 2^23 / N: bits(x + magic), rounded toward zero, = bits(magic) + floor(x N)
+  uint32_t dec_shift;  // log2(16 R)
+  uint32_t dec_off;    // LDS address + lane's copy offset - (bits(magic) << dec_shift)
+  uint32_t enc_shift;  // log2(8 R2)
+  uint32_t enc_off;    // LDS address of the encode table + lane's copy offset
+  uint32_t split_offset, split_shift;  // SplitTable: q = min(qf, (qf >> shift) + offset)
+  float quarter_scale;  // 0.25 * n_fine of the encode table
+  float scale;          // n_fine
+};
+
+// Stages both tables in 2^r1 / 2^r2 interleaved copies (0 / 0: plain) and returns the lookup
+// constants of this lane.  The caller synchronises.
+__device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds_raw, const DecodeParams &p, uint32_t r1,
+                                                              uint32_t r2) {
+  const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
+  u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
+  const u32x4 *src = reinterpret_cast<const u32x4 *>(p.table_linear);
+  const uint32_t n = (p.table_linear_bytes / 16) << r1;
+  for (uint32_t i = tid; i < n; i += nthreads) d[i] = src[i >> r1];
+  const uint32_t dec_bytes = p.table_linear_bytes << r1;
+  u32x2 *d2 = reinterpret_cast<u32x2 *>(lds_raw + dec_bytes);
+  const u32x2 *src2 = reinterpret_cast<const u32x2 *>(p.table_encode);
+  const uint32_t n2 = (p.table_encode_bytes / 8) << r2;
+  for (uint32_t i = tid; i < n2; i += nthreads) d2[i] = src2[i >> r2];
+
+  const uint32_t base = lds_address(lds_raw);
+  RescaleLookup r;
+  r.magic = p.unit_magic;
+  r.dec_shift = 4u + r1;
+  r.dec_off = base + (tid & ((1u << r1) - 1u)) * 16u - (__float_as_uint(r.magic) << r.dec_shift);
+  r.enc_shift = 3u + r2;
+  r.enc_off = base + dec_bytes + (tid & ((1u << r2) - 1u)) * 8u;
+  r.split_offset = p.encode_offset;
+  r.split_shift = p.encode_shift;
+  r.scale = p.encode_scale;
+  r.quarter_scale = __fmul_rn(0.25f, p.encode_scale);
+  return r;
+}
+
+// sRGB byte of a linear value scaled into the encode table's domain (xs = v * n_fine)
+__device__ __forceinline__ uint32_t encode_byte(const RescaleLookup &r, float xs) {
+  // fine index below the split, coarse above: the two index functions cross exactly at the split
+  // and the fine one grows faster, so the smaller one is always the right one
+  const uint32_t qf = static_cast<uint32_t>(xs);
+  const uint32_t q = min(qf, (qf >> r.split_shift) + r.split_offset);
+  const u32x2 e = *reinterpret_cast<LdsPairPtr>((q << r.enc_shift) + r.enc_off);
+  return e.y + (xs >= __uint_as_float(e.x) ? 1u : 0u);
+}
+
+// linear-light values of 12 saturated channel values: 6 buckets in flight per wait
+__device__ __forceinline__ void linearise12(const RescaleLookup &r, const float *x, float *lin) {
+  uint32_t t[12];
+  magic_floor12(x, t, r.magic);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u32x4 e[6];  // {edge, lin(base), lin(base + 1), base}: whole vectors keep the read a ds_read_b128
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[i] = *reinterpret_cast<LdsQuadPtr>((t[6 * h + i] << r.dec_shift) + r.dec_off);
+    asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait per batch
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      lin[6 * h + i] = x[6 * h + i] >= __uint_as_float(e[i].x) ? __uint_as_float(e[i].z) : __uint_as_float(e[i].y);
+  }
+}
+
+// One output pixel of the exact 2:1 rescale: the four source pixels of a 2x2 block share one
+// CbCr sample; (((a+b)+c)+d) * 0.25f per channel.
+__device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, float y01, float y10, float y11,
+                                            const Chroma &c, uint32_t alpha_word) {
+  float x[12];  // r0..r3, g0..g3, b0..b3
+  pixel_rgb(y00, c, x[0], x[4], x[8]);
+  pixel_rgb(y01, c, x[1], x[5], x[9]);
+  pixel_rgb(y10, c, x[2], x[6], x[10]);
+  pixel_rgb(y11, c, x[3], x[7], x[11]);
+  float lin[12];
+  linearise12(r, x, lin);
+  const float *lr = lin, *lg = lin + 4, *lb = lin + 8;
+  // the average and the scaling into the encode table's domain are both exact powers of two
+  const float mr = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]), r.quarter_scale);
+  const float mg = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]), r.quarter_scale);
+  const float mb = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]), r.quarter_scale);
+  return pack_bgra(encode_byte(r, mr), encode_byte(r, mg), encode_byte(r, mb), alpha_word);
+}
+
+// the two output pixels of a quad (4x2 source pixels)
+__device__ __forceinline__ u32x2 half_quad(const RescaleLookup &r, uint32_t ya, uint32_t yb, uint32_t cw,
+                                           uint32_t alpha_word) {
+  const Chroma c0 = chroma_terms(byte_of(cw, 0), byte_of(cw, 1));
+  const Chroma c1 = chroma_terms(byte_of(cw, 2), byte_of(cw, 3));
+  u32x2 v;
+  v.x = half_px(r, byte_of(ya, 0), byte_of(ya, 1), byte_of(yb, 0), byte_of(yb, 1), c0, alpha_word);
+  v.y = half_px(r, byte_of(ya, 2), byte_of(ya, 3), byte_of(yb, 2), byte_of(yb, 3), c1, alpha_word);
+  return v;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Exact 2:1, one workgroup per tile of an output row (small launches, any layout).
+// WIDE: a lane owns quads = 4x2 source pixels = 2 output pixels (two dword luma loads, one
+// dword CbCr load, one 8-byte store); grid = (tiles, H/2, frames) as in the 1:1 kernel.
+// Preconditions: width % 4 == 0, planes/strides 4-byte aligned, output 8-byte aligned.
+// !WIDE: one lane per output pixel, byte loads, any layout.
+// ---------------------------------------------------------------------------
+template <bool NT, bool WIDE>
+__global__ void __launch_bounds__(kMaxBlockThreads)
+decode_nv12_half(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const FramePlanes f = frame_planes(p, blockIdx.z);
+  const uint32_t out_rows = p.height >> 1;
+  const uint32_t orow_raw = blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform
+  const uint32_t orow = min(orow_raw, out_rows - 1);
+  const uint8_t *y0 = f.y + static_cast<size_t>(2 * orow) * p.y_stride;
+  const uint8_t *y1 = y0 + p.y_stride;
+  const uint8_t *cc = f.cbcr + static_cast<size_t>(orow) * p.cbcr_stride;
+  uint8_t *o = f.out + static_cast<size_t>(orow) * p.out_stride;
+
+  if (WIDE) {
+    constexpr int UNROLL = kQuadsPerLane;
+    const uint32_t quads = p.width >> 2;
+    const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
+    uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t q = min(q0 + u * blockDim.x, quads - 1);  // clamped load, predicated store (see 1:1 kernel)
+      ya[u] = load32<NT>(y0 + 4 * q);
+      yb[u] = load32<NT>(y1 + 4 * q);
+      cw[u] = load32<NT>(cc + 4 * q);
+    }
+    const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);  // after the tile's loads are in flight
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("" : "+v"(ya[u]), "+v"(yb[u]), "+v"(cw[u]));  // see 1:1 kernel
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t q = q0 + u * blockDim.x;
+      const u32x2 v = half_quad(r, ya[u], yb[u], cw[u], p.alpha_word);
+      if (q < quads && orow_raw < out_rows) store8<NT>(o + 8 * q, v);
+    }
+  } else {
+    const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);
+    __syncthreads();
+    const uint32_t out_w = p.width >> 1;
+    for (uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x; ox < out_w && orow_raw < out_rows;
+         ox += gridDim.x * blockDim.x) {
+      const Chroma c = chroma_terms(byte_value(cc[2 * ox]), byte_value(cc[2 * ox + 1]));
+      reinterpret_cast<uint32_t *>(o)[ox] = half_px(r, byte_value(y0[2 * ox]), byte_value(y0[2 * ox + 1]),
+                                                    byte_value(y1[2 * ox]), byte_value(y1[2 * ox + 1]), c, p.alpha_word);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Exact 2:1, CONFLICT-FREE form for large launches: same arithmetic, same bytes out.  On random
+// content a bucket lookup from a single LDS copy of the table costs ~2.4x its conflict-free
+// cycles.  Here the decode-side table sits in LDS in R = 16 interleaved copies and lane l reads
+// copy l & 15: the 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...:
+// MI355X_MICROARCH.md, LDS) then hit 16 different 16-byte bank groups whatever their q, so each
+// lookup costs its 4 LDS cycles and no more.  The encode table gets the copies that still fit (4
+// for the default gamma: 131 + 24 KiB of the CU's 160).  One workgroup per CU can hold that, so
+// workgroups are PERSISTENT: the tables are staged once per launch, then workgroup w walks tile
+// rows w, w + G, w + 2G, ... (G = gridDim.x; at any moment the CUs work on neighbouring row
+// pairs, i.e. the DRAM stream stays address-ordered).  A tile row = blockDim.x quads of one row
+// pair; the cursor (tile, row pair, frame) advances by G decomposed on the host: no division in
+// the loop.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct TileCursor {
+  uint32_t tx, rp, f;
+};
+
+struct QuadIn {
+  uint32_t ya, yb, cw;
+};
+
+__device__ __forceinline__ void advance(TileCursor &c, const DecodeParams &p, uint32_t row_pairs) {
+  c.tx += p.cursor_tx;  // < tiles_x
+  c.rp += p.cursor_rp;  // < row_pairs
+  c.f += p.cursor_f;
+  if (c.tx >= p.tiles_x) {
+    c.tx -= p.tiles_x;
+    ++c.rp;
+  }
+  if (c.rp >= row_pairs) {
+    c.rp -= row_pairs;
+    ++c.f;
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ QuadIn load_quad(const DecodeParams &p, const TileCursor &c, uint32_t quads) {
+  const FramePlanes f = frame_planes(p, c.f);
+  const uint8_t *y0 = f.y + static_cast<size_t>(2 * c.rp) * p.y_stride;
+  const uint8_t *cc = f.cbcr + static_cast<size_t>(c.rp) * p.cbcr_stride;
+  const uint32_t q = min(c.tx * blockDim.x + threadIdx.x, quads - 1);  // clamped: see the store
+  QuadIn in;
+  in.ya = load32<NT>(y0 + 4 * q);
+  in.yb = load32<NT>(y0 + p.y_stride + 4 * q);
+  in.cw = load32<NT>(cc + 4 * q);
+  return in;
+}
+
+}  // namespace
+
+template <bool NT, int U>
+__global__ void __launch_bounds__(kRepBlockThreads)
+decode_nv12_half_rep(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const uint32_t row_pairs = p.height >> 1, quads = p.width >> 2;
+  const uint32_t G = gridDim.x;
+
+  uint32_t t = blockIdx.x;  // < tile_rows (the launcher never starts more workgroups than tile rows)
+  TileCursor pre;
+  pre.tx = t % p.tiles_x;
+  pre.rp = (t / p.tiles_x) % row_pairs;
+  pre.f = (t / p.tiles_x) / row_pairs;
+  TileCursor cur = pre;
+
+  // A step is U tile rows t, t + G, ...: their loads are issued one whole step ahead (first ones:
+  // before the tables are staged).  Past the end of the launch a slot repeats the step's first tile
+  // row -- same loads, same result, same store -- so every step is exactly 3U loads and U stores
+  // and the in-order vmcnt hipcc derives never has to cover a shorter path.
+  QuadIn in[U];
+  {
+    const TileCursor first = pre;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool have = t + u * G < p.tile_rows;
+      const TileCursor c = {have ? pre.tx : first.tx, have ? pre.rp : first.rp, have ? pre.f : first.f};
+      in[u] = load_quad<NT>(p, c, quads);
+      advance(pre, p, row_pairs);
+    }
+  }
+
+  const RescaleLookup r = stage_rescale_tables(lds_raw, p, p.rep_dec_log2, p.rep_enc_log2);
+  __syncthreads();
+
+  for (; t < p.tile_rows; t += U * G) {
+    // next step's loads first: they have this step's arithmetic (and the other waves') to arrive
+    QuadIn nx[U];
+    {
+      const TileCursor first = pre;  // valid or not: only dereferenced when t + U * G < tile_rows
+      const bool any = t + U * G < p.tile_rows;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool have = t + (U + u) * G < p.tile_rows;
+        const TileCursor a = have ? pre : first;
+        const TileCursor c = {any ? a.tx : cur.tx, any ? a.rp : cur.rp, any ? a.f : cur.f};
+        nx[u] = load_quad<NT>(p, c, quads);
+        advance(pre, p, row_pairs);
+      }
+    }
+    const TileCursor first = cur;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool have = t + u * G < p.tile_rows;
+      const TileCursor c = {have ? cur.tx : first.tx, have ? cur.rp : first.rp, have ? cur.f : first.f};
+      const u32x2 v = half_quad(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word);
+      const FramePlanes f = frame_planes(p, c.f);
+      uint8_t *o = f.out + static_cast<size_t>(c.rp) * p.out_stride;
+      // lanes past the row's end loaded the last quad (clamp), hold its result and store it again
+      const uint32_t q = min(c.tx * blockDim.x + threadIdx.x, quads - 1);
+      store8<NT>(o + 8 * q, v);
+      advance(cur, p, row_pairs);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) in[u] = nx[u];  // hipcc waits here for the loads issued at the top (not for the stores)
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused decode + bilinear rescale to ANY output size (MetalScaleRenderContext -renderScaled:
+// for a view that is not an exact 2:1 of the frame).  Definition (ours: the reference leaves it
+// to the sampler hardware):
+//   sx = (ox + 0.5f) * (W / OW) - 0.5f,  x0 = floor(sx), fx = sx - x0, taps clamped to the edge
+//   (same in y); each tap is decoded to its 8-bit sRGB value and linearised as the sRGB8 sampler
+//   does; v = (((w00*l00 + w01*l01) + w10*l10) + w11*l11) with w00 = (1-fx)(1-fy), ...;
+//   sRGB-encode, quantise.  For an exact 2:1 ratio every weight is 0.25 and this is bit for bit
+//   the decode_nv12_half result.
+// One lane per output pixel, byte gathers (cached), 4-byte coalesced stores; grid =
+// (ceil(OW / blockDim), OH, frames).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlockThreads)
+decode_nv12_scaled(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);
+  __syncthreads();
+
+  const FramePlanes f = frame_planes(p, blockIdx.z);
+  const uint32_t oy = blockIdx.y;
+  const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ox >= p.out_width) return;
+
+  const float sx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ox), 0.5f), p.scale_x), -0.5f);
+  const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy), 0.5f), p.scale_y), -0.5f);
+  const float x0f = __builtin_floorf(sx), y0f = __builtin_floorf(sy);
+  const float fx = __fadd_rn(sx, -x0f), fy = __fadd_rn(sy, -y0f);
+  const int wmax = static_cast<int>(p.width) - 1, hmax = static_cast<int>(p.height) - 1;
+  const int xi = static_cast<int>(x0f), yi = static_cast<int>(y0f);
+  const int xs[2] = {min(max(xi, 0), wmax), min(max(xi + 1, 0), wmax)};
+  const int ys[2] = {min(max(yi, 0), hmax), min(max(yi + 1, 0), hmax)};
+  const float gx = __fadd_rn(1.0f, -fx), gy = __fadd_rn(1.0f, -fy);
+  const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+
+  float x[12];  // tap t: x[3t] = R, x[3t + 1] = G, x[3t + 2] = B
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int px = xs[t & 1], py = ys[t >> 1];
+    const uint8_t *c = f.cbcr + static_cast<size_t>(py >> 1) * p.cbcr_stride + 2 * (px >> 1);
+    const Chroma ch = chroma_terms(byte_value(c[0]), byte_value(c[1]));
+    pixel_rgb(byte_value(f.y[static_cast<size_t>(py) * p.y_stride + px]), ch, x[3 * t], x[3 * t + 1], x[3 * t + 2]);
+  }
+  float lin[12];
+  linearise12(r, x, lin);
+  float acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    acc[k] = __fmul_rn(w[0], lin[k]);
+#pragma unroll
+    for (int t = 1; t < 4; ++t) acc[k] = __fadd_rn(acc[k], __fmul_rn(w[t], lin[3 * t + k]));
+  }
+  const uint32_t R = encode_byte(r, __fmul_rn(acc[0], r.scale));
+  const uint32_t G = encode_byte(r, __fmul_rn(acc[1], r.scale));
+  const uint32_t B = encode_byte(r, __fmul_rn(acc[2], r.scale));
+  reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, p.alpha_word);
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------
+#ifndef BT709_REP_STEP
+#define BT709_REP_STEP 2  // tile rows per step of the persistent kernel (loads run one step ahead)
+#endif
+
+const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
+                               uint32_t block_threads, hipStream_t stream) {
+  const uint32_t by = wide ? quads_rows_per_block(block_threads, grid_x) : 1;
+  const dim3 grid(grid_x, (p.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
+  const dim3 block(block_threads, by, 1);
+  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes;
+  if (wide) {
+    if (nontemporal) hipLaunchKernelGGL((decode_nv12_half<true, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((decode_nv12_half<false, true>), grid, block, lds, stream, p);
+    return "decode_nv12_half<wide>";
+  }
+  hipLaunchKernelGGL((decode_nv12_half<false, false>), grid, block, lds, stream, p);
+  return "decode_nv12_half<narrow>";
+}
+
+const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool nontemporal, uint32_t workgroups,
+                                   hipStream_t stream) {
+  DecodeParams p = p_in;
+  // copies: as many as fit the CU's LDS, decode side first (12 of the 15 lookups per output pixel)
+  uint32_t r1 = 4, r2 = 0;
+  while (r1 > 0 && (static_cast<uint64_t>(p.table_linear_bytes) << r1) + p.table_encode_bytes > kRepLdsBytes) --r1;
+  if ((static_cast<uint64_t>(p.table_linear_bytes) << r1) + p.table_encode_bytes > kRepLdsBytes) return nullptr;
+  while (r2 < 5 && (static_cast<uint64_t>(p.table_linear_bytes) << r1) +
+                           (static_cast<uint64_t>(p.table_encode_bytes) << (r2 + 1)) <=
+                       kRepLdsBytes)
+    ++r2;
+  p.rep_dec_log2 = r1;
+  p.rep_enc_log2 = r2;
+  const uint32_t quads = p.width / 4, row_pairs = p.height / 2;
+  p.tiles_x = (quads + kRepBlockThreads - 1) / kRepBlockThreads;
+  const uint32_t threads = ((quads + p.tiles_x - 1) / p.tiles_x + 63) / 64 * 64;
+  const uint64_t total = static_cast<uint64_t>(p.tiles_x) * row_pairs * static_cast<uint32_t>(frames);
+  if (total == 0 || total > 0x7fffffffu) return nullptr;
+  p.tile_rows = static_cast<uint32_t>(total);
+  if (workgroups > p.tile_rows) workgroups = p.tile_rows;
+  if (workgroups == 0) workgroups = 1;
+  p.cursor_tx = workgroups % p.tiles_x;
+  p.cursor_rp = (workgroups / p.tiles_x) % row_pairs;
+  p.cursor_f = (workgroups / p.tiles_x) / row_pairs;
+  const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << r1) + (static_cast<size_t>(p.table_encode_bytes) << r2);
+  if (nontemporal)
+    hipLaunchKernelGGL((decode_nv12_half_rep<true, BT709_REP_STEP>), dim3(workgroups), dim3(threads), lds, stream, p);
+  else
+    hipLaunchKernelGGL((decode_nv12_half_rep<false, BT709_REP_STEP>), dim3(workgroups), dim3(threads), lds, stream, p);
+  return "decode_nv12_half_rep";
+}
+
+const char *launch_decode_scaled(const DecodeParams &p, int frames, hipStream_t stream) {
+  const dim3 grid((p.out_width + kBlockThreads - 1) / kBlockThreads, p.out_height, static_cast<uint32_t>(frames));
+  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes;
+  hipLaunchKernelGGL(decode_nv12_scaled, grid, dim3(kBlockThreads), lds, stream, p);
+  return "decode_nv12_scaled";
+}
+
+hipError_t prepare_rescale_kernels() {
+  const int cap = static_cast<int>(kRepLdsBytes);  // gfx950: 160 KiB LDS per workgroup
+  const void *fns[] = {
+      reinterpret_cast<const void *>(&decode_nv12_half<true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_half<false, true>),
+      reinterpret_cast<const void *>(&decode_nv12_half<false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_half_rep<true, BT709_REP_STEP>),
+      reinterpret_cast<const void *>(&decode_nv12_half_rep<false, BT709_REP_STEP>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled),
+  };
+  for (const void *fn : fns) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+}  // namespace bt709

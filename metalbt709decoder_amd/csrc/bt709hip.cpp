@@ -48,19 +48,16 @@ struct bt709hip_decoder {
   int half_rep = -1;  // persistent conflict-free rescale kernel: -1 = when the launch is large enough, 0 never, 1 always
   std::mutex setup_mutex;
   bool ready = false;
-  // device copies
-  void *d_table = nullptr;         // TransferBucket[n+1(+pad)]
-  uint32_t table_bytes = 0;
-  uint32_t table_n = 0;
-  void *d_table_unit = nullptr;    // TransferBucket[n+1], unscaled edges (fast 1:1 kernel)
+  // device copies (transfer_tables.h)
+  uint32_t table_n = 0;            // bucket count N of the decoder's gamma
+  void *d_table_unit = nullptr;    // TransferBucket[N + 1] (decode kernels)
   uint32_t table_unit_bytes = 0;
-  void *d_table_linear = nullptr;  // TransferBucketLinear[n+1] (half-scale decode side)
+  void *d_table_linear = nullptr;  // TransferBucketLinear[N + 1] (rescale kernels, decode side)
   uint32_t table_linear_bytes = 0;
-  void *d_encode = nullptr;        // LINEAR-mode TransferBucket[] (half-scale encode side)
+  void *d_encode = nullptr;        // LINEAR-mode two-resolution TransferBucket[] (rescale kernels, encode side)
   uint32_t encode_bytes = 0;
   uint32_t encode_n = 0;
-  float encode_split = 0.0f, encode_coarse = 1.0f;
-  uint32_t encode_offset = 0;
+  uint32_t encode_offset = 0, encode_shift = 0;
 };
 
 namespace {
@@ -138,15 +135,18 @@ int upload_table(const void *src, size_t bytes, void **dst) {
   return BT709HIP_OK;
 }
 
-// Matrix of BT709.h:389-397 scaled by the table's bucket count (a power of two: exact).
-void set_matrix(DecodeParams *p, uint32_t n) {
-  const float fn = static_cast<float>(n);
-  p->table_scale = fn;
-  p->m_y = kMY * fn;
-  p->m_cr_r = kMCrR * fn;
-  p->m_cb_g = kMCbG * fn;
-  p->m_cr_g = kMCrG * fn;
-  p->m_cb_b = kMCbB * fn;
+// Table pointers and lookup constants of a launch.
+void set_tables(DecodeParams *p, const bt709hip_decoder *dec) {
+  p->table_unit = dec->d_table_unit;
+  p->table_unit_bytes = dec->table_unit_bytes;
+  p->table_linear = dec->d_table_linear;
+  p->table_linear_bytes = dec->table_linear_bytes;
+  p->table_encode = dec->d_encode;
+  p->table_encode_bytes = dec->encode_bytes;
+  p->encode_scale = static_cast<float>(dec->encode_n);
+  p->encode_offset = dec->encode_offset;
+  p->encode_shift = dec->encode_shift;
+  p->unit_magic = 8388608.0f / static_cast<float>(dec->table_n);  // 2^23 / N, exact: N is a power of two
 }
 
 int64_t byte_step(const void *a, const void *b) {
@@ -209,6 +209,7 @@ int bt709hip_context_create(int device_ordinal, bt709hip_context **out) {
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->props, device_ordinal);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->default_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = prepare_kernels();
+  if (e == hipSuccess) e = prepare_rescale_kernels();
   if (e == hipSuccess) e = prepare_encode_kernels();
   if (e != hipSuccess) {
     delete ctx;
@@ -395,7 +396,6 @@ int bt709hip_decoder_create(bt709hip_context *ctx, int gamma, int has_alpha, bt7
 int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
   if (dec == nullptr) return BT709HIP_OK;
   if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) {
-    if (dec->d_table) (void)hipFree(dec->d_table);
     if (dec->d_table_unit) (void)hipFree(dec->d_table_unit);
     if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
     if (dec->d_encode) (void)hipFree(dec->d_encode);
@@ -434,16 +434,13 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   if (!build_transfer_table(dec->gamma, &t) || !build_split_table(kGammaLinear, &enc))
     return BT709HIP_ERR_UNSUPPORTED;
   dec->table_n = t.n;
-  dec->table_bytes = static_cast<uint32_t>(t.buckets.size() * sizeof(TransferBucket));
-  // rescale kernel: unit part only (it clamps), see lookup_linear
-  dec->table_linear_bytes = static_cast<uint32_t>(t.unit_entries * sizeof(TransferBucketLinear));
-  dec->encode_n = enc.n_fine;
-  dec->encode_split = enc.split;
-  dec->encode_coarse = enc.coarse_scale;
-  dec->encode_offset = enc.coarse_offset;
-  dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
-  if (int rc = upload_table(t.buckets.data(), dec->table_bytes, &dec->d_table)) return rc;
   dec->table_unit_bytes = static_cast<uint32_t>(t.buckets_unit.size() * sizeof(TransferBucket));
+  dec->table_linear_bytes = static_cast<uint32_t>(t.buckets_linear.size() * sizeof(TransferBucketLinear));
+  dec->encode_n = enc.n_fine;
+  dec->encode_offset = enc.coarse_offset;
+  dec->encode_shift = 0;
+  for (float r = enc.coarse_scale; r < 1.0f; r *= 2.0f) ++dec->encode_shift;  // log2(fine buckets per coarse bucket)
+  dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
   if (int rc = upload_table(t.buckets_unit.data(), dec->table_unit_bytes, &dec->d_table_unit)) return rc;
   if (int rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &dec->d_table_linear)) return rc;
   if (int rc = upload_table(enc.buckets.data(), dec->encode_bytes, &dec->d_encode)) return rc;
@@ -493,11 +490,7 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
     p.step_alpha = dec->has_alpha ? byte_step(alphas[0].y, alphas[1].y) : 0;
     p.step_out = byte_step(outs[0].bgra, outs[1].bgra);
   }
-  p.table = dec->d_table;
-  p.table_bytes = dec->table_bytes;
-  p.table_unit = dec->d_table_unit;
-  p.table_unit_bytes = dec->table_unit_bytes;
-  set_matrix(&p, dec->table_n);
+  set_tables(&p, dec);
   p.width = static_cast<uint32_t>(f0.width);
   p.height = static_cast<uint32_t>(f0.height);
   p.y_stride = static_cast<uint32_t>(f0.y_stride);
@@ -568,15 +561,7 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
     p.step_cbcr = byte_step(frames[0].cbcr, frames[1].cbcr);
     p.step_out = byte_step(outs[0].bgra, outs[1].bgra);
   }
-  p.table = dec->d_table_linear;
-  p.table_bytes = dec->table_linear_bytes;
-  set_matrix(&p, dec->table_n);
-  p.table2 = dec->d_encode;
-  p.table2_bytes = dec->encode_bytes;
-  p.table2_scale = static_cast<float>(dec->encode_n);
-  p.table2_split = dec->encode_split;
-  p.table2_coarse = dec->encode_coarse;
-  p.table2_offset = dec->encode_offset;
+  set_tables(&p, dec);
   p.width = static_cast<uint32_t>(f0.width);
   p.height = static_cast<uint32_t>(f0.height);
   p.y_stride = static_cast<uint32_t>(f0.y_stride);
@@ -618,15 +603,7 @@ int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, c
   p.frames[0].y = static_cast<const uint8_t *>(frame->y);
   p.frames[0].cbcr = static_cast<const uint8_t *>(frame->cbcr);
   p.frames[0].out = static_cast<uint8_t *>(out->bgra);
-  p.table = dec->d_table_linear;
-  p.table_bytes = dec->table_linear_bytes;
-  set_matrix(&p, dec->table_n);
-  p.table2 = dec->d_encode;
-  p.table2_bytes = dec->encode_bytes;
-  p.table2_scale = static_cast<float>(dec->encode_n);
-  p.table2_split = dec->encode_split;
-  p.table2_coarse = dec->encode_coarse;
-  p.table2_offset = dec->encode_offset;
+  set_tables(&p, dec);
   p.width = static_cast<uint32_t>(frame->width);
   p.height = static_cast<uint32_t>(frame->height);
   p.y_stride = static_cast<uint32_t>(frame->y_stride);

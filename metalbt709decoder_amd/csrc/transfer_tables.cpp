@@ -125,19 +125,9 @@ bool build_transfer_table(int gamma, TransferTable *out) {
     }
     if (!ok) continue;
     out->n = n;
-    out->buckets_unit.assign(b.begin(), b.begin() + n + 1);
-    while ((out->buckets_unit.size() * sizeof(TransferBucket)) % 16 != 0) out->buckets_unit.push_back(TransferBucket{inf, 255u});
-    // Scaled domain: the kernels index with xs = N*x, so edges are stored times N (exact,
-    // power of two).  Unsaturated inputs reach ~2.15: extend with "answer 255" buckets up to
-    // kTableReach*N so that no clamp is needed; negative xs convert to bucket 0.
-    const float fn = static_cast<float>(n);
-    for (uint32_t q = 0; q <= n; ++q)
-      if (b[q].edge != inf) b[q].edge *= fn;
-    out->unit_entries = n + 1;
-    while ((out->unit_entries * sizeof(TransferBucket)) % 16 != 0) ++out->unit_entries;
-    const uint32_t total = static_cast<uint32_t>(kTableReach * fn) + 2;
-    while (b.size() < total || (b.size() * sizeof(TransferBucket)) % 16 != 0) b.push_back(TransferBucket{inf, 255u});
-    out->buckets = b;
+    out->buckets_unit = b;  // N + 1 buckets, edges in x units
+    while ((out->buckets_unit.size() * sizeof(TransferBucket)) % 16 != 0)
+      out->buckets_unit.push_back(TransferBucket{inf, 255u});
     out->buckets_linear.resize(b.size());
     for (size_t q = 0; q < b.size(); ++q) {
       TransferBucketLinear &e = out->buckets_linear[q];

@@ -12,11 +12,10 @@
 // out in N uniform buckets, N a power of two chosen so no bucket holds two
 // thresholds:
 //     byte(x) = bucket[q].base + (xs >= bucket[q].edge),   xs = N * x,  q = (uint)xs
-// The kernels work in the SCALED domain xs = N*x (their matrix constants are pre-multiplied
-// by N; scaling by a power of two commutes with IEEE rounding), so `edge` is stored as
-// N * threshold, and the table extends past N (x > 1, before saturation) with buckets that
-// answer 255, up to kTableReach * N: the largest reachable pre-saturation value is
-// B(Y=255, Cb=255) = 2.1434.  Negative xs convert to bucket 0, whose answer is 0.
+// The kernels saturate x to [0,1] first (as the reference does, BT709.h:444-446) and compare in
+// x units, so the table is N + 1 buckets (the last one holds x == 1.0) and `edge` is the
+// threshold itself.  The bucket index floor(x N) comes from a round-toward-zero add of 2^23 / N
+// (csrc/bt709_device.h magic_floor12).
 #pragma once
 
 #include <cstdint>
@@ -34,9 +33,7 @@ enum Gamma : int { kGammaApple = 0, kGammaSRGB = 1, kGammaLinear = 2, kGammaITU7
 constexpr int kTableEncodeApple = 4;
 constexpr int kTableKinds = 5;
 
-constexpr float kTableReach = 2.25f;  // table covers xs in [0, kTableReach * N]
-
-// One bucket.  `edge` is N times the single threshold strictly inside the bucket, or +inf.
+// One bucket.  `edge` is the single threshold strictly inside the bucket, or +inf.
 struct alignas(8) TransferBucket {
   float edge;
   uint32_t base;
@@ -54,14 +51,11 @@ struct alignas(16) TransferBucketLinear {
 
 struct TransferTable {
   int gamma = 0;
-  uint32_t n = 0;                        // bucket count N (power of two); table has N + 1 entries
-  float thresholds[255];                 // t[k-1] = min { x in [0,1] : byte(x) >= k }
-  uint32_t unit_entries = 0;             // entries covering x in [0,1] (N + 1, padded to 16 bytes)
-  std::vector<TransferBucket> buckets;   // kTableReach * N + 2 entries (+ padding to a 16-byte multiple)
-  std::vector<TransferBucketLinear> buckets_linear;  // same buckets, linearised outputs
-  // buckets 0..N with the edge left in x units (the fast kernel saturates x to [0,1] before the
-  // lookup and compares in x units), padded to a 16-byte multiple
+  uint32_t n = 0;          // bucket count N (power of two)
+  float thresholds[255];   // t[k-1] = min { x in [0,1] : byte(x) >= k }
+  // buckets 0..N (bucket N: x == 1.0), padded to a 16-byte multiple
   std::vector<TransferBucket> buckets_unit;
+  std::vector<TransferBucketLinear> buckets_linear;  // the same N + 1 buckets, linearised outputs
 };
 
 // Scalar transfer functions, float in / float out, C semantics of the reference.
@@ -92,6 +86,8 @@ bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out);
 // (the encoder's BT709_from_linear tables need N = 4096 uniformly, 33 KiB, only because of
 // their first 1/16 of the range).  With xs = n_fine * x:
 //     q = xs < split ? (uint)xs : (uint)(xs * coarse_scale) + coarse_offset
+//       = min((uint)xs, ((uint)xs >> log2(ratio)) + coarse_offset)   // the two index functions cross at
+//                                                                    // the split, the fine one grows faster
 //     byte = buckets[q].base + (xs >= buckets[q].edge)          // edges stored times n_fine
 // i.e. buckets of width 1/n_fine below split/n_fine and ratio times wider above.
 struct SplitTable {

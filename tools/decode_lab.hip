@@ -1,6 +1,8 @@
 // Decode lab: times the PRODUCTION kernels (csrc/bt709_kernels.hip included verbatim) over a
 // ring of 64 distinct 4K frames, several launch shapes, interleaved rounds (median / min).
-// Build variants with -DBT709_LAB_NO_LDS / -DBT709_LAB_NO_CONFLICT to price the LDS lookups.
+// Build variants: -DBT709_LAB_NO_LDS prices the LDS lookups, -DBT709_LAB_LDS_CHROMA the LDS-staged chroma
+// tile, -DBT709_LAB_LDS_PAD (+ env BT709_LAB_LDS_PAD=KiB) caps the workgroups resident per CU,
+// -DBT709_MAX_BLOCK_THREADS / -DBT709_QUADS_PER_LANE change the tile shape.
 //
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 tools/decode_lab.hip \
 //         metalbt709decoder_amd/csrc/transfer_tables.cpp -o tools/bin/decode_lab
@@ -37,7 +39,7 @@ struct Ring {
   int W, H, ring, batch;
   size_t yb, cb, ob, in_stride, out_stride;
   uint8_t *d_in = nullptr, *d_out = nullptr;
-  void *d_table = nullptr, *d_table_unit = nullptr;
+  void *d_table_unit = nullptr;
   TransferTable tt;
   std::vector<DecodeParams> params;
   hipStream_t s;
@@ -68,9 +70,6 @@ struct Ring {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     if (!build_transfer_table(gamma, &tt)) std::exit(2);
-    const size_t tb = tt.buckets.size() * sizeof(TransferBucket);
-    CK(hipMalloc(&d_table, tb));
-    CK(hipMemcpy(d_table, tt.buckets.data(), tb, hipMemcpyHostToDevice));
     const size_t tub = tt.buckets_unit.size() * sizeof(TransferBucket);
     CK(hipMalloc(&d_table_unit, tub));
     CK(hipMemcpy(d_table_unit, tt.buckets_unit.data(), tub, hipMemcpyHostToDevice));
@@ -82,12 +81,9 @@ struct Ring {
         uint8_t *base = d_in + size_t(l * batch + i) * in_stride;
         p.frames[i] = FramePlanes{base, base + yb, nullptr, d_out + size_t(l * batch + i) * out_stride};
       }
-      p.table = d_table;
-      p.table_bytes = uint32_t(tb);
       p.table_unit = d_table_unit;
       p.table_unit_bytes = uint32_t(tub);
-      p.table_scale = float(tt.n);
-      p.m_y = kMY * tt.n; p.m_cr_r = kMCrR * tt.n; p.m_cb_g = kMCbG * tt.n; p.m_cr_g = kMCrG * tt.n; p.m_cb_b = kMCbB * tt.n;
+      p.unit_magic = 8388608.0f / float(tt.n);
       p.width = W;
       p.height = H;
       p.y_stride = W;

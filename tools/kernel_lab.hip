@@ -223,9 +223,9 @@ struct Lab {
     CK(hipEventCreate(&e1));
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     if (!build_transfer_table(gamma, &tt)) std::exit(2);
-    const size_t tb = tt.buckets.size() * sizeof(TransferBucket);
+    const size_t tb = tt.buckets_unit.size() * sizeof(TransferBucket);
     CK(hipMalloc(&d_table, tb));
-    CK(hipMemcpy(d_table, tt.buckets.data(), tb, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_table, tt.buckets_unit.data(), tb, hipMemcpyHostToDevice));
     for (int l = 0; l < RING / BATCH; ++l) {
       DecodeParams &p = params[l];
       std::memset(&p, 0, sizeof p);
@@ -233,10 +233,9 @@ struct Lab {
         uint8_t *base = d_in + size_t(l * BATCH + i) * IN_STRIDE;
         p.frames[i] = FramePlanes{base, base + YB, nullptr, d_out + size_t(l * BATCH + i) * OUT_STRIDE};
       }
-      p.table = d_table;
-      p.table_bytes = uint32_t(tb);
-      p.table_scale = float(tt.n);
-      p.m_y = kMY * tt.n; p.m_cr_r = kMCrR * tt.n; p.m_cb_g = kMCbG * tt.n; p.m_cr_g = kMCrG * tt.n; p.m_cb_b = kMCbB * tt.n;
+      p.table_unit = d_table;
+      p.table_unit_bytes = uint32_t(tb);
+      p.unit_magic = 8388608.0f / float(tt.n);
       p.width = W;
       p.height = H;
       p.y_stride = W;
