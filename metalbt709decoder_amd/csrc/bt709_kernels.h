@@ -59,6 +59,7 @@ struct DecodeParams {
   // decode_nv12_scaled only: output size and source-per-output-pixel ratios W/OW, H/OH (float)
   uint32_t out_width, out_height;
   float scale_x, scale_y;
+  uint32_t scaled_rows;  // output rows a workgroup walks (filled by launch_decode_scaled)
   // uniform != 0: frame i = frames[0] + i * step_* (bytes); lets one launch cover any number of frames
   uint32_t uniform;
   int64_t step_y, step_cbcr, step_alpha, step_out;
@@ -143,8 +144,8 @@ const char *launch_decode_half_rep(const DecodeParams &p, int frames, bool nonte
 constexpr int kRepBlockThreads = 1024;      // one workgroup per CU: 16 waves
 constexpr uint32_t kRepLdsBytes = 160 * 1024;
 
-// scaled: grid = (ceil(OW / kBlockThreads), OH, frames) x kBlockThreads.
-const char *launch_decode_scaled(const DecodeParams &p, int frames, hipStream_t stream);
+// scaled: grid = (ceil(OW / kBlockThreads), ceil(OH / rows), frames) x kBlockThreads, rows chosen from the CU count.
+const char *launch_decode_scaled(const DecodeParams &p, int frames, uint32_t compute_units, hipStream_t stream);
 
 // Fast-path launch geometry for a frame width: tiles (workgroups) per row pair and the
 // workgroup size -- ceil(quads per tile / kQuadsPerLane) rounded up to a whole wave.

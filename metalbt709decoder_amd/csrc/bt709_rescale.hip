@@ -311,9 +311,15 @@ decode_nv12_half_rep(const DecodeParams p) {
 //   does; v = (((w00*l00 + w01*l01) + w10*l10) + w11*l11) with w00 = (1-fx)(1-fy), ...;
 //   sRGB-encode, quantise.  For an exact 2:1 ratio every weight is 0.25 and this is bit for bit
 //   the decode_nv12_half result.
-// One lane per output pixel, byte gathers (cached), 4-byte coalesced stores; grid =
-// (ceil(OW / blockDim), OH, frames).
+// One lane per output column, walking `rows` consecutive output rows (grid = (ceil(OW /
+// blockDim), ceil(OH / rows), frames)): the horizontal tap positions and weights are computed
+// once per lane, the vertical ones are uniform per row (scalar), and the 14 KiB of tables are
+// staged once per workgroup instead of once per 256 output pixels (the first version did that and
+// spent its time staging: 86 Gpixel/s whatever the size; prefetching the next row's taps was
+// tried and is slower).  Byte gathers (cached; PAIRS: a tap's Cb,Cr with one 2-byte load when the
+// CbCr plane is 2-byte aligned), 4-byte coalesced stores.
 // ---------------------------------------------------------------------------
+template <bool PAIRS>
 __global__ void __launch_bounds__(kBlockThreads)
 decode_nv12_scaled(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -321,42 +327,56 @@ decode_nv12_scaled(const DecodeParams p) {
   __syncthreads();
 
   const FramePlanes f = frame_planes(p, blockIdx.z);
-  const uint32_t oy = blockIdx.y;
   const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
   if (ox >= p.out_width) return;
 
   const float sx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ox), 0.5f), p.scale_x), -0.5f);
-  const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy), 0.5f), p.scale_y), -0.5f);
-  const float x0f = __builtin_floorf(sx), y0f = __builtin_floorf(sy);
-  const float fx = __fadd_rn(sx, -x0f), fy = __fadd_rn(sy, -y0f);
+  const float x0f = __builtin_floorf(sx);
+  const float fx = __fadd_rn(sx, -x0f), gx = __fadd_rn(1.0f, -fx);
   const int wmax = static_cast<int>(p.width) - 1, hmax = static_cast<int>(p.height) - 1;
-  const int xi = static_cast<int>(x0f), yi = static_cast<int>(y0f);
+  const int xi = static_cast<int>(x0f);
   const int xs[2] = {min(max(xi, 0), wmax), min(max(xi + 1, 0), wmax)};
-  const int ys[2] = {min(max(yi, 0), hmax), min(max(yi + 1, 0), hmax)};
-  const float gx = __fadd_rn(1.0f, -fx), gy = __fadd_rn(1.0f, -fy);
-  const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+  const uint32_t cx[2] = {2u * (static_cast<uint32_t>(xs[0]) >> 1), 2u * (static_cast<uint32_t>(xs[1]) >> 1)};
 
-  float x[12];  // tap t: x[3t] = R, x[3t + 1] = G, x[3t + 2] = B
+  const uint32_t oy0 = blockIdx.y * p.scaled_rows, oy1 = min(oy0 + p.scaled_rows, p.out_height);
+  for (uint32_t oy = oy0; oy < oy1; ++oy) {
+    const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy), 0.5f), p.scale_y), -0.5f);
+    const float y0f = __builtin_floorf(sy);
+    const float fy = __fadd_rn(sy, -y0f), gy = __fadd_rn(1.0f, -fy);
+    const int yi = static_cast<int>(y0f);
+    const int ys[2] = {min(max(yi, 0), hmax), min(max(yi + 1, 0), hmax)};
+    const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+
+    float x[12];  // tap t: x[3t] = R, x[3t + 1] = G, x[3t + 2] = B
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int px = xs[t & 1], py = ys[t >> 1];
-    const uint8_t *c = f.cbcr + static_cast<size_t>(py >> 1) * p.cbcr_stride + 2 * (px >> 1);
-    const Chroma ch = chroma_terms(byte_value(c[0]), byte_value(c[1]));
-    pixel_rgb(byte_value(f.y[static_cast<size_t>(py) * p.y_stride + px]), ch, x[3 * t], x[3 * t + 1], x[3 * t + 2]);
+    for (int t = 0; t < 4; ++t) {
+      const uint8_t *yrow = f.y + static_cast<size_t>(ys[t >> 1]) * p.y_stride;
+      const uint8_t *crow = f.cbcr + static_cast<size_t>(ys[t >> 1] >> 1) * p.cbcr_stride;
+      float cb, cr;
+      if (PAIRS) {
+        const uint32_t pair = *reinterpret_cast<const uint16_t *>(crow + cx[t & 1]);  // Cb low byte, Cr high
+        cb = byte_of(pair, 0);
+        cr = byte_of(pair, 1);
+      } else {
+        cb = byte_value(crow[cx[t & 1]]);
+        cr = byte_value(crow[cx[t & 1] + 1]);
+      }
+      pixel_rgb(byte_value(yrow[xs[t & 1]]), chroma_terms(cb, cr), x[3 * t], x[3 * t + 1], x[3 * t + 2]);
+    }
+    float lin[12];
+    linearise12(r, x, lin);
+    float acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      acc[k] = __fmul_rn(w[0], lin[k]);
+#pragma unroll
+      for (int t = 1; t < 4; ++t) acc[k] = __fadd_rn(acc[k], __fmul_rn(w[t], lin[3 * t + k]));
+    }
+    const uint32_t R = encode_byte(r, __fmul_rn(acc[0], r.scale));
+    const uint32_t G = encode_byte(r, __fmul_rn(acc[1], r.scale));
+    const uint32_t B = encode_byte(r, __fmul_rn(acc[2], r.scale));
+    reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, p.alpha_word);
   }
-  float lin[12];
-  linearise12(r, x, lin);
-  float acc[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    acc[k] = __fmul_rn(w[0], lin[k]);
-#pragma unroll
-    for (int t = 1; t < 4; ++t) acc[k] = __fadd_rn(acc[k], __fmul_rn(w[t], lin[3 * t + k]));
-  }
-  const uint32_t R = encode_byte(r, __fmul_rn(acc[0], r.scale));
-  const uint32_t G = encode_byte(r, __fmul_rn(acc[1], r.scale));
-  const uint32_t B = encode_byte(r, __fmul_rn(acc[2], r.scale));
-  reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, p.alpha_word);
 }
 
 // ---------------------------------------------------------------------------
@@ -413,10 +433,21 @@ const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool no
   return "decode_nv12_half_rep";
 }
 
-const char *launch_decode_scaled(const DecodeParams &p, int frames, hipStream_t stream) {
-  const dim3 grid((p.out_width + kBlockThreads - 1) / kBlockThreads, p.out_height, static_cast<uint32_t>(frames));
+const char *launch_decode_scaled(const DecodeParams &p_in, int frames, uint32_t compute_units, hipStream_t stream) {
+  DecodeParams p = p_in;
+  // rows per workgroup: as many as still leave ~8 workgroups per CU (table staging is per workgroup)
+  const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
+  const uint64_t want = 8ull * (compute_units ? compute_units : 256u);
+  uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height * static_cast<uint32_t>(frames) / want);
+  rows = rows < 1 ? 1 : (rows > 32 ? 32 : rows);
+  p.scaled_rows = rows;
+  const dim3 grid(cols, (p.out_height + rows - 1) / rows, static_cast<uint32_t>(frames));
   const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes;
-  hipLaunchKernelGGL(decode_nv12_scaled, grid, dim3(kBlockThreads), lds, stream, p);
+  bool pairs = (p.cbcr_stride % 2) == 0;
+  for (int i = 0; i < frames && i < kMaxBatch; ++i) pairs = pairs && (reinterpret_cast<uintptr_t>(p.frames[i].cbcr) % 2) == 0;
+  if (p.uniform) pairs = pairs && (p.step_cbcr % 2) == 0;
+  if (pairs) hipLaunchKernelGGL(decode_nv12_scaled<true>, grid, dim3(kBlockThreads), lds, stream, p);
+  else hipLaunchKernelGGL(decode_nv12_scaled<false>, grid, dim3(kBlockThreads), lds, stream, p);
   return "decode_nv12_scaled";
 }
 
@@ -428,7 +459,8 @@ hipError_t prepare_rescale_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_half<false, false>),
       reinterpret_cast<const void *>(&decode_nv12_half_rep<true, BT709_REP_STEP>),
       reinterpret_cast<const void *>(&decode_nv12_half_rep<false, BT709_REP_STEP>),
-      reinterpret_cast<const void *>(&decode_nv12_scaled),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<true>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<false>),
   };
   for (const void *fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

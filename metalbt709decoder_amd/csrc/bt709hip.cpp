@@ -573,12 +573,13 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   // wide: same tiling as the 1:1 kernel over the source width; narrow: 256 output pixels per workgroup
   const uint32_t gx = wide ? quads_tiles(p.width) : (p.width / 2 + kBlockThreads - 1) / kBlockThreads;
   const uint32_t threads = wide ? quads_block_threads(p.width) : kBlockThreads;
-  // Large launches: persistent workgroups with bank-conflict-free (replicated) LDS tables, one per CU.
-  // Staging ~150 KiB of LDS per workgroup pays once a CU has a few dozen tile rows to walk.
+  // Larger launches: persistent workgroups with bank-conflict-free (replicated) LDS tables, one per CU.
+  // Staging ~150 KiB of LDS per workgroup pays once a CU has several tile rows to walk (measured
+  // with tools/half_threshold.sh: one 8K frame = 17 tile rows per CU is already 19 % faster).
   const uint32_t cus = static_cast<uint32_t>(dec->ctx->props.multiProcessorCount);
   const uint64_t tile_rows = static_cast<uint64_t>((p.width / 4 + kRepBlockThreads - 1) / kRepBlockThreads) *
                              (p.height / 2) * static_cast<uint32_t>(count);
-  const bool rep = wide && dec->half_rep != 0 && (dec->half_rep > 0 || tile_rows >= 32ull * cus);
+  const bool rep = wide && dec->half_rep != 0 && (dec->half_rep > 0 || tile_rows >= 8ull * cus);
   const char *name = rep ? launch_decode_half_rep(p, count, dec->nontemporal,
                                                   static_cast<uint32_t>(env_int("BT709HIP_REP_WORKGROUPS", static_cast<int>(cus))), s)
                          : nullptr;
@@ -615,7 +616,7 @@ int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, c
   p.scale_y = static_cast<float>(frame->height) / static_cast<float>(out->height);
   p.alpha_word = dec->alpha_fill << 24;
   hipStream_t s = pick(dec->ctx, stream);
-  tl_kernel_name = launch_decode_scaled(p, 1, s);
+  tl_kernel_name = launch_decode_scaled(p, 1, static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), s);
   HIP_TRY(hipGetLastError());
   if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;

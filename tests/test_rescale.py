@@ -71,6 +71,21 @@ def test_gpu_scaled_matches_oracle(gh, oracle, gamma, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strides", [(67, 65), (64, 66), (80, 64)])
+def test_gpu_scaled_odd_strides_and_many_rows(gh, oracle, strides):
+    """Odd plane strides take the byte-gather form of the kernel (an even CbCr plane: one 2-byte load
+    per tap); a tall output makes a workgroup walk several rows."""
+    ctx = gh.context()
+    y, c = _frame(64, 600, 5)
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    buf = gh.make_buffer(y, c, dec.gamma, y_stride=strides[0], cbcr_stride=strides[1])
+    tex = ctx.makeBGRATexture((300, 4000))
+    assert dec.decodeBT709Scaled(buf, tex, ctx.commandQueue.commandBuffer(), True), dec.lastStatus
+    got = ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(4000, 300 * 4)
+    assert np.array_equal(got, oracle.decode_nv12_scaled(0, y, c, 300, 4000))
+
+
+@pytest.mark.gpu
 def test_gpu_view_fit_like_the_renderer(gh, oracle):
     """AAPLRenderer's case: a 1920x1080 frame into a view of another aspect and size
     (AAPLRenderer.m:891-977 takes the 2-pass route whenever the sizes differ)."""
