@@ -46,11 +46,17 @@ struct Ring {
   hipEvent_t e0, e1;
 
   Ring(int w, int h, int ring_, int batch_, int gamma) : W(w), H(h), ring(ring_), batch(batch_) {
-    yb = size_t(W) * H;
+    // placement experiments: LAB_ROW_PAD bytes added to every output row, LAB_IN_ROW_PAD to every input row,
+    // LAB_FRAME_PAD to the frame pitches
+    const size_t row_pad = std::getenv("LAB_ROW_PAD") ? std::atoi(std::getenv("LAB_ROW_PAD")) : 0;
+    const size_t in_row_pad = std::getenv("LAB_IN_ROW_PAD") ? std::atoi(std::getenv("LAB_IN_ROW_PAD")) : 0;
+    const size_t frame_pad = std::getenv("LAB_FRAME_PAD") ? std::atoi(std::getenv("LAB_FRAME_PAD")) : 0;
+    const size_t ys = W + in_row_pad, os = size_t(W) * 4 + row_pad;
+    yb = ys * H;
     cb = yb / 2;
-    ob = yb * 4;
-    in_stride = (yb + cb + 255) / 256 * 256;
-    out_stride = ob;
+    ob = os * H;
+    in_stride = (yb + cb + 255) / 256 * 256 + frame_pad;
+    out_stride = ob + frame_pad;
     CK(hipMalloc(&d_in, in_stride * ring));
     CK(hipMalloc(&d_out, out_stride * ring));
     std::vector<uint8_t> h8(in_stride);
@@ -86,13 +92,13 @@ struct Ring {
       p.unit_magic = 8388608.0f / float(tt.n);
       p.width = W;
       p.height = H;
-      p.y_stride = W;
-      p.cbcr_stride = W;
-      p.out_stride = W * 4;
+      p.y_stride = uint32_t(ys);
+      p.cbcr_stride = uint32_t(ys);
+      p.out_stride = uint32_t(os);
       p.alpha_word = 0xff000000u;
     }
   }
-  double bytes_per_launch() const { return double(yb + cb + ob) * batch; }
+  double bytes_per_launch() const { return double(size_t(W) * H * 11 / 2) * batch; }  // algorithmic, whatever the padding
   double once(const std::function<void(int)> &fn, int reps) {
     CK(hipEventRecord(e0, s));
     for (int r = 0; r < reps; ++r)
