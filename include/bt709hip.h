@@ -149,6 +149,19 @@ int bt709hip_event_record(bt709hip_context *ctx, void *event, void *stream);
 int bt709hip_event_synchronize(bt709hip_context *ctx, void *event);
 int bt709hip_event_elapsed_ms(bt709hip_context *ctx, void *start, void *stop, float *ms);
 
+/* Recorded command buffers.  The reference encodes a frame's passes into an MTLCommandBuffer
+ * and commits it (MetalBT709Decoder.h:65-72 takes the buffer; AAPLRenderer.m:891-977 builds one
+ * per frame); the HIP twin of a command buffer that is recorded once and replayed is a graph.
+ * Between begin and end every bt709hip_decode* / _encode* / upload / download / memset issued
+ * on `stream` (a created stream, not NULL) is recorded instead of executed; `graph` then
+ * replays them all with one launch -- for pipelines of small frames, where the per-launch host
+ * cost exceeds the kernel (a 1080p decode is ~2 us of GPU time).  Decoders must have been set up
+ * (bt709hip_decoder_setup) before capture begins; do not wait inside a capture. */
+int bt709hip_graph_begin_capture(bt709hip_context *ctx, void *stream);
+int bt709hip_graph_end_capture(bt709hip_context *ctx, void *stream, void **graph);
+int bt709hip_graph_launch(bt709hip_context *ctx, void *graph, void *stream);
+int bt709hip_graph_destroy(bt709hip_context *ctx, void *graph);
+
 /* Device memory ~ make*Texture / fill* / get*TexturePixels
  * (MetalRenderContext.h:62-105).  upload/download are asynchronous on `stream`
  * (hipMemcpy2DAsync); host memory should be pinned for true overlap

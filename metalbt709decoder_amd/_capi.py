@@ -64,6 +64,10 @@ SYMBOLS = {
     "bt709hip_event_record": (_I, [_P, _P, _P]),
     "bt709hip_event_synchronize": (_I, [_P, _P]),
     "bt709hip_event_elapsed_ms": (_I, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "bt709hip_graph_begin_capture": (_I, [_P, _P]),
+    "bt709hip_graph_end_capture": (_I, [_P, _P, C.POINTER(C.c_void_p)]),
+    "bt709hip_graph_launch": (_I, [_P, _P, _P]),
+    "bt709hip_graph_destroy": (_I, [_P, _P]),
     "bt709hip_malloc": (_I, [_P, _Z, c_void_pp]),
     "bt709hip_free": (_I, [_P, _P]),
     "bt709hip_host_alloc": (_I, [_P, _Z, c_void_pp]),

@@ -313,6 +313,41 @@ int bt709hip_event_elapsed_ms(bt709hip_context *ctx, void *start, void *stop, fl
   return BT709HIP_OK;
 }
 
+int bt709hip_graph_begin_capture(bt709hip_context *ctx, void *stream) {
+  if (stream == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
+  return BT709HIP_OK;
+}
+
+int bt709hip_graph_end_capture(bt709hip_context *ctx, void *stream, void **graph) {
+  if (stream == nullptr || graph == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *graph = nullptr;
+  if (int rc = bind(ctx)) return rc;
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamEndCapture(static_cast<hipStream_t>(stream), &g));
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return hip_fail(e);
+  *graph = exec;
+  return BT709HIP_OK;
+}
+
+int bt709hip_graph_launch(bt709hip_context *ctx, void *graph, void *stream) {
+  if (graph == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(graph), pick(ctx, stream)));
+  return BT709HIP_OK;
+}
+
+int bt709hip_graph_destroy(bt709hip_context *ctx, void *graph) {
+  if (graph == nullptr) return BT709HIP_OK;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph)));
+  return BT709HIP_OK;
+}
+
 int bt709hip_malloc(bt709hip_context *ctx, size_t bytes, void **dptr) {
   if (dptr == nullptr) return BT709HIP_ERR_INVALID_ARG;
   *dptr = nullptr;

@@ -86,6 +86,32 @@ class CommandBuffer:
             self.ctx.lib.bt709hip_stream_destroy(self.ctx.handle, self.stream)
             self.stream = None
 
+    # A command buffer that is recorded once and replayed = a HIP graph (needs a stream of its own).
+    def beginRecording(self):
+        _capi.check(self.ctx.lib.bt709hip_graph_begin_capture(self.ctx.handle, self.stream), "begin capture")
+
+    def endRecording(self):
+        g = C.c_void_p()
+        _capi.check(self.ctx.lib.bt709hip_graph_end_capture(self.ctx.handle, self.stream, C.byref(g)), "end capture")
+        return RecordedCommands(self.ctx, g.value)
+
+
+class RecordedCommands:
+    """Everything issued on a command buffer between beginRecording and endRecording; replay()
+    re-issues it with one launch."""
+
+    def __init__(self, ctx, graph):
+        self.ctx, self.graph = ctx, graph
+
+    def replay(self, commandBuffer=None):
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        _capi.check(self.ctx.lib.bt709hip_graph_launch(self.ctx.handle, self.graph, stream), "graph launch")
+
+    def release(self):
+        if self.graph:
+            self.ctx.lib.bt709hip_graph_destroy(self.ctx.handle, self.graph)
+            self.graph = None
+
 
 class CommandQueue:
     def __init__(self, ctx):

@@ -347,6 +347,38 @@ def test_decode_is_idempotent_and_stateless(gh):
     assert np.array_equal(a1, a2)
 
 
+def test_recorded_command_buffer_replays(gh, oracle):
+    """Six single-frame decodes recorded into one graph (the HIP twin of a command buffer that is
+    encoded once): replaying it decodes whatever the input buffers hold at that moment."""
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    w, h, n = 128, 36, 6
+    frames = [gh.random_nv12(w, h, seed=400 + i) for i in range(n)]
+    bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
+    texs = [ctx.makeBGRATexture((w, h)) for _ in range(n)]
+    cb = ctx.commandQueue.commandBuffer(new_stream=True)
+    cb.beginRecording()
+    for b, t in zip(bufs, texs):
+        assert dec.decodeBT709(b, None, t, cb, None, w, h, False), dec.lastStatus
+    rec = cb.endRecording()
+    for t in texs:  # nothing ran during the recording
+        assert not ctx.getBGRATexturePixels(t).any()
+    rec.replay(cb)
+    cb.waitUntilCompleted()
+    for (y, c), t in zip(frames, texs):
+        assert np.array_equal(ctx.getBGRATexturePixels(t).view(np.uint8).reshape(h, w * 4), oracle.decode_nv12(0, y, c))
+    # new content in the same buffers, same recording
+    frames2 = [gh.random_nv12(w, h, seed=500 + i) for i in range(n)]
+    for b, (y, c) in zip(bufs, frames2):
+        b.upload_planes(y, c)
+    rec.replay(cb)
+    cb.waitUntilCompleted()
+    for (y, c), t in zip(frames2, texs):
+        assert np.array_equal(ctx.getBGRATexturePixels(t).view(np.uint8).reshape(h, w * 4), oracle.decode_nv12(0, y, c))
+    rec.release()
+    cb.release()
+
+
 # ------------------------------------------------------------------ fused 2:1 rescale
 
 @pytest.mark.parametrize("gamma", GAMMAS)

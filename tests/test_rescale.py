@@ -105,3 +105,57 @@ def test_gpu_scaled_rejects_alpha_decoder_and_bad_tags(gh):
     da = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
     assert not da.decodeBT709Scaled(srgb_tagged, ctx.makeBGRATexture((5, 3)), None, True)
     assert da.lastStatus == _capi.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rep", ["0", "1"])
+def test_fuzzed_rescale_geometry(gh, oracle, monkeypatch, rep):
+    """Seeded fuzz over the rescale entry points: any 4-multiple source size, any plane pitch and
+    byte alignment, any output pitch; exact 2:1 through the per-tile kernel (rep=0) or the persistent
+    one with a random workgroup count (rep=1), and an arbitrary output size through the bilinear
+    kernel.  Bytes must equal the oracle's and nothing outside the output rows may be written."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    lib, h = ctx.lib, ctx.handle
+    rng = np.random.default_rng(709 + int(rep))
+    monkeypatch.setenv("BT709HIP_HALF_REP", rep)
+    for case in range(40):
+        w = 4 * int(rng.integers(1, 120))
+        hgt = 4 * int(rng.integers(1, 12))
+        gamma = int(rng.integers(0, 4))
+        aligned = bool(rng.integers(0, 2))
+        ys = w + (int(rng.integers(0, 5)) * 4 if aligned else int(rng.integers(0, 37)))
+        cs = w + (int(rng.integers(0, 5)) * 4 if aligned else int(rng.integers(0, 37)))
+        oy, oc = (0, 0) if aligned else (int(rng.integers(0, 16)) for _ in range(2))
+        exact = bool(rng.integers(0, 2))
+        ow, oh = (w // 2, hgt // 2) if exact else (int(rng.integers(1, 2 * w)), int(rng.integers(1, 3 * hgt)))
+        os_ = 4 * ow + (int(rng.integers(0, 3)) * 8 if aligned else 4 * int(rng.integers(0, 9)))
+        oo = 0 if aligned else 4 * int(rng.integers(0, 4))
+        monkeypatch.setenv("BT709HIP_REP_WORKGROUPS", str(int(rng.integers(1, 300))))
+        dec = gh.make_decoder(gamma)
+        y, c = _frame(w, hgt, 2000 + case)
+
+        def plane(arr, pitch, off):
+            buf = DeviceBuffer(ctx, pitch * arr.shape[0] + off + 64)
+            ctx._upload(buf.ptr + off, pitch, np.ascontiguousarray(arr), None)
+            return buf, buf.ptr + off
+
+        by, py = plane(y, ys, oy)
+        bc, pc = plane(c, cs, oc)
+        src = mb.CVPixelBuffer(ctx, w, hgt, ys, cs, planes=(py, pc))
+        src.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2)
+        src.setAttachment("TransferFunction", gh.TRANSFER_FOR_GAMMA[dec.gamma])
+        out_bytes = os_ * oh + oo + 64
+        bo = DeviceBuffer(ctx, out_bytes)
+        _capi.check(lib.bt709hip_memset(h, bo.ptr, 0x5A, out_bytes, None))
+        ctx._sync(None)
+        tex = mb.BGRATexture(ctx, ow, oh, os_, ptr=bo.ptr + oo)
+        assert dec.decodeBT709Scaled(src, tex, None, True), (case, dec.lastStatus)
+        raw = np.empty(out_bytes, np.uint8)
+        _capi.check(lib.bt709hip_download(h, raw.ctypes.data, out_bytes, bo.ptr, out_bytes, out_bytes, 1, None))
+        ctx._sync(None)
+        rows = raw[oo:oo + os_ * oh].reshape(oh, os_)
+        want = oracle.decode_nv12_half(gamma, y, c) if exact else oracle.decode_nv12_scaled(gamma, y, c, ow, oh)
+        info = (case, w, hgt, ow, oh, gamma, exact, ys, cs, os_, oy, oc, oo, lib.bt709hip_last_kernel_name())
+        assert np.array_equal(rows[:, :4 * ow], want), info
+        assert (rows[:, 4 * ow:] == 0x5A).all() and (raw[:oo] == 0x5A).all() and (raw[oo + os_ * oh:] == 0x5A).all(), info
