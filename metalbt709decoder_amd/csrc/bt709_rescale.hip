@@ -315,13 +315,24 @@ decode_nv12_half_rep(const DecodeParams p) {
 // blockDim), ceil(OH / rows), frames)): the horizontal tap positions and weights are computed
 // once per lane, the vertical ones are uniform per row (scalar), and the 14 KiB of tables are
 // staged once per workgroup instead of once per 256 output pixels (the first version did that and
-// spent its time staging: 86 Gpixel/s whatever the size; prefetching the next row's taps was
-// tried and is slower).  Byte gathers (cached; PAIRS: a tap's Cb,Cr with one 2-byte load when the
-// CbCr plane is 2-byte aligned), 4-byte coalesced stores.
+// spent its time staging: 86 Gpixel/s whatever the size).  The next row's taps are fetched
+// before the current row's arithmetic, as widely as the layout allows (12 -> 8 loads per pixel was
+// worth +25 %; 8 -> 4 and the prefetch are neutral on random content, where the kernel is bound by
+// the bank conflicts of its single-copy tables like decode_nv12_half: 140-160 Gpixel/s for one
+// frame per launch against 200 for that kernel and 240 for the replicated-table one):
+//   TAPS_WIDE  (planes and strides 4-byte aligned, width % 4 == 0, width >= 8): per source row ONE
+//              aligned 8-byte load that contains both horizontal taps, and one v_perm_b32 with a
+//              per-lane selector (computed once) picks them out: 4 loads per output pixel;
+//   TAPS_PAIRS (CbCr plane 2-byte aligned): a tap's Cb,Cr with one 2-byte load: 8 loads;
+//   TAPS_BYTES any layout: 12 loads.
+// 4-byte coalesced stores.
 // ---------------------------------------------------------------------------
-template <bool PAIRS>
+enum : int { TAPS_BYTES = 0, TAPS_PAIRS = 1, TAPS_WIDE = 2 };
+
+template <int TAPS>
 __global__ void __launch_bounds__(kBlockThreads)
 decode_nv12_scaled(const DecodeParams p) {
+  typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);
   __syncthreads();
@@ -335,33 +346,77 @@ decode_nv12_scaled(const DecodeParams p) {
   const float fx = __fadd_rn(sx, -x0f), gx = __fadd_rn(1.0f, -fx);
   const int wmax = static_cast<int>(p.width) - 1, hmax = static_cast<int>(p.height) - 1;
   const int xi = static_cast<int>(x0f);
-  const int xs[2] = {min(max(xi, 0), wmax), min(max(xi + 1, 0), wmax)};
-  const uint32_t cx[2] = {2u * (static_cast<uint32_t>(xs[0]) >> 1), 2u * (static_cast<uint32_t>(xs[1]) >> 1)};
+  const uint32_t xs[2] = {static_cast<uint32_t>(min(max(xi, 0), wmax)), static_cast<uint32_t>(min(max(xi + 1, 0), wmax))};
+  const uint32_t cx[2] = {2u * (xs[0] >> 1), 2u * (xs[1] >> 1)};
+  // TAPS_WIDE: 8-byte windows [ybase, ybase + 8) and [cbase, cbase + 8) hold both taps of a row
+  const uint32_t ybase = min(xs[0] & ~3u, p.width - 8u), cbase = min(cx[0] & ~3u, p.width - 8u);
+  const uint32_t ysel = ((xs[1] - ybase) << 8) | (xs[0] - ybase);  // v_perm_b32 selector: {Y0, Y1, -, -}
+  const uint32_t k0 = cx[0] - cbase, k1 = cx[1] - cbase;
+  const uint32_t csel = ((k1 + 1u) << 24) | (k1 << 16) | ((k0 + 1u) << 8) | k0;  // {Cb0, Cr0, Cb1, Cr1}
 
-  const uint32_t oy0 = blockIdx.y * p.scaled_rows, oy1 = min(oy0 + p.scaled_rows, p.out_height);
-  for (uint32_t oy = oy0; oy < oy1; ++oy) {
+  // vertical taps of an output row: uniform, hence scalar
+  struct RowTaps {
+    int ys[2];
+    float fy;
+  };
+  auto row_taps = [&](uint32_t oy) {
+    RowTaps rt;
     const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy), 0.5f), p.scale_y), -0.5f);
     const float y0f = __builtin_floorf(sy);
-    const float fy = __fadd_rn(sy, -y0f), gy = __fadd_rn(1.0f, -fy);
+    rt.fy = __fadd_rn(sy, -y0f);
     const int yi = static_cast<int>(y0f);
-    const int ys[2] = {min(max(yi, 0), hmax), min(max(yi + 1, 0), hmax)};
-    const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+    rt.ys[0] = min(max(yi, 0), hmax);
+    rt.ys[1] = min(max(yi + 1, 0), hmax);
+    return rt;
+  };
+  // the source bytes of one output pixel: [row] = {Y0 | Y1 << 8, Cb0 | Cr0 << 8 | Cb1 << 16 | Cr1 << 24}
+  struct Fetched {
+    uint32_t yy[2], cc[2];
+  };
+  auto fetch = [&](const RowTaps &rt) {
+    Fetched v;
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+      const uint8_t *yrow = f.y + static_cast<size_t>(rt.ys[row]) * p.y_stride;
+      const uint8_t *crow = f.cbcr + static_cast<size_t>(rt.ys[row] >> 1) * p.cbcr_stride;
+      if (TAPS == TAPS_WIDE) {
+        const u32x2a4 yw = *reinterpret_cast<const u32x2a4 *>(yrow + ybase);
+        const u32x2a4 cw = *reinterpret_cast<const u32x2a4 *>(crow + cbase);
+        v.yy[row] = __builtin_amdgcn_perm(yw.y, yw.x, ysel);
+        v.cc[row] = __builtin_amdgcn_perm(cw.y, cw.x, csel);
+      } else {
+        v.yy[row] = yrow[xs[0]] | (static_cast<uint32_t>(yrow[xs[1]]) << 8);
+        if (TAPS == TAPS_PAIRS) {
+          v.cc[row] = *reinterpret_cast<const uint16_t *>(crow + cx[0]) |
+                      (static_cast<uint32_t>(*reinterpret_cast<const uint16_t *>(crow + cx[1])) << 16);
+        } else {
+          v.cc[row] = crow[cx[0]] | (static_cast<uint32_t>(crow[cx[0] + 1]) << 8) |
+                      (static_cast<uint32_t>(crow[cx[1]]) << 16) | (static_cast<uint32_t>(crow[cx[1] + 1]) << 24);
+        }
+      }
+    }
+    return v;
+  };
 
-    float x[12];  // tap t: x[3t] = R, x[3t + 1] = G, x[3t + 2] = B
+  const uint32_t oy0 = blockIdx.y * p.scaled_rows, oy1 = min(oy0 + p.scaled_rows, p.out_height);
+  RowTaps rt = row_taps(oy0);
+  Fetched cur = fetch(rt);
+  for (uint32_t oy = oy0; oy < oy1; ++oy) {
+    // the next row's taps go out before this row's arithmetic (uniform branch: not on the last row)
+    RowTaps nrt = rt;
+    Fetched nxt = cur;
+    if (oy + 1 < oy1) {
+      nrt = row_taps(oy + 1);
+      nxt = fetch(nrt);
+    }
+    const float fy = rt.fy, gy = __fadd_rn(1.0f, -fy);
+    const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+    float x[12];  // tap t = (row t >> 1, column t & 1): x[3t] = R, x[3t + 1] = G, x[3t + 2] = B
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const uint8_t *yrow = f.y + static_cast<size_t>(ys[t >> 1]) * p.y_stride;
-      const uint8_t *crow = f.cbcr + static_cast<size_t>(ys[t >> 1] >> 1) * p.cbcr_stride;
-      float cb, cr;
-      if (PAIRS) {
-        const uint32_t pair = *reinterpret_cast<const uint16_t *>(crow + cx[t & 1]);  // Cb low byte, Cr high
-        cb = byte_of(pair, 0);
-        cr = byte_of(pair, 1);
-      } else {
-        cb = byte_value(crow[cx[t & 1]]);
-        cr = byte_value(crow[cx[t & 1] + 1]);
-      }
-      pixel_rgb(byte_value(yrow[xs[t & 1]]), chroma_terms(cb, cr), x[3 * t], x[3 * t + 1], x[3 * t + 2]);
+      const uint32_t yy = cur.yy[t >> 1], cc = cur.cc[t >> 1];
+      const Chroma ch = (t & 1) ? chroma_terms(byte_of(cc, 2), byte_of(cc, 3)) : chroma_terms(byte_of(cc, 0), byte_of(cc, 1));
+      pixel_rgb((t & 1) ? byte_of(yy, 1) : byte_of(yy, 0), ch, x[3 * t], x[3 * t + 1], x[3 * t + 2]);
     }
     float lin[12];
     linearise12(r, x, lin);
@@ -376,6 +431,8 @@ decode_nv12_scaled(const DecodeParams p) {
     const uint32_t G = encode_byte(r, __fmul_rn(acc[1], r.scale));
     const uint32_t B = encode_byte(r, __fmul_rn(acc[2], r.scale));
     reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, p.alpha_word);
+    cur = nxt;
+    rt = nrt;
   }
 }
 
@@ -443,11 +500,22 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, uint32_t 
   p.scaled_rows = rows;
   const dim3 grid(cols, (p.out_height + rows - 1) / rows, static_cast<uint32_t>(frames));
   const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes;
-  bool pairs = (p.cbcr_stride % 2) == 0;
-  for (int i = 0; i < frames && i < kMaxBatch; ++i) pairs = pairs && (reinterpret_cast<uintptr_t>(p.frames[i].cbcr) % 2) == 0;
-  if (p.uniform) pairs = pairs && (p.step_cbcr % 2) == 0;
-  if (pairs) hipLaunchKernelGGL(decode_nv12_scaled<true>, grid, dim3(kBlockThreads), lds, stream, p);
-  else hipLaunchKernelGGL(decode_nv12_scaled<false>, grid, dim3(kBlockThreads), lds, stream, p);
+  // widest tap fetch the layout allows (see the kernel)
+  uint32_t align = 4;
+  auto fold = [&align](uintptr_t v) { while (align > 1 && v % align) align /= 2; };
+  fold(p.y_stride);
+  fold(p.cbcr_stride);
+  for (int i = 0; i < frames && i < kMaxBatch; ++i) {
+    fold(reinterpret_cast<uintptr_t>(p.frames[i].y));
+    fold(reinterpret_cast<uintptr_t>(p.frames[i].cbcr));
+  }
+  if (p.uniform) fold(static_cast<uintptr_t>(p.step_y)), fold(static_cast<uintptr_t>(p.step_cbcr));
+  if (align == 4 && p.width % 4 == 0 && p.width >= 8)
+    hipLaunchKernelGGL(decode_nv12_scaled<TAPS_WIDE>, grid, dim3(kBlockThreads), lds, stream, p);
+  else if (align >= 2 || ((p.cbcr_stride % 2) == 0 && (reinterpret_cast<uintptr_t>(p.frames[0].cbcr) % 2) == 0 && frames == 1))
+    hipLaunchKernelGGL(decode_nv12_scaled<TAPS_PAIRS>, grid, dim3(kBlockThreads), lds, stream, p);
+  else
+    hipLaunchKernelGGL(decode_nv12_scaled<TAPS_BYTES>, grid, dim3(kBlockThreads), lds, stream, p);
   return "decode_nv12_scaled";
 }
 
@@ -459,8 +527,9 @@ hipError_t prepare_rescale_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_half<false, false>),
       reinterpret_cast<const void *>(&decode_nv12_half_rep<true, BT709_REP_STEP>),
       reinterpret_cast<const void *>(&decode_nv12_half_rep<false, BT709_REP_STEP>),
-      reinterpret_cast<const void *>(&decode_nv12_scaled<true>),
-      reinterpret_cast<const void *>(&decode_nv12_scaled<false>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_BYTES>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_PAIRS>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_WIDE>),
   };
   for (const void *fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
