@@ -51,6 +51,16 @@ class MetalRenderContext {
     return s;
   }
   void releaseCommandBuffer(void *s) { bt709hip_stream_destroy(ctx_, s); }
+  // a command buffer that is encoded once and replayed: everything issued on `s` between the two
+  // calls is recorded into a HIP graph instead of executed
+  bool beginRecording(void *s) { return (lastStatus_ = bt709hip_graph_begin_capture(ctx_, s)) == BT709HIP_OK; }
+  void *endRecording(void *s) {
+    void *g = nullptr;
+    lastStatus_ = bt709hip_graph_end_capture(ctx_, s, &g);
+    return g;
+  }
+  bool replay(void *recorded, void *s) { return (lastStatus_ = bt709hip_graph_launch(ctx_, recorded, s)) == BT709HIP_OK; }
+  void releaseRecording(void *recorded) { bt709hip_graph_destroy(ctx_, recorded); }
   bool waitUntilCompleted(void *s) { return bt709hip_stream_synchronize(ctx_, s) == BT709HIP_OK; }
 
  private:
@@ -194,11 +204,18 @@ class MetalBT709Decoder {
     return rc == BT709HIP_OK ? ok() : fail(rc);
   }
 
-  // decode + MetalScaleRenderContext -renderScaled: fused for the exact 2:1 ratio
+  // -decodeBT709 into an intermediate + MetalScaleRenderContext -renderScaled: (AAPLRenderer.m:940-977), fused:
+  // the tuned kernels for the exact 2:1 ratio, the bilinear kernel for any other view size (bit-identical where
+  // both apply).
   bool decodeBT709Scaled(const CVPixelBuffer *in, const BGRATexture *out, void *commandBuffer,
                          bool waitUntilCompleted) {
     if (!setupMetal()) return false;
-    const int rc = bt709hip_decode_half(dec_, in->frame(), out->surface(), commandBuffer, waitUntilCompleted ? 1 : 0);
+    if (in == nullptr || out == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
+    const bt709hip_frame *f = in->frame();
+    const bt709hip_surface *s = out->surface();
+    const bool exact_half = 2 * s->width == f->width && 2 * s->height == f->height && f->width % 4 == 0 && f->height % 4 == 0;
+    const int rc = exact_half ? bt709hip_decode_half(dec_, f, s, commandBuffer, waitUntilCompleted ? 1 : 0)
+                              : bt709hip_decode_scaled(dec_, f, s, commandBuffer, waitUntilCompleted ? 1 : 0);
     return rc == BT709HIP_OK ? ok() : fail(rc);
   }
 
