@@ -143,7 +143,13 @@ decode_nv12_quads(const DecodeParams p) {
   // address arithmetic).
   const uint32_t rp_raw = blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
   const uint32_t rp = min(rp_raw, row_pairs - 1);
+#if defined(BT709_LAB_ADJACENT)  // tools/decode_lab only: a lane owns UNROLL ADJACENT quads (8-byte loads, 32-byte store runs)
+  const uint32_t q0 = (blockIdx.x * blockDim.x + threadIdx.x) * UNROLL;
+#define BT709_QUAD_OF(u) (q0 + (u))
+#else
   const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
+#define BT709_QUAD_OF(u) (q0 + (u) * blockDim.x)
+#endif
 
   const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
   const uint8_t *y1 = y0 + p.y_stride;
@@ -159,7 +165,7 @@ decode_nv12_quads(const DecodeParams p) {
   uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
-    const uint32_t q = min(q0 + u * blockDim.x, quads - 1);
+    const uint32_t q = min(BT709_QUAD_OF(u), quads - 1);
     ya[u] = load32<NT>(y0 + 4 * q);
     yb[u] = load32<NT>(y1 + 4 * q);
 #if !defined(BT709_LAB_LDS_CHROMA)
@@ -204,7 +210,7 @@ decode_nv12_quads(const DecodeParams p) {
   const UnitLookup ul = unit_lookup(p, lds_raw);
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
-    const uint32_t q = q0 + u * blockDim.x;
+    const uint32_t q = BT709_QUAD_OF(u);
     u32x4 top, bot;
     decode_quad<HAS_ALPHA>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
                            bot);
