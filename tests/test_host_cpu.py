@@ -120,6 +120,16 @@ def test_decoder_without_context(lib):
     assert lib.bt709hip_decoder_create(None, 9, 0, C.byref(d)) == _capi.ERR_INVALID_ARG
 
 
+def test_graph_entry_points_reject_bad_arguments(lib):
+    """No device needed: argument checks come first, and a NULL context never reaches HIP."""
+    g = C.c_void_p()
+    assert lib.bt709hip_graph_begin_capture(None, None) == _capi.ERR_INVALID_ARG   # capture needs a created stream
+    assert lib.bt709hip_graph_begin_capture(None, 1) == _capi.ERR_INVALID_ARG      # ... and a context
+    assert lib.bt709hip_graph_end_capture(None, None, C.byref(g)) == _capi.ERR_INVALID_ARG and not g.value
+    assert lib.bt709hip_graph_launch(None, None, None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_graph_destroy(None, None) == 0                              # destroying nothing is fine
+
+
 def test_strerror_covers_every_status(lib):
     seen = set()
     for code in range(0, -12, -1):
