@@ -206,6 +206,34 @@ def test_isa_memory_shape(asm):
     assert meta and int(meta.group(1)) <= 64                # 8 waves per SIMD
 
 
+def test_isa_valu_budget_contract(asm):
+    """The cycle-count decisions of DESIGN 6.0 hold in the generated code: bytes become floats with
+    v_cvt_f32_ubyte (not the integer SDWA add + v_cvt_f32_i32 hipcc prefers), bucket indices come
+    from the round-toward-zero magic add (no v_cvt_u32_f32 in the 1:1 kernel), and every switch
+    of the rounding mode is undone inside the same asm statement."""
+    quads = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1EE")
+    assert len(re.findall(r"\bv_cvt_f32_ubyte[0-3]", quads)) == 24          # 16 luma + 8 chroma bytes per 16 pixels
+    assert not re.search(r"\bv_cvt_f32_i32|\bv_cvt_u32_f32|\bv_add_u32_sdwa", quads)
+    assert len(re.findall(r"v_add_f32_e64 .* clamp", quads)) == 48            # saturation rides on the adds
+    n = 0
+    for kernel in ("17decode_nv12_quads", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
+                   "18decode_nv12_scaled", "16encode_bgra_nv12", "23encode_bgra_nv12_blocks"):
+        for body in _kernel_bodies(asm, kernel):
+            to_zero = len(re.findall(r"s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 0, 2\), 3", body))
+            to_even = len(re.findall(r"s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 0, 2\), 0", body))
+            assert to_zero == to_even and to_zero > 0, kernel
+            # between a switch and its undo there is nothing but the instructions of that asm statement
+            for block in re.findall(r"HW_REG_MODE, 0, 2\), 3\n(.*?)s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 0, 2\), 0", body, flags=re.S):
+                ops = {line.split()[0] for line in block.strip().split("\n") if line.strip()}
+                assert ops <= {"v_add_f32", "v_cvt_pk_u8_f32"}, (kernel, ops)
+            n += 1
+    assert n == 15
+    rep = _kernel_body(asm, "20decode_nv12_half_repILb1E")
+    assert "ds_read_b128" in rep and not re.search(r"\bv_cvt_u32_f32\b.*\n.*v_and_or", rep)
+    enc = _kernel_body(asm, "16encode_bgra_nv12E")
+    assert enc.count("v_cvt_pk_u8_f32") == 12 and enc.count("v_lshlrev_b32_sdwa") == 24
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.dirname(mb.__file__)
     for dirpath, _, files in os.walk(pkg):
