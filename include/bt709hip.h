@@ -43,6 +43,7 @@ extern "C" {
 
 typedef struct bt709hip_context bt709hip_context; /* ~ MetalRenderContext */
 typedef struct bt709hip_decoder bt709hip_decoder; /* ~ MetalBT709Decoder  */
+typedef struct bt709hip_pool bt709hip_pool;       /* ~ CVPixelBufferPool + texture cache + in-flight semaphore */
 
 typedef enum {
   BT709HIP_OK = 0,
@@ -237,6 +238,23 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count,
  * hardware (AAPLShaders.metal:73-85), so the definition is ours ("rescale"). */
 int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
                            void *stream, int wait_until_completed);
+
+/* --------------------------------------------------------------- frame pool */
+/* Frames that live in HOST memory.  The reference hands the decoder CVPixelBuffers the GPU reads
+ * in place (unified memory) and keeps MaxBuffersInFlight = 3 frames in flight behind a semaphore
+ * (AAPLRenderer.m:34, 891-977); a discrete GPU needs the copies, so the pool owns, per in-flight
+ * slot, one HIP stream, pinned host staging and device buffers:
+ *   acquire  -> pointers to the slot's pinned Y / CbCr planes (waits for the slot's previous frame)
+ *   submit   -> upload, decode, download enqueued on the slot's stream; returns at once
+ *   wait     -> the slot's pinned BGRA rows, valid until the slot is acquired again
+ * Slots are handed out round-robin, so `depth` frames overlap their copies and kernels.  The decoder
+ * must not have an alpha channel. */
+int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth, bt709hip_pool **out);
+int bt709hip_pool_destroy(bt709hip_pool *pool);
+int bt709hip_pool_acquire(bt709hip_pool *pool, int *slot, void **y, size_t *y_stride, void **cbcr,
+                          size_t *cbcr_stride);
+int bt709hip_pool_submit(bt709hip_pool *pool, int slot);
+int bt709hip_pool_wait(bt709hip_pool *pool, int slot, const void **bgra, size_t *stride);
 
 /* ------------------------------------------------------------------ encoder */
 /* The step before the decode path, on the GPU: 8-bit BGRA -> NV12 BT.709 video range with

@@ -64,6 +64,12 @@ SYMBOLS = {
     "bt709hip_event_record": (_I, [_P, _P, _P]),
     "bt709hip_event_synchronize": (_I, [_P, _P]),
     "bt709hip_event_elapsed_ms": (_I, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "bt709hip_pool_create": (_I, [_P, _I, _I, _I, C.POINTER(C.c_void_p)]),
+    "bt709hip_pool_destroy": (_I, [_P]),
+    "bt709hip_pool_acquire": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "bt709hip_pool_submit": (_I, [_P, _I]),
+    "bt709hip_pool_wait": (_I, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bt709hip_graph_begin_capture": (_I, [_P, _P]),
     "bt709hip_graph_end_capture": (_I, [_P, _P, C.POINTER(C.c_void_p)]),
     "bt709hip_graph_launch": (_I, [_P, _P, _P]),

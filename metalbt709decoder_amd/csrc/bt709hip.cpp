@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <mutex>
 #include <new>
 
@@ -58,6 +59,21 @@ struct bt709hip_decoder {
   uint32_t encode_bytes = 0;
   uint32_t encode_n = 0;
   uint32_t encode_offset = 0, encode_shift = 0;
+};
+
+struct bt709hip_pool {
+  struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t *h_in = nullptr, *h_out = nullptr;  // pinned
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    bool busy = false;       // submitted, not yet waited for
+    bool acquired = false;   // handed out, not yet submitted
+  };
+  bt709hip_decoder *dec = nullptr;
+  int width = 0, height = 0;
+  size_t in_bytes = 0, out_bytes = 0;
+  std::vector<Slot> slots;
+  size_t next = 0;
 };
 
 namespace {
@@ -660,6 +676,121 @@ int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, c
 int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
                          void *stream, int wait_until_completed) {
   return bt709hip_decode_half_batch(dec, 1, frame, out, stream, wait_until_completed);
+}
+
+// ------------------------------------------------------------------ frame pool
+
+int bt709hip_pool_destroy(bt709hip_pool *pool) {
+  if (pool == nullptr) return BT709HIP_OK;
+  if (pool->dec && pool->dec->ctx && hipSetDevice(pool->dec->ctx->device) == hipSuccess) {
+    for (auto &s : pool->slots) {
+      if (s.stream) (void)hipStreamSynchronize(s.stream), (void)hipStreamDestroy(s.stream);
+      if (s.h_in) (void)hipHostFree(s.h_in);
+      if (s.h_out) (void)hipHostFree(s.h_out);
+      if (s.d_in) (void)hipFree(s.d_in);
+      if (s.d_out) (void)hipFree(s.d_out);
+    }
+  }
+  delete pool;
+  return BT709HIP_OK;
+}
+
+int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth, bt709hip_pool **out) {
+  if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (dec == nullptr || width <= 0 || height <= 0 || depth <= 0 || depth > 64) return BT709HIP_ERR_INVALID_ARG;
+  if ((width & 1) || (height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;
+  if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;
+  if (int rc = bt709hip_decoder_setup(dec)) return rc;
+  if (int rc = bind(dec->ctx)) return rc;
+  bt709hip_pool *pool = new (std::nothrow) bt709hip_pool();
+  if (pool == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  pool->dec = dec;
+  pool->width = width;
+  pool->height = height;
+  pool->in_bytes = static_cast<size_t>(width) * height * 3 / 2;
+  pool->out_bytes = static_cast<size_t>(width) * height * 4;
+  pool->slots.resize(static_cast<size_t>(depth));
+  hipError_t e = hipSuccess;
+  for (auto &s : pool->slots) {
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), pool->in_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), pool->out_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_in), pool->in_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_out), pool->out_bytes);
+  }
+  if (e != hipSuccess) {
+    bt709hip_pool_destroy(pool);
+    return hip_fail(e);
+  }
+  *out = pool;
+  return BT709HIP_OK;
+}
+
+int bt709hip_pool_acquire(bt709hip_pool *pool, int *slot, void **y, size_t *y_stride, void **cbcr,
+                          size_t *cbcr_stride) {
+  if (pool == nullptr || slot == nullptr || y == nullptr || cbcr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(pool->dec->ctx)) return rc;
+  const size_t i = pool->next;
+  bt709hip_pool::Slot &s = pool->slots[i];
+  if (s.acquired) return BT709HIP_ERR_INVALID_ARG;  // every slot is out: submit one first
+  if (s.busy) {
+    HIP_TRY(hipStreamSynchronize(s.stream));  // the in-flight semaphore of the reference
+    s.busy = false;
+  }
+  s.acquired = true;
+  pool->next = (i + 1) % pool->slots.size();
+  *slot = static_cast<int>(i);
+  *y = s.h_in;
+  *cbcr = s.h_in + static_cast<size_t>(pool->width) * pool->height;
+  if (y_stride) *y_stride = static_cast<size_t>(pool->width);
+  if (cbcr_stride) *cbcr_stride = static_cast<size_t>(pool->width);
+  return BT709HIP_OK;
+}
+
+int bt709hip_pool_submit(bt709hip_pool *pool, int slot) {
+  if (pool == nullptr || slot < 0 || static_cast<size_t>(slot) >= pool->slots.size()) return BT709HIP_ERR_INVALID_ARG;
+  bt709hip_pool::Slot &s = pool->slots[static_cast<size_t>(slot)];
+  if (!s.acquired) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(pool->dec->ctx)) return rc;
+  const int w = pool->width, h = pool->height;
+  HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, pool->in_bytes, hipMemcpyHostToDevice, s.stream));
+  bt709hip_frame f;
+  std::memset(&f, 0, sizeof f);
+  f.y = s.d_in;
+  f.y_stride = static_cast<size_t>(w);
+  f.cbcr = s.d_in + static_cast<size_t>(w) * h;
+  f.cbcr_stride = static_cast<size_t>(w);
+  f.width = w;
+  f.height = h;
+  f.matrix = BT709HIP_MATRIX_ITU_R_709_2;
+  f.transfer = required_transfer(pool->dec->gamma);
+  bt709hip_surface o;
+  std::memset(&o, 0, sizeof o);
+  o.bgra = s.d_out;
+  o.stride = static_cast<size_t>(w) * 4;
+  o.width = w;
+  o.height = h;
+  if (int rc = bt709hip_decode(pool->dec, &f, nullptr, &o, w, h, s.stream, 0)) return rc;
+  HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, pool->out_bytes, hipMemcpyDeviceToHost, s.stream));
+  s.acquired = false;
+  s.busy = true;
+  return BT709HIP_OK;
+}
+
+int bt709hip_pool_wait(bt709hip_pool *pool, int slot, const void **bgra, size_t *stride) {
+  if (pool == nullptr || slot < 0 || static_cast<size_t>(slot) >= pool->slots.size() || bgra == nullptr)
+    return BT709HIP_ERR_INVALID_ARG;
+  bt709hip_pool::Slot &s = pool->slots[static_cast<size_t>(slot)];
+  if (s.acquired) return BT709HIP_ERR_INVALID_ARG;  // acquired but never submitted
+  if (int rc = bind(pool->dec->ctx)) return rc;
+  if (s.busy) {
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.busy = false;
+  }
+  *bgra = s.h_out;
+  if (stride) *stride = static_cast<size_t>(pool->width) * 4;
+  return BT709HIP_OK;
 }
 
 // ------------------------------------------------------------------ encoder

@@ -96,6 +96,49 @@ class CommandBuffer:
         return RecordedCommands(self.ctx, g.value)
 
 
+class InFlightFramePool:
+    """`depth` frames in flight between host memory and the GPU, one HIP stream each (the reference
+    keeps MaxBuffersInFlight = 3 behind a semaphore, AAPLRenderer.m:34; its CVPixelBuffers are read by
+    the GPU in place, a discrete GPU needs the copies the pool owns)."""
+
+    def __init__(self, decoder, size, depth=3):
+        import numpy as np
+        self._np = np
+        self.decoder, (self.width, self.height), self.depth = decoder, size, depth
+        self.lib = decoder.metalRenderContext.lib
+        if not decoder.setupMetal():
+            raise RuntimeError("decoder setup failed: %s" % decoder.lastStatus)
+        h = C.c_void_p()
+        _capi.check(self.lib.bt709hip_pool_create(decoder._handle, self.width, self.height, depth, C.byref(h)), "pool create")
+        self.handle = h
+
+    def acquire(self):
+        """-> (slot, y, cbcr): writable numpy views of the slot's pinned planes."""
+        slot, y, c = C.c_int(), C.c_void_p(), C.c_void_p()
+        ys, cs = C.c_size_t(), C.c_size_t()
+        _capi.check(self.lib.bt709hip_pool_acquire(self.handle, C.byref(slot), C.byref(y), C.byref(ys), C.byref(c), C.byref(cs)),
+                    "pool acquire")
+        np, w, h = self._np, self.width, self.height
+        yv = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_uint8)), shape=(h, ys.value))[:, :w]
+        cv = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_uint8)), shape=(h // 2, cs.value))[:, :w]
+        return slot.value, yv, cv
+
+    def submit(self, slot):
+        _capi.check(self.lib.bt709hip_pool_submit(self.handle, slot), "pool submit")
+
+    def wait(self, slot):
+        """-> (H, W*4) uint8 view of the slot's pinned BGRA rows (valid until the slot is acquired again)."""
+        p, stride = C.c_void_p(), C.c_size_t()
+        _capi.check(self.lib.bt709hip_pool_wait(self.handle, slot, C.byref(p), C.byref(stride)), "pool wait")
+        a = self._np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.height, stride.value))
+        return a[:, :self.width * 4]
+
+    def release(self):
+        if self.handle:
+            self.lib.bt709hip_pool_destroy(self.handle)
+            self.handle = None
+
+
 class RecordedCommands:
     """Everything issued on a command buffer between beginRecording and endRecording; replay()
     re-issues it with one launch."""

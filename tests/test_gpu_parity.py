@@ -7,6 +7,8 @@ BT.709, copy packed pixels in, -decodeBT709:... waitUntilCompleted, read the tex
 """
 import hashlib
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -345,6 +347,36 @@ def test_decode_is_idempotent_and_stateless(gh):
     gh.gpu_decode(yb, cb, decoder=dec)
     a2 = gh.gpu_decode(ya, ca, decoder=dec)
     assert np.array_equal(a1, a2)
+
+
+@pytest.mark.parametrize("gamma", [mb.MetalBT709GammaApple, mb.MetalBT709GammaSRGB])
+def test_in_flight_frame_pool(gh, oracle, gamma):
+    """Host frames through the pool: 3 slots, 8 frames, every frame submitted before the oldest is
+    waited for; each result equals the oracle's and slots are recycled in order."""
+    dec = gh.make_decoder(gamma)
+    w, h, depth = 200, 34, 3
+    pool = mb.InFlightFramePool(dec, (w, h), depth)
+    frames = [gh.random_nv12(w, h, seed=700 + i) for i in range(8)]
+    pending = []
+    for i, (y, c) in enumerate(frames):
+        if len(pending) == depth:  # the oldest frame's slot is about to be reused: collect it first
+            j, slot = pending.pop(0)
+            assert np.array_equal(pool.wait(slot), oracle.decode_nv12(gamma, *frames[j])), j
+        slot, ybuf, cbuf = pool.acquire()
+        assert slot == i % depth
+        ybuf[:], cbuf[:] = y, c
+        pool.submit(slot)
+        pending.append((i, slot))
+    for j, slot in pending:
+        assert np.array_equal(pool.wait(slot), oracle.decode_nv12(gamma, *frames[j])), j
+    # misuse is reported, not executed
+    lib = gh.context().lib
+    assert lib.bt709hip_pool_submit(pool.handle, 0) == _capi.ERR_INVALID_ARG      # not acquired
+    assert lib.bt709hip_pool_submit(pool.handle, 99) == _capi.ERR_INVALID_ARG
+    pool.release()
+    da = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
+    hnd = C.c_void_p()
+    assert lib.bt709hip_pool_create(da._handle, 64, 32, 2, C.byref(hnd)) == _capi.ERR_UNSUPPORTED
 
 
 def test_recorded_command_buffer_replays(gh, oracle):

@@ -120,6 +120,21 @@ def test_decoder_without_context(lib):
     assert lib.bt709hip_decoder_create(None, 9, 0, C.byref(d)) == _capi.ERR_INVALID_ARG
 
 
+def test_pool_entry_points_reject_bad_arguments(lib):
+    h, slot, y, c = C.c_void_p(), C.c_int(), C.c_void_p(), C.c_void_p()
+    assert lib.bt709hip_pool_create(None, 64, 32, 2, C.byref(h)) == _capi.ERR_INVALID_ARG and not h.value
+    d = C.c_void_p()
+    assert lib.bt709hip_decoder_create(None, 0, 0, C.byref(d)) == 0
+    assert lib.bt709hip_pool_create(d, 63, 32, 2, C.byref(h)) == _capi.ERR_ODD_DIMENSIONS
+    assert lib.bt709hip_pool_create(d, 64, 32, 0, C.byref(h)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_pool_create(d, 64, 32, 2, C.byref(h)) == _capi.ERR_NOT_SETUP      # decoder has no context
+    lib.bt709hip_decoder_destroy(d)
+    assert lib.bt709hip_pool_acquire(None, C.byref(slot), C.byref(y), None, C.byref(c), None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_pool_submit(None, 0) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_pool_wait(None, 0, C.byref(y), None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_pool_destroy(None) == 0
+
+
 def test_graph_entry_points_reject_bad_arguments(lib):
     """No device needed: argument checks come first, and a NULL context never reaches HIP."""
     g = C.c_void_p()

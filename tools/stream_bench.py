@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""BASELINE config 2 as a real stream: host frames in, host frames out, one HIP stream per
-in-flight frame (upload Y + CbCr with hipMemcpy2DAsync from pinned memory, decode, download
-BGRA), `--inflight` frames pipelined.  Reports the PCIe-INCLUSIVE rate, which is never the
+"""BASELINE config 2 as a real stream: host frames in, host frames out through the C ABI's frame
+pool (bt709hip_pool_*: one HIP stream per in-flight frame, pinned staging, upload -> decode ->
+download per slot), `--inflight` frames pipelined.  Reports the PCIe-INCLUSIVE rate, which is never the
 headline `value` of bench.py (that one is HBM-resident); DESIGN.md quotes this number.
 
     python tools/stream_bench.py [--width 1920 --height 1080] [--frames 600] [--inflight 4]
@@ -21,7 +21,6 @@ import numpy as np  # noqa: E402
 
 import metalbt709decoder_amd as mb  # noqa: E402
 from metalbt709decoder_amd import _capi  # noqa: E402
-from metalbt709decoder_amd._capi import Frame, Surface  # noqa: E402
 
 
 def main():
@@ -41,21 +40,7 @@ def main():
     assert dec.setupMetal()
 
     in_bytes, out_bytes = W * H * 3 // 2, W * H * 4
-    slots = []
-    for k in range(K):
-        s = C.c_void_p()
-        _capi.check(lib.bt709hip_stream_create(h, C.byref(s)))
-        hin, hout, din, dout = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _capi.check(lib.bt709hip_host_alloc(h, in_bytes, C.byref(hin)))
-        _capi.check(lib.bt709hip_host_alloc(h, out_bytes, C.byref(hout)))
-        _capi.check(lib.bt709hip_malloc(h, in_bytes, C.byref(din)))
-        _capi.check(lib.bt709hip_malloc(h, out_bytes, C.byref(dout)))
-        hin_np = np.ctypeslib.as_array(C.cast(hin, C.POINTER(C.c_uint8)), shape=(in_bytes,))
-        hout_np = np.ctypeslib.as_array(C.cast(hout, C.POINTER(C.c_uint8)), shape=(out_bytes,))
-        frame = Frame(din.value, W, din.value + W * H, W, W, H, 1, 1)
-        surf = Surface(dout.value, W * 4, W, H)
-        slots.append(dict(stream=s, hin=hin, hout=hout, din=din, dout=dout, hin_np=hin_np, hout_np=hout_np,
-                          frame=frame, surf=surf, pending=None))
+    pool = mb.InFlightFramePool(dec, (W, H), K)   # bt709hip_pool_*: per slot a stream, pinned staging, device buffers
 
     # a ring of distinct source frames in ordinary host memory (the "decoder output" of a real pipeline)
     ring = [np.random.default_rng(0x709 + i).integers(0, 256, in_bytes, dtype=np.uint8) for i in range(16)]
@@ -64,44 +49,37 @@ def main():
         from oracle_lib import Oracle
         oracle = Oracle()
     checked = 0
+    pending = []  # (frame number, slot), oldest first
 
-    def retire(slot):
+    def retire():
         nonlocal checked
-        _capi.check(lib.bt709hip_stream_synchronize(h, slot["stream"]))
-        n = slot["pending"]
+        n, slot = pending.pop(0)
+        out = pool.wait(slot)
         if oracle is not None and n % args.check_every == 0:
             src = ring[n % len(ring)]
             want = oracle.decode_nv12(0, src[:W * H].reshape(H, W)[:16], src[W * H:].reshape(H // 2, W)[:8])
-            assert np.array_equal(slot["hout_np"][:16 * W * 4].reshape(16, W * 4), want), "frame %d differs" % n
+            assert np.array_equal(out[:16], want), "frame %d differs" % n
             checked += 1
-        slot["pending"] = None
 
-    def submit(slot, n):
-        slot["hin_np"][:] = ring[n % len(ring)]  # host copy into pinned memory (part of a real pipeline too)
-        s = slot["stream"]
-        _capi.check(lib.bt709hip_upload(h, slot["din"], in_bytes, slot["hin"], in_bytes, in_bytes, 1, s))
-        rc = lib.bt709hip_decode(dec._handle, C.byref(slot["frame"]), None, C.byref(slot["surf"]), W, H, s, 0)
-        _capi.check(rc, "decode")
-        _capi.check(lib.bt709hip_download(h, slot["hout"], out_bytes, slot["dout"], out_bytes, out_bytes, 1, s))
-        slot["pending"] = n
+    def submit(n):
+        if len(pending) == K:
+            retire()
+        slot, ybuf, cbuf = pool.acquire()
+        src = ring[n % len(ring)]
+        ybuf[:] = src[:W * H].reshape(H, W)              # host copy into pinned memory (part of a real pipeline too)
+        cbuf[:] = src[W * H:].reshape(H // 2, W)
+        pool.submit(slot)
+        pending.append((n, slot))
 
     for n in range(2 * K):  # warm-up
-        slot = slots[n % K]
-        if slot["pending"] is not None:
-            retire(slot)
-        submit(slot, n)
-    for slot in slots:
-        if slot["pending"] is not None:
-            retire(slot)
+        submit(n)
+    while pending:
+        retire()
     t0 = time.perf_counter()
     for n in range(args.frames):
-        slot = slots[n % K]
-        if slot["pending"] is not None:
-            retire(slot)
-        submit(slot, n)
-    for slot in slots:
-        if slot["pending"] is not None:
-            retire(slot)
+        submit(n)
+    while pending:
+        retire()
     dt = time.perf_counter() - t0
     fps = args.frames / dt
     print(json.dumps({
