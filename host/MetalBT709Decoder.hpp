@@ -219,6 +219,8 @@ class MetalBT709Decoder {
     return rc == BT709HIP_OK ? ok() : fail(rc);
   }
 
+  bt709hip_decoder *handle() const { return dec_; }
+
  private:
   bool ok() {
     lastStatus_ = BT709HIP_OK;
@@ -230,6 +232,42 @@ class MetalBT709Decoder {
     return false;
   }
   bt709hip_decoder *dec_ = nullptr;
+  int lastStatus_ = BT709HIP_OK;
+};
+
+// `depth` frames in flight between host memory and the GPU, one HIP stream each: the role of
+// CVPixelBufferPool + the texture cache + the renderer's in-flight semaphore (AAPLRenderer.m:34).
+class InFlightFramePool {
+ public:
+  InFlightFramePool(MetalBT709Decoder &decoder, int width, int height, int depth = 3) {
+    if (decoder.setupMetal()) lastStatus_ = bt709hip_pool_create(decoder.handle(), width, height, depth, &pool_);
+    else lastStatus_ = decoder.lastStatus();
+  }
+  ~InFlightFramePool() { bt709hip_pool_destroy(pool_); }
+  InFlightFramePool(const InFlightFramePool &) = delete;
+  InFlightFramePool &operator=(const InFlightFramePool &) = delete;
+  bool valid() const { return pool_ != nullptr; }
+  int lastStatus() const { return lastStatus_; }
+
+  // pinned planes of the next slot (waits for that slot's previous frame); returns the slot or -1
+  int acquire(uint8_t **y, size_t *yStride, uint8_t **cbcr, size_t *cbcrStride) {
+    int slot = -1;
+    void *py = nullptr, *pc = nullptr;
+    lastStatus_ = bt709hip_pool_acquire(pool_, &slot, &py, yStride, &pc, cbcrStride);
+    *y = static_cast<uint8_t *>(py);
+    *cbcr = static_cast<uint8_t *>(pc);
+    return lastStatus_ == BT709HIP_OK ? slot : -1;
+  }
+  bool submit(int slot) { return (lastStatus_ = bt709hip_pool_submit(pool_, slot)) == BT709HIP_OK; }
+  // pinned BGRA rows of a submitted slot, valid until the slot is acquired again
+  const uint8_t *wait(int slot, size_t *stride) {
+    const void *p = nullptr;
+    lastStatus_ = bt709hip_pool_wait(pool_, slot, &p, stride);
+    return static_cast<const uint8_t *>(p);
+  }
+
+ private:
+  bt709hip_pool *pool_ = nullptr;
   int lastStatus_ = BT709HIP_OK;
 };
 
