@@ -13,8 +13,9 @@
 // Er = (R-Ey)/1.5748f, Y = round(Ey*219 + 16), C = round(E*224 + 128).
 //
 // Exactness notes:
-//   * the per-byte LUT already holds the float product K_c * byteNorm(encoded byte), so a pixel's
-//     Ey is two adds;
+//   * the per-byte LUT holds {lin, byteNorm(encoded byte)} -- one 2 KiB table for the three channels
+//     (a 6 KiB version with the K_c products folded in saved three 2-cycle multiplies per pixel and
+//     cost 4 KiB more staging per workgroup);
 //   * x / c for the two constant divisors is computed as q0 = x*rc, q = fma(fma(-c, q0, x), rc, q0)
 //     with rc = fl(1/c): this equals the correctly rounded quotient for EVERY float with
 //     1e-30 <= |x| <= 4 (exhaustive check over all 2^32 patterns: tools/div_exact.hip, run by
@@ -35,7 +36,7 @@
 //
 // A lane owns a 4x2-pixel quad (two blocks): two 16-byte loads, three 4-byte stores; lanes
 // of a wave are consecutive quads of one row pair; grid = (tiles, row-pair groups, frames).  LDS holds
-// the three 2 KiB per-byte tables and the two-resolution BT709_from_linear table.
+// the 2 KiB per-byte table and the two-resolution BT709_from_linear table.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -60,16 +61,16 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const u32x2 *LdsPairPtr;  // one ds_read_b64, base in the offset field
 
 struct EncodeLds {
-  // The per-byte tables sit at LDS address 0 (R), 2048 (G), 4096 (B): these kernels have no static
-  // LDS, so the dynamic segment starts at 0 -- stage_encode_tables traps if that ever changes.
+  // The per-byte table sits at LDS address 0: these kernels have no static LDS, so the dynamic
+  // segment starts at 0 -- stage_encode_tables traps if that ever changes.
   uint32_t fl;     // ... of the two-resolution BT709_from_linear table (transfer_tables.h SplitTable)
   uint32_t offset, coarse_shift;
   uint32_t three;  // VGPR holding 3: SDWA operands cannot be inline constants
 };
 
-// {lin, k_enc} of byte LANE of a BGRA word: v_lshlrev_b32_sdwa selects the byte and scales it to
+// {lin, enc_norm} of byte LANE of a BGRA word: v_lshlrev_b32_sdwa selects the byte and scales it to
 // the 8-byte entry in one instruction
-template <int LANE, int TABLE>
+template <int LANE>
 __device__ __forceinline__ u32x2 byte_entry(const EncodeLds &t, uint32_t word) {
   uint32_t a;
   if (LANE == 0)
@@ -78,7 +79,7 @@ __device__ __forceinline__ u32x2 byte_entry(const EncodeLds &t, uint32_t word) {
     asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(t.three), "v"(word));
   else
     asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(t.three), "v"(word));
-  return *reinterpret_cast<LdsPairPtr>(a + 2048u * TABLE);  // constant lands in the ds_read offset field
+  return *reinterpret_cast<LdsPairPtr>(a);
 }
 
 __device__ __forceinline__ uint32_t from_linear(const EncodeLds &t, float xs) {
@@ -102,13 +103,14 @@ __device__ __forceinline__ void encode_block(const EncodeLds &t, float fl_quarte
   float sr = 0.f, sg = 0.f, sb = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const u32x2 r = byte_entry<2, 0>(t, p[i]);
-    const u32x2 g = byte_entry<1, 1>(t, p[i]);
-    const u32x2 b = byte_entry<0, 2>(t, p[i]);
+    const u32x2 r = byte_entry<2>(t, p[i]);
+    const u32x2 g = byte_entry<1>(t, p[i]);
+    const u32x2 b = byte_entry<0>(t, p[i]);
     sr = i ? __fadd_rn(sr, __uint_as_float(r.x)) : __uint_as_float(r.x);
     sg = i ? __fadd_rn(sg, __uint_as_float(g.x)) : __uint_as_float(g.x);
     sb = i ? __fadd_rn(sb, __uint_as_float(b.x)) : __uint_as_float(b.x);
-    const float ey = __fadd_rn(__fadd_rn(__uint_as_float(r.y), __uint_as_float(g.y)), __uint_as_float(b.y));  // BT709.h:222
+    const float ey = __fadd_rn(__fadd_rn(__fmul_rn(kKr, __uint_as_float(r.y)), __fmul_rn(kKg, __uint_as_float(g.y))),
+                               __fmul_rn(kKb, __uint_as_float(b.y)));  // BT709.h:222
     v[i] = quant_arg(ey, static_cast<float>(kYMax - kYMin), 16.0f);                                            // BT709.h:233, 244
   }
   // ave = sum / 4.0f, then scaled into the table's domain: sum * (0.25 * N), both powers of two
@@ -157,7 +159,7 @@ __device__ __forceinline__ EncodeLds stage_encode_tables(unsigned char *lds_raw,
   u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
   const u32x4 *sb = reinterpret_cast<const u32x4 *>(p.per_byte);
   const u32x4 *sf = reinterpret_cast<const u32x4 *>(p.from_linear);
-  const uint32_t nb = 3 * 256 * sizeof(EncodeByteEntry) / 16, nf = p.from_linear_bytes / 16;
+  const uint32_t nb = 256 * sizeof(EncodeByteEntry) / 16, nf = p.from_linear_bytes / 16;
   // (The first version staged a uniform 33 KiB BT709_from_linear table here -- ten dependent L2
   // round trips per workgroup -- and a version that left it in global memory was bound by the
   // 64-line gathers; the two-resolution table is 6-10 KiB.)
@@ -165,7 +167,7 @@ __device__ __forceinline__ EncodeLds stage_encode_tables(unsigned char *lds_raw,
   EncodeLds t;
   if (static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)lds_raw)) != 0u)
     __builtin_trap();
-  t.fl = 3u * 256u * static_cast<uint32_t>(sizeof(EncodeByteEntry));
+  t.fl = 256u * static_cast<uint32_t>(sizeof(EncodeByteEntry));
   t.offset = p.from_linear_offset;
   t.coarse_shift = 127u - (__float_as_uint(p.from_linear_coarse) >> 23);  // log2(1 / coarse), coarse = 2^-k
   t.three = 3u;
@@ -273,7 +275,7 @@ encode_bgra_nv12_blocks(const EncodeParams p) {
 const char *launch_encode(const EncodeParams &params, int frames, bool fast, hipStream_t stream) {
   EncodeParams p = params;
   if (p.row_pairs_per_block == 0) p.row_pairs_per_block = encode_row_pairs_per_block(p.width, p.height, frames);
-  const size_t lds = 3 * 256 * sizeof(EncodeByteEntry) + p.from_linear_bytes;
+  const size_t lds = 256 * sizeof(EncodeByteEntry) + p.from_linear_bytes;
   if (fast) {
     const uint32_t quads = p.width / 4;
     uint32_t threads = p.block_threads ? p.block_threads : encode_block_threads(p.width);

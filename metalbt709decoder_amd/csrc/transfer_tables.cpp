@@ -198,12 +198,8 @@ bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out) {
     if (in_gamma == kGammaSRGB) lin = srgb_to_linear(n);
     else if (in_gamma == kGammaApple) lin = apple196_to_linear(n);
     const int e = transfer_to_byte(out->from_linear_kind, lin);  // BT709_from_linear(lin, outputGamma)
-    const float enc_norm = e * (1.0f / 255.0f);  // byteNorm inside sRGB_from_sRGB_convertRGBToYCbCr
-    const float k[3] = {0.2126f, 0.7152f, 0.0722f};  // BT709_Kr, Kg, Kb (BT709.h:40-42)
-    for (int c = 0; c < 3; ++c) {
-      out->per_byte[c][b].lin = lin;
-      out->per_byte[c][b].k_enc = k[c] * enc_norm;  // the float product (BT709_Kx * Xn) of BT709.h:222
-    }
+    out->per_byte[b].lin = lin;
+    out->per_byte[b].enc_norm = e * (1.0f / 255.0f);  // byteNorm inside sRGB_from_sRGB_convertRGBToYCbCr
   }
   return true;
 }

@@ -73,12 +73,12 @@ int transfer_to_byte(int gamma, float v);
 // BT709_average_pixel_values (Renderer/CVPixelBufferUtils.h:241-399, Renderer/BT709.h:1349-1509);
 // gammas use this file's ids (kGammaApple / kGammaSRGB / kGammaLinear).
 struct alignas(8) EncodeByteEntry {
-  float lin;    // BT709_tolinearNorm of the byte for the input gamma (BT709.h:1100-1146)
-  float k_enc;  // K_c * byteNorm(BT709_from_linear(lin, output gamma)): this channel's term of Ey (BT709.h:222)
+  float lin;       // BT709_tolinearNorm of the byte for the input gamma (BT709.h:1100-1146)
+  float enc_norm;  // byteNorm(BT709_from_linear(lin, output gamma)): the kernel multiplies by Kr / Kg / Kb (BT709.h:222)
 };
 struct EncodeTables {
-  EncodeByteEntry per_byte[3][256];  // [R, G, B][byte]; the three differ only in K_c = Kr, Kg, Kb
-  int from_linear_kind = 0;          // table kind whose buckets implement BT709_from_linear(., output gamma)
+  EncodeByteEntry per_byte[256];  // one 2 KiB table for the three channels
+  int from_linear_kind = 0;       // table kind whose buckets implement BT709_from_linear(., output gamma)
 };
 bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out);
 
