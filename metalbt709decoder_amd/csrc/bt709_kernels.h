@@ -139,8 +139,9 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
 // half, conflict-free form: grid = workgroups (<= compute units, one resident per CU) x block_threads,
 // each walking tile rows workgroup, workgroup + grid, ...; fills the rep_*, tiles_x, tile_rows and cursor_*
 // fields of its copy of `p`.  Returns nullptr when the tables do not fit LDS (caller falls back).
+// lds_budget: LDS bytes one workgroup may take (kRepLdsBytes = one workgroup per CU).
 const char *launch_decode_half_rep(const DecodeParams &p, int frames, bool nontemporal, uint32_t workgroups,
-                                   hipStream_t stream);
+                                   uint32_t lds_budget, hipStream_t stream);
 constexpr int kRepBlockThreads = 1024;      // one workgroup per CU: 16 waves
 constexpr uint32_t kRepLdsBytes = 160 * 1024;
 

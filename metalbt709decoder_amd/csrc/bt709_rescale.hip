@@ -459,8 +459,9 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
 }
 
 const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool nontemporal, uint32_t workgroups,
-                                   hipStream_t stream) {
+                                   uint32_t lds_budget, hipStream_t stream) {
   DecodeParams p = p_in;
+  const uint64_t kRepLdsBytes = lds_budget < 16384u ? 16384u : (lds_budget > bt709::kRepLdsBytes ? bt709::kRepLdsBytes : lds_budget);
   // copies: as many as fit the CU's LDS, decode side first (12 of the 15 lookups per output pixel)
   uint32_t r1 = 4, r2 = 0;
   while (r1 > 0 && (static_cast<uint64_t>(p.table_linear_bytes) << r1) + p.table_encode_bytes > kRepLdsBytes) --r1;

@@ -632,7 +632,8 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
                              (p.height / 2) * static_cast<uint32_t>(count);
   const bool rep = wide && dec->half_rep != 0 && (dec->half_rep > 0 || tile_rows >= 8ull * cus);
   const char *name = rep ? launch_decode_half_rep(p, count, dec->nontemporal,
-                                                  static_cast<uint32_t>(env_int("BT709HIP_REP_WORKGROUPS", static_cast<int>(cus))), s)
+                                                  static_cast<uint32_t>(env_int("BT709HIP_REP_WORKGROUPS", static_cast<int>(cus))),
+                                                  static_cast<uint32_t>(env_int("BT709HIP_REP_LDS_KB", 160)) * 1024u, s)
                          : nullptr;
   tl_kernel_name = name ? name : launch_decode_half(p, count, wide, dec->nontemporal, gx, threads, s);
   HIP_TRY(hipGetLastError());
