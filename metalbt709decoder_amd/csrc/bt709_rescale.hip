@@ -7,13 +7,13 @@
 // so parity is against the oracle's restatement of this definition): each source pixel is
 // decoded to its 8-bit sRGB value and linearised as the sRGB8 sampler would -- the decode-side
 // table returns that linear float directly, {edge, lin(base), lin(base + 1)} in one 16-byte
-// bucket -- the taps are combined in linear light, and the result is sRGB-encoded and quantised
+// bucket (transfer_tables.h TransferBucketLinear) -- the taps are combined in linear light, and the result is sRGB-encoded and quantised
 // through the LINEAR-mode composite, held as a two-resolution bucket table (transfer_tables.h
 // SplitTable).
 //
 // All three kernels are VALU-bound (12 decode-side + 3 encode-side lookups per output pixel), so
 // everything is counted in cycles (bt709_device.h, VALU BUDGET): per decode-side lookup
-// 2 (saturating add) + 2 (magic add) + 4 (address) + 4 + 4 (compare, select).
+// 2 (saturating add) + 2 (magic add) + 4 (address) + 2 + 4 (subtract, median-of-three select).
 //
 //   decode_nv12_half       exact 2:1, one short-lived workgroup per tile of an output row
 //   decode_nv12_half_rep   exact 2:1, persistent workgroups, bank-conflict-free LDS tables
@@ -37,8 +37,8 @@ struct RescaleLookup {
   uint32_t enc_shift;  // log2(8 R2)
   uint32_t enc_off;    // LDS address of the encode table + lane's copy offset
   uint32_t split_offset, split_shift;  // SplitTable: q = min(qf, (qf >> shift) + offset)
-  float quarter_scale;  // 0.25 * n_fine of the encode table
-  float scale;          // n_fine
+  float quarter_scale;  // 0.25 * scale
+  float scale;          // n_fine of the encode table * 2^40 (the linear values come scaled by 2^-40)
 };
 
 // Stages both tables in 2^r1 / 2^r2 interleaved copies (0 / 0: plain) and returns the lookup
@@ -65,8 +65,9 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   r.enc_off = base + dec_bytes + (tid & ((1u << r2) - 1u)) * 8u;
   r.split_offset = p.encode_offset;
   r.split_shift = p.encode_shift;
-  r.scale = p.encode_scale;
-  r.quarter_scale = __fmul_rn(0.25f, p.encode_scale);
+  const float unscale = __uint_as_float(static_cast<uint32_t>(127 - kLinearScaleLog2) << 23);  // 2^40
+  r.scale = __fmul_rn(p.encode_scale, unscale);
+  r.quarter_scale = __fmul_rn(0.25f, r.scale);
   return r;
 }
 
@@ -80,7 +81,7 @@ __device__ __forceinline__ uint32_t encode_byte(const RescaleLookup &r, float xs
   return e.y + (xs >= __uint_as_float(e.x) ? 1u : 0u);
 }
 
-// linear-light values of 12 saturated channel values: 6 buckets in flight per wait
+// linear-light values (times 2^-40) of 12 saturated channel values: 6 buckets in flight per wait
 __device__ __forceinline__ void linearise12(const RescaleLookup &r, const float *x, float *lin) {
   uint32_t t[12];
   magic_floor12(x, t, r.magic);
@@ -91,8 +92,9 @@ __device__ __forceinline__ void linearise12(const RescaleLookup &r, const float 
     for (int i = 0; i < 6; ++i) e[i] = *reinterpret_cast<LdsQuadPtr>((t[6 * h + i] << r.dec_shift) + r.dec_off);
     asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait per batch
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      lin[6 * h + i] = x[6 * h + i] >= __uint_as_float(e[i].x) ? __uint_as_float(e[i].z) : __uint_as_float(e[i].y);
+    for (int i = 0; i < 6; ++i)  // transfer_tables.h TransferBucketLinear: below / above by sub + med3
+      lin[6 * h + i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z),
+                                               __fadd_rn(x[6 * h + i], -__uint_as_float(e[i].x)));
   }
 }
 

@@ -131,10 +131,10 @@ bool build_transfer_table(int gamma, TransferTable *out) {
     out->buckets_linear.resize(b.size());
     for (size_t q = 0; q < b.size(); ++q) {
       TransferBucketLinear &e = out->buckets_linear[q];
-      e.edge = b[q].edge;
+      e.edge_pred = b[q].edge == inf ? inf : std::nextafter(b[q].edge, -inf);
       e.base = b[q].base;
-      e.lin_below = lin_of_byte[b[q].base];
-      e.lin_above = lin_of_byte[b[q].base + 1];
+      e.lin_below = std::ldexp(lin_of_byte[b[q].base], kLinearScaleLog2);      // exact: power of two
+      e.lin_above = std::ldexp(lin_of_byte[b[q].base + 1], kLinearScaleLog2);
     }
     return true;
   }

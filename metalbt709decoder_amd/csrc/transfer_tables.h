@@ -39,13 +39,22 @@ struct alignas(8) TransferBucket {
   uint32_t base;
 };
 
-// Bucket for the fused 2:1 rescale: the decoded byte is never materialised, the
-// lookup returns it already linearised (sampler-side sRGB decode of an sRGB8 texel:
-// sRGB_nonLinearNormToLinear(byteNorm(b)), Renderer/sRGB.h:32-57).
+// Bucket for the fused rescale kernels: the decoded byte is never materialised, the lookup returns
+// it already linearised (sampler-side sRGB decode of an sRGB8 texel:
+// sRGB_nonLinearNormToLinear(byteNorm(b)), Renderer/sRGB.h:32-57), and the choice between the two
+// values of a bucket is ONE v_sub_f32 + ONE v_med3_f32 instead of compare + select:
+//     d   = x - edge_pred                 edge_pred = the float just below the threshold, so
+//                                         d > 0  <=>  x >= threshold (d == 0 when x == edge_pred)
+//     lin = med3(lin_below, lin_above, d)
+// which is exact because both linear values are stored times 2^-40: 0 <= lin_below <= lin_above
+// <= 2^-40, while a positive d is at least one ulp of a threshold (>= 2^-36).  The kernels fold
+// 2^40 into the power-of-two scale they apply after averaging; scaling by a power of two commutes
+// with every rounding on the way (smallest product in the bilinear kernel ~2^-98: no underflow).
+constexpr int kLinearScaleLog2 = -40;
 struct alignas(16) TransferBucketLinear {
-  float edge;
-  float lin_below;  // linear value of byte `base`
-  float lin_above;  // linear value of byte `base + 1`
+  float edge_pred;  // nextafter(threshold, -inf), or +inf when the bucket holds no threshold
+  float lin_below;  // 2^-40 * linear value of byte `base`
+  float lin_above;  // 2^-40 * linear value of byte `base + 1`
   uint32_t base;
 };
 
