@@ -319,9 +319,9 @@ decode_nv12_half_rep(const DecodeParams p) {
 // staged once per workgroup instead of once per 256 output pixels (the first version did that and
 // spent its time staging: 86 Gpixel/s whatever the size).  The next row's taps are fetched
 // before the current row's arithmetic, as widely as the layout allows (12 -> 8 loads per pixel was
-// worth +25 %; 8 -> 4 and the prefetch are neutral on random content, where the kernel is bound by
-// the bank conflicts of its single-copy tables like decode_nv12_half: 140-160 Gpixel/s for one
-// frame per launch against 200 for that kernel and 240 for the replicated-table one):
+// worth +25 %; 8 -> 4 and the prefetch are neutral: what is left is VALU time -- chroma products
+// per tap, weights and twelve weighted terms, ~600 cycles per output pixel; a replicated-table
+// one-workgroup-per-CU form was measured and is no faster.  140-160 Gpixel/s, one frame per launch):
 //   TAPS_WIDE  (planes and strides 4-byte aligned, width % 4 == 0, width >= 8): per source row ONE
 //              aligned 8-byte load that contains both horizontal taps, and one v_perm_b32 with a
 //              per-lane selector (computed once) picks them out: 4 loads per output pixel;
