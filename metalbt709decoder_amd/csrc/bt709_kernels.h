@@ -98,9 +98,9 @@ struct EncodeParams {
 };
 const char *launch_encode(const EncodeParams &p, int frames, bool fast, hipStream_t stream);
 hipError_t prepare_encode_kernels();
-// Encoder fast-path geometry, measured on 4K (tools/bench_encode.py sweeps):
+// Encoder fast-path geometry, measured on 4K (tools/encode_shapes.sh sweeps):
 // one quad per lane, equal tiles of <= 320 lanes rounded up to whole waves (3840 -> 3 x 320,
-// 1920 -> 2 x 256); a workgroup walks 3 to 9 consecutive row pairs (amortising its 12 KiB of
+// 1920 -> 2 x 256); a workgroup walks 3 to 9 consecutive row pairs (amortising its 8 KiB of
 // table staging): the most that still leaves the launch >= 4096 workgroups.
 inline uint32_t encode_block_threads(uint32_t width) {
   const uint32_t quads = width / 4, tiles = quads == 0 ? 1 : (quads + 319) / 320;
@@ -150,7 +150,7 @@ const char *launch_decode_scaled(const DecodeParams &p, int frames, uint32_t com
 
 // Fast-path launch geometry for a frame width: tiles (workgroups) per row pair and the
 // workgroup size -- ceil(quads per tile / kQuadsPerLane) rounded up to a whole wave.
-//   3840 -> 1 tile x 480 threads, 1920 -> 1 x 256, 7680 -> 2 x 480.
+//   3840 -> 1 tile x 512 threads (480 rounded up to whole waves), 1920 -> 1 x 256, 7680 -> 2 x 512.
 inline uint32_t quads_tiles(uint32_t width) {
   const uint32_t quads = width / 4, cap = kMaxBlockThreads * kQuadsPerLane;
   return quads == 0 ? 1 : (quads + cap - 1) / cap;
