@@ -248,7 +248,8 @@ int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, c
  *   submit   -> upload, decode, download enqueued on the slot's stream; returns at once
  *   wait     -> the slot's pinned BGRA rows, valid until the slot is acquired again
  * Slots are handed out round-robin, so `depth` frames overlap their copies and kernels.  The decoder
- * must not have an alpha channel. */
+ * must not have an alpha channel and must outlive the pool; a pool is used from one thread at a time
+ * (decoders and contexts may be shared between threads, each thread with pools / streams of its own). */
 int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth, bt709hip_pool **out);
 int bt709hip_pool_destroy(bt709hip_pool *pool);
 int bt709hip_pool_acquire(bt709hip_pool *pool, int *slot, void **y, size_t *y_stride, void **cbcr,
