@@ -42,8 +42,8 @@ struct Ring {
   void *d_table_unit = nullptr;
   TransferTable tt;
   std::vector<DecodeParams> params;
-  hipStream_t s;
-  hipEvent_t e0, e1;
+  hipStream_t s, s2 = nullptr;  // s2: second stream when env LAB_STREAMS=2 (launch l goes to stream l & 1)
+  hipEvent_t e0, e1, e2;
 
   Ring(int w, int h, int ring_, int batch_, int gamma) : W(w), H(h), ring(ring_), batch(batch_) {
     // placement experiments: LAB_ROW_PAD bytes added to every output row, LAB_IN_ROW_PAD to every input row,
@@ -75,6 +75,8 @@ struct Ring {
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    CK(hipEventCreate(&e2));
+    if (std::getenv("LAB_STREAMS") && std::atoi(std::getenv("LAB_STREAMS")) == 2) CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     if (!build_transfer_table(gamma, &tt)) std::exit(2);
     const size_t tub = tt.buckets_unit.size() * sizeof(TransferBucket);
     CK(hipMalloc(&d_table_unit, tub));
@@ -103,6 +105,10 @@ struct Ring {
     CK(hipEventRecord(e0, s));
     for (int r = 0; r < reps; ++r)
       for (size_t l = 0; l < params.size(); ++l) fn(int(l));
+    if (s2) {  // LAB_STREAMS=2: the odd launches went to s2; e1 must follow both streams
+      CK(hipEventRecord(e2, s2));
+      CK(hipStreamWaitEvent(s, e2, 0));
+    }
     CK(hipEventRecord(e1, s));
     CK(hipStreamSynchronize(s));
     CK(hipGetLastError());
@@ -131,7 +137,7 @@ int main(int argc, char **argv) {
     int t = ((per_tile + kQuadsPerLane - 1) / kQuadsPerLane + 63) / 64 * 64;
     if (t > kMaxBlockThreads) continue;
     add("quads<nt> qpl=" + std::to_string(kQuadsPerLane) + " tiles=" + std::to_string(tiles) + " threads=" + std::to_string(t),
-        [&r, s, t, tiles](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, true, tiles, t, s); });
+        [&r, s, t, tiles](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, true, tiles, t, (r.s2 && (l & 1)) ? r.s2 : s); });
   }
 
   // warm the clocks
