@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "../include/bt709hip.h"
@@ -159,6 +160,24 @@ class BGRATexture {
   bt709hip_surface s_{};
 };
 
+// What the reference's caller actually holds: a CVPixelBuffer whose planes live in HOST memory (the
+// GPU reads them in place on Apple's unified memory) and a BGRA texture it reads back with -getBytes.
+// On a discrete GPU the decoder moves them through its in-flight frame pool.
+struct HostPixelBuffer {  // CVPixelBufferLockBaseAddress + GetBaseAddressOfPlane / GetBytesPerRowOfPlane
+  const uint8_t *y = nullptr;
+  size_t yStride = 0;
+  const uint8_t *cbcr = nullptr;
+  size_t cbcrStride = 0;
+  int width = 0, height = 0;
+  int matrix = BT709HIP_MATRIX_ITU_R_709_2;        // kCVImageBufferYCbCrMatrixKey
+  int transfer = BT709HIP_TRANSFER_ITU_R_709_2;    // kCVImageBufferTransferFunctionKey
+};
+struct HostTexture {  // BGRA8Unorm_sRGB pixels in host memory
+  uint8_t *bgra = nullptr;
+  size_t stride = 0;
+  int width = 0, height = 0;
+};
+
 class MetalBT709Decoder {
  public:
   MetalRenderContext *metalRenderContext = nullptr;
@@ -168,6 +187,7 @@ class MetalBT709Decoder {
   int alphaFill = 0xFF;
 
   ~MetalBT709Decoder() {
+    releaseHostPool();
     if (metalRenderContext && metalRenderContext->handle()) bt709hip_decoder_destroy(dec_);
   }
   MetalBT709Decoder() = default;
@@ -204,18 +224,86 @@ class MetalBT709Decoder {
     return rc == BT709HIP_OK ? ok() : fail(rc);
   }
 
+  // The SAME selector for a caller whose buffers are in host memory, as the reference's are
+  // (AAPLRenderer.m:927-957, MetalBT709DecoderTests.m:248-255): planes are copied into the pinned
+  // staging of an in-flight slot, upload + decode + download are enqueued on the slot's stream, and
+  // the pixels are copied out of the slot when it completes.  waitUntilCompleted == false returns
+  // at once; the texture is filled by the next call that recycles the slot or by finishHostFrames().
+  // alphaPixelBuffer: required iff hasAlphaChannel (only its Y plane is read).
+  bool decodeBT709(const HostPixelBuffer &yCbCrInputTexture, const HostPixelBuffer *alphaPixelBuffer,
+                   const HostTexture &bgraSRGBTexture, const void * /*commandBuffer*/,
+                   const void * /*renderPassDescriptor*/, int renderWidth, int renderHeight, bool waitUntilCompleted) {
+    if (!setupMetal()) return false;
+    const HostPixelBuffer &in = yCbCrInputTexture;
+    // the checks -processBT709ToSRGB: makes before it touches a plane (.m:272-368), in its order
+    if (bgraSRGBTexture.width != in.width || bgraSRGBTexture.height != in.height) return fail(BT709HIP_ERR_SIZE_MISMATCH);
+    if (renderWidth != in.width || renderHeight != in.height) return fail(BT709HIP_ERR_SIZE_MISMATCH);
+    if (alphaPixelBuffer && (alphaPixelBuffer->width != in.width || alphaPixelBuffer->height != in.height))
+      return fail(BT709HIP_ERR_SIZE_MISMATCH);
+    if (in.matrix != BT709HIP_MATRIX_ITU_R_709_2) return fail(BT709HIP_ERR_MATRIX);
+    if (in.transfer != requiredTransfer()) return fail(BT709HIP_ERR_TRANSFER);
+    if (alphaPixelBuffer && alphaPixelBuffer->transfer != BT709HIP_TRANSFER_LINEAR) return fail(BT709HIP_ERR_ALPHA_TRANSFER);
+    if ((in.width & 1) || (in.height & 1)) return fail(BT709HIP_ERR_ODD_DIMENSIONS);
+    if (hasAlphaChannel && alphaPixelBuffer == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
+    if (in.width == 0 || in.height == 0) return ok();
+    if (in.y == nullptr || in.cbcr == nullptr || bgraSRGBTexture.bgra == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
+    if (in.yStride < static_cast<size_t>(in.width) || in.cbcrStride < static_cast<size_t>(in.width) ||
+        bgraSRGBTexture.stride < static_cast<size_t>(in.width) * 4)
+      return fail(BT709HIP_ERR_STRIDE);
+    if (!hostPool(in.width, in.height)) return false;
+
+    int slot = -1;
+    void *py = nullptr, *pc = nullptr;
+    size_t ys = 0, cs = 0;
+    if (pending_[next_].valid && !finishSlot(next_)) return false;  // the slot about to be recycled still owes its pixels
+    int rc = bt709hip_pool_acquire(pool_, &slot, &py, &ys, &pc, &cs);
+    if (rc != BT709HIP_OK) return fail(rc);
+    copyRows(py, ys, in.y, in.yStride, static_cast<size_t>(in.width), in.height);
+    copyRows(pc, cs, in.cbcr, in.cbcrStride, static_cast<size_t>(in.width), in.height / 2);
+    if (hasAlphaChannel) {
+      void *pa = nullptr;
+      size_t as = 0;
+      rc = bt709hip_pool_alpha_plane(pool_, slot, &pa, &as);
+      if (rc != BT709HIP_OK) return fail(rc);
+      copyRows(pa, as, alphaPixelBuffer->y, alphaPixelBuffer->yStride, static_cast<size_t>(in.width), in.height);
+    }
+    rc = bt709hip_pool_submit(pool_, slot);
+    if (rc != BT709HIP_OK) return fail(rc);
+    pending_[static_cast<size_t>(slot)] = {true, bgraSRGBTexture};
+    next_ = (static_cast<size_t>(slot) + 1) % pending_.size();
+    if (waitUntilCompleted) return finishSlot(static_cast<size_t>(slot));  // .m:486-489
+    return ok();
+  }
+
+  // Completes every frame submitted with waitUntilCompleted == false (fills their textures).
+  bool finishHostFrames() {
+    bool all = true;
+    for (size_t i = 0; i < pending_.size(); ++i)
+      if (pending_[i].valid) all = finishSlot(i) && all;
+    return all;
+  }
+  int maxBuffersInFlight = 3;  // AAPLRenderer.m:34; read when the host pool is first needed
+
   // -decodeBT709 into an intermediate + MetalScaleRenderContext -renderScaled: (AAPLRenderer.m:940-977), fused:
   // the tuned kernels for the exact 2:1 ratio, the bilinear kernel for any other view size (bit-identical where
   // both apply).
   bool decodeBT709Scaled(const CVPixelBuffer *in, const BGRATexture *out, void *commandBuffer,
-                         bool waitUntilCompleted) {
+                         bool waitUntilCompleted, const CVPixelBuffer *alphaPixelBuffer = nullptr) {
     if (!setupMetal()) return false;
     if (in == nullptr || out == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
     const bt709hip_frame *f = in->frame();
+    const bt709hip_frame *a = alphaPixelBuffer ? alphaPixelBuffer->frame() : nullptr;
     const bt709hip_surface *s = out->surface();
     const bool exact_half = 2 * s->width == f->width && 2 * s->height == f->height && f->width % 4 == 0 && f->height % 4 == 0;
-    const int rc = exact_half ? bt709hip_decode_half(dec_, f, s, commandBuffer, waitUntilCompleted ? 1 : 0)
-                              : bt709hip_decode_scaled(dec_, f, s, commandBuffer, waitUntilCompleted ? 1 : 0);
+    const int rc = exact_half ? bt709hip_decode_half(dec_, f, a, s, commandBuffer, waitUntilCompleted ? 1 : 0)
+                              : bt709hip_decode_scaled(dec_, f, a, s, commandBuffer, waitUntilCompleted ? 1 : 0);
+    return rc == BT709HIP_OK ? ok() : fail(rc);
+  }
+
+  // kernel-selection knob (bt709hip_decoder_option): tuning and test hook
+  bool setOption(int option, int value) {
+    if (!setupMetal()) return false;
+    const int rc = bt709hip_decoder_set_option(dec_, option, value);
     return rc == BT709HIP_OK ? ok() : fail(rc);
   }
 
@@ -231,8 +319,53 @@ class MetalBT709Decoder {
     std::fprintf(stderr, "MetalBT709Decoder: %s\n", bt709hip_strerror(rc));  // NSLog in the reference
     return false;
   }
+  int requiredTransfer() const {  // MetalBT709Decoder.m:335-353
+    return gamma == MetalBT709GammaSRGB ? BT709HIP_TRANSFER_SRGB
+                                        : (gamma == MetalBT709GammaLinear ? BT709HIP_TRANSFER_LINEAR : BT709HIP_TRANSFER_ITU_R_709_2);
+  }
+  static void copyRows(void *dst, size_t dstStride, const void *src, size_t srcStride, size_t rowBytes, int rows) {
+    for (int r = 0; r < rows; ++r)
+      std::memcpy(static_cast<uint8_t *>(dst) + static_cast<size_t>(r) * dstStride,
+                  static_cast<const uint8_t *>(src) + static_cast<size_t>(r) * srcStride, rowBytes);
+  }
+  // one pool per frame size; a new size drains and replaces it
+  bool hostPool(int width, int height) {
+    if (pool_ && poolW_ == width && poolH_ == height) return true;
+    if (pool_ && !finishHostFrames()) return false;
+    releaseHostPool();
+    const int rc = bt709hip_pool_create(dec_, width, height, maxBuffersInFlight, &pool_);
+    if (rc != BT709HIP_OK) return fail(rc);
+    poolW_ = width;
+    poolH_ = height;
+    pending_.assign(static_cast<size_t>(maxBuffersInFlight), Pending{});
+    next_ = 0;
+    return true;
+  }
+  void releaseHostPool() {
+    if (pool_) bt709hip_pool_destroy(pool_);
+    pool_ = nullptr;
+    pending_.clear();
+  }
+  bool finishSlot(size_t slot) {
+    const void *p = nullptr;
+    size_t stride = 0;
+    const int rc = bt709hip_pool_wait(pool_, static_cast<int>(slot), &p, &stride);
+    if (rc != BT709HIP_OK) return fail(rc);
+    const HostTexture &t = pending_[slot].texture;
+    copyRows(t.bgra, t.stride, p, stride, static_cast<size_t>(t.width) * 4, t.height);
+    pending_[slot].valid = false;
+    return ok();
+  }
+  struct Pending {
+    bool valid = false;
+    HostTexture texture;
+  };
   bt709hip_decoder *dec_ = nullptr;
   int lastStatus_ = BT709HIP_OK;
+  bt709hip_pool *pool_ = nullptr;
+  int poolW_ = 0, poolH_ = 0;
+  std::vector<Pending> pending_;
+  size_t next_ = 0;
 };
 
 // `depth` frames in flight between host memory and the GPU, one HIP stream each: the role of

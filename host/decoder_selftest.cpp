@@ -5,23 +5,91 @@
 // file holds no oracle and no reference data.
 //
 //   g++ -std=c++17 host/decoder_selftest.cpp -Lmetalbt709decoder_amd -lbt709hip -o selftest
-//   ./selftest Y Cb Cr R G B [Y Cb Cr R G B ...]
+//   ./selftest [--host] Y Cb Cr R G B [Y Cb Cr R G B ...]
+// --host: the same vectors with the frame and the texture in HOST memory, through the unchanged
+// 8-argument selector's host overload (in-flight frame pool), three frames in flight.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "MetalBT709Decoder.hpp"
 
 using namespace bt709;
 
+// Host-memory flow: every vector is one 6x4 frame and one texture in plain host memory; frames are
+// submitted without waiting (three in flight), then finished and compared.
+static int run_host_vectors(MetalBT709Decoder &metalDecoder, int argc, char **argv) {
+  const int width = 6, height = 4, n = (argc - 1) / 6;
+  std::vector<std::vector<uint8_t>> ys(n), cs(n), outs(n);
+  int failures = 0;
+  for (int v = 0; v < n; ++v) {
+    const int i = 1 + 6 * v;
+    ys[v].assign(static_cast<size_t>(width + 3) * height, static_cast<uint8_t>(std::atoi(argv[i])));  // pitch > width
+    cs[v].resize(static_cast<size_t>(width) * (height / 2));
+    for (size_t k = 0; k < cs[v].size(); k += 2) {
+      cs[v][k] = static_cast<uint8_t>(std::atoi(argv[i + 1]));
+      cs[v][k + 1] = static_cast<uint8_t>(std::atoi(argv[i + 2]));
+    }
+    outs[v].assign(static_cast<size_t>(width * 4 + 8) * height, 0x5A);
+    HostPixelBuffer yCbCrBuffer;
+    yCbCrBuffer.y = ys[v].data();
+    yCbCrBuffer.yStride = width + 3;
+    yCbCrBuffer.cbcr = cs[v].data();
+    yCbCrBuffer.cbcrStride = width;
+    yCbCrBuffer.width = width;
+    yCbCrBuffer.height = height;
+    HostTexture bgraSRGBTexture{outs[v].data(), static_cast<size_t>(width * 4 + 8), width, height};
+    if (!metalDecoder.decodeBT709(yCbCrBuffer, nullptr, bgraSRGBTexture, nullptr, nullptr, width, height, v == n - 1))
+      ++failures;
+  }
+  if (!metalDecoder.finishHostFrames()) ++failures;
+  for (int v = 0; v < n; ++v) {
+    const int i = 1 + 6 * v;
+    const uint32_t want = 0xFF000000u | (static_cast<uint32_t>(std::atoi(argv[i + 3])) << 16) |
+                          (static_cast<uint32_t>(std::atoi(argv[i + 4])) << 8) | static_cast<uint32_t>(std::atoi(argv[i + 5]));
+    for (int row = 0; row < height; ++row) {
+      const uint8_t *r = outs[v].data() + static_cast<size_t>(row) * (width * 4 + 8);
+      for (int col = 0; col < width; ++col) {
+        uint32_t px;
+        std::memcpy(&px, r + 4 * col, 4);
+        if (px != want) ++failures;
+      }
+      for (int k = width * 4; k < width * 4 + 8; ++k)
+        if (r[k] != 0x5A) ++failures;  // row padding untouched
+    }
+  }
+  // the overload validates like the reference: a BT.601-tagged buffer is refused
+  HostPixelBuffer bad;
+  bad.y = ys[0].data();
+  bad.yStride = width + 3;
+  bad.cbcr = cs[0].data();
+  bad.cbcrStride = width;
+  bad.width = width;
+  bad.height = height;
+  bad.matrix = BT709HIP_MATRIX_ITU_R_601_4;
+  HostTexture tex{outs[0].data(), static_cast<size_t>(width * 4 + 8), width, height};
+  if (metalDecoder.decodeBT709(bad, nullptr, tex, nullptr, nullptr, width, height, true) ||
+      metalDecoder.lastStatus() != BT709HIP_ERR_MATRIX)
+    ++failures;
+  std::printf("%s: %d host vectors, %d failures\n", failures ? "FAIL" : "ok", n, failures);
+  return failures ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+  const bool host = argc > 1 && std::strcmp(argv[1], "--host") == 0;
+  if (host) {
+    --argc;
+    ++argv;
+  }
   if (argc < 7 || (argc - 1) % 6 != 0) {
-    std::fprintf(stderr, "usage: %s Y Cb Cr R G B [...]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s [--host] Y Cb Cr R G B [...]\n", argv[0]);
     return 2;
   }
   MetalRenderContext metalRenderContext;
   MetalBT709Decoder metalDecoder;
   metalDecoder.metalRenderContext = &metalRenderContext;
   if (!metalDecoder.setupMetal()) return 3;
+  if (host) return run_host_vectors(metalDecoder, argc, argv);
 
   int failures = 0;
   for (int i = 1; i + 5 < argc; i += 6) {

@@ -39,7 +39,9 @@
 extern "C" {
 #endif
 
-#define BT709HIP_VERSION 100
+/* ABI version: bumped whenever a struct layout or a signature in this file changes.  Bindings compare
+ * it with bt709hip_abi_version() so that a library older than the header is refused, not mis-called. */
+#define BT709HIP_VERSION 200
 
 typedef struct bt709hip_context bt709hip_context; /* ~ MetalRenderContext */
 typedef struct bt709hip_decoder bt709hip_decoder; /* ~ MetalBT709Decoder  */
@@ -101,15 +103,27 @@ typedef struct {
   int32_t transfer;   /* bt709hip_transfer_tag */
 } bt709hip_frame;
 
-/* 8-bit BGRA sRGB render target; replaces id<MTLTexture> BGRA8Unorm_sRGB.
- * Memory order B,G,R,A i.e. little-endian word (A<<24)|(R<<16)|(G<<8)|B
+/* MTLPixelFormat of a render target.  The reference renders pass 1 into BGRA8Unorm_sRGB, or --
+ * where sRGB texture writes are unavailable (macOS < 10.14) -- into RGBA16Float holding LINEAR
+ * light (Renderer/AAPLRenderer.m:143-170). */
+typedef enum {
+  BT709HIP_FORMAT_BGRA8_SRGB = 0, /* default: 4 bytes per pixel, gamma-encoded sRGB */
+  BT709HIP_FORMAT_RGBA16F = 1     /* 8 bytes per pixel: IEEE binary16 R,G,B,A in that memory order, linear light */
+} bt709hip_format;
+
+/* Render target; replaces id<MTLTexture>.
+ * BGRA8_SRGB: memory order B,G,R,A i.e. little-endian word (A<<24)|(R<<16)|(G<<8)|B
  * (MetalBT709DecoderTests.m:47-52).  bgra must be 4-byte aligned, stride a
- * multiple of 4 (16-byte alignment of both enables the wide-store kernel). */
+ * multiple of 4 (16-byte alignment of both enables the wide-store kernel).
+ * RGBA16F: 8-byte aligned, stride a multiple of 8; accepted by bt709hip_decode[_batch] as output
+ * and by bt709hip_render_scaled as input. */
 typedef struct {
   void *bgra;
   size_t stride;
   int32_t width;
   int32_t height;
+  int32_t format;   /* bt709hip_format; 0 = BGRA8_SRGB */
+  int32_t reserved; /* must be 0 */
 } bt709hip_surface;
 
 typedef struct {
@@ -136,6 +150,17 @@ int bt709hip_context_destroy(bt709hip_context *ctx);
 int bt709hip_context_info(const bt709hip_context *ctx, bt709hip_device_info *info);
 /* Number of visible GPUs; does not initialise any of them.  Returns count or <0. */
 int bt709hip_device_count(void);
+/* BT709HIP_VERSION the library was compiled against. */
+int bt709hip_abi_version(void);
+
+/* Launch-shape knobs of a context (tuning and test hooks; no reference twin).  Values are
+ * clamped to their valid range; 0 restores the default. */
+typedef enum {
+  BT709HIP_CTX_OPT_GRID_MULT = 1,       /* general (unaligned-layout) kernels: workgroups per launch = CUs x 8 x this; default 2 */
+  BT709HIP_CTX_OPT_ENCODE_ROW_PAIRS = 2,/* encoder: consecutive row pairs per workgroup; default 0 = sized per launch */
+  BT709HIP_CTX_OPT_ENCODE_THREADS = 3   /* encoder: lanes per workgroup (rounded down to whole waves); default 0 = from the width */
+} bt709hip_context_option;
+int bt709hip_context_set_option(bt709hip_context *ctx, int option, int value);
 
 /* Streams ~ MTLCommandQueue/-commandBuffer (MetalRenderContext.h:20): one per
  * in-flight frame.  `stream == NULL` anywhere below means the context's default. */
@@ -193,6 +218,16 @@ int bt709hip_decoder_set_context(bt709hip_decoder *dec, bt709hip_context *ctx);
  * (BGRAToBT709Converter.m:187-193). */
 int bt709hip_decoder_set_alpha_fill(bt709hip_decoder *dec, int alpha_byte);
 int bt709hip_decoder_get_gamma(const bt709hip_decoder *dec);
+/* Kernel-selection knobs of a decoder (tuning and test hooks; no reference twin).  They may be
+ * changed between calls, not during one. */
+typedef enum {
+  BT709HIP_OPT_NONTEMPORAL = 1,      /* 1 (default): streaming loads / stores in the fast kernels; 0: default cache policy */
+  BT709HIP_OPT_HALF_KERNEL = 2,      /* 2:1 rescale: -1 (default) persistent kernel when the launch is large enough, 0 never, 1 always */
+  BT709HIP_OPT_HALF_WORKGROUPS = 3,  /* persistent 2:1 kernel: workgroups; 0 (default) = one per compute unit */
+  BT709HIP_OPT_HALF_LDS_KB = 4       /* persistent 2:1 kernel: KiB of LDS a workgroup may fill with table copies; 0 (default) = 160 */
+} bt709hip_decoder_option;
+int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value);
+int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *value);
 /* -setupMetal: builds the exact transfer table for the decoder's gamma and puts
  * it in device memory.  Idempotent (MetalBT709Decoder.m:66-70); implied by decode. */
 int bt709hip_decoder_setup(bt709hip_decoder *dec);
@@ -223,21 +258,32 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count,
 /* Pass 1 + pass 2 (MetalScaleRenderContext -renderScaled:, bilinear) fused for the
  * exact 2:1 ratio: out is (W/2) x (H/2).  Frame W,H must be multiples of 4.
  * Two-pass-equivalent arithmetic: each output channel is the linear-light mean of
- * the four decoded 8-bit sRGB values, re-encoded to sRGB ("rescale"). */
-int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame,
+ * the four decoded 8-bit sRGB values, re-encoded to sRGB ("rescale").
+ * `alpha` / `alphas`: NULL unless the decoder has an alpha channel; the reference renders alpha
+ * clips through the same two passes (AAPLShaders.metal:411-438 into the intermediate, then
+ * MetalScaleRenderContext.m:55-105), where the alpha channel is stored and filtered as a plain
+ * unorm: out alpha = round(255 * mean(byteNorm(decoded alpha bytes))). */
+int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_frame *alpha,
                          const bt709hip_surface *out,
                          void *stream, int wait_until_completed);
 int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count,
-                               const bt709hip_frame *frames, const bt709hip_surface *outs,
+                               const bt709hip_frame *frames, const bt709hip_frame *alphas,
+                               const bt709hip_surface *outs,
                                void *stream, int wait_until_completed);
 
 /* Pass 1 + pass 2 fused for ANY output size (view-fit): out->width x out->height need not be
  * related to the frame size (down- or up-scaling).  Bilinear in linear light over the decoded
  * 8-bit sRGB values, texel-centre sampling, clamp-to-edge; for an exact 2:1 ratio the result is
  * bit-identical to bt709hip_decode_half.  The reference leaves this arithmetic to the sampler
- * hardware (AAPLShaders.metal:73-85), so the definition is ours ("rescale"). */
-int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
-                           void *stream, int wait_until_completed);
+ * hardware (AAPLShaders.metal:73-85), so the definition is ours ("rescale").
+ * The batch form takes `count` same-geometry frames and same-sized outputs in one launch
+ * (grid.z = frame; same count limits as bt709hip_decode_batch): AAPLRenderer.m:970-976 calls
+ * pass 2 once per frame, a 4K -> 1440p frame is a ~25 us kernel. */
+int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_frame *alpha,
+                           const bt709hip_surface *out, void *stream, int wait_until_completed);
+int bt709hip_decode_scaled_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
+                                 const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
+                                 int wait_until_completed);
 
 /* --------------------------------------------------------------- frame pool */
 /* Frames that live in HOST memory.  The reference hands the decoder CVPixelBuffers the GPU reads
@@ -248,12 +294,15 @@ int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, c
  *   submit   -> upload, decode, download enqueued on the slot's stream; returns at once
  *   wait     -> the slot's pinned BGRA rows, valid until the slot is acquired again
  * Slots are handed out round-robin, so `depth` frames overlap their copies and kernels.  The decoder
- * must not have an alpha channel and must outlive the pool; a pool is used from one thread at a time
- * (decoders and contexts may be shared between threads, each thread with pools / streams of its own). */
+ * must outlive the pool; a pool is used from one thread at a time (decoders and contexts may be
+ * shared between threads, each thread with pools / streams of its own).  For a decoder with an
+ * alpha channel every slot also owns an alpha plane: fetch its pinned pointer with
+ * bt709hip_pool_alpha_plane after acquire and fill it before submit. */
 int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth, bt709hip_pool **out);
 int bt709hip_pool_destroy(bt709hip_pool *pool);
 int bt709hip_pool_acquire(bt709hip_pool *pool, int *slot, void **y, size_t *y_stride, void **cbcr,
                           size_t *cbcr_stride);
+int bt709hip_pool_alpha_plane(bt709hip_pool *pool, int slot, void **alpha, size_t *alpha_stride);
 int bt709hip_pool_submit(bt709hip_pool *pool, int slot);
 int bt709hip_pool_wait(bt709hip_pool *pool, int slot, const void **bgra, size_t *stride);
 
@@ -270,6 +319,12 @@ int bt709hip_pool_wait(bt709hip_pool *pool, int slot, const void **bgra, size_t 
  * out->transfer are ignored.  Width and height must be even and equal on both sides. */
 int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_frame *out,
                     int input_gamma, int output_gamma, void *stream, int wait_until_completed);
+
+/* The encoder's lookup tables for one (input_gamma, output_gamma) pair are built on first use
+ * (device allocation + blocking copies).  That is not allowed while a stream records a graph:
+ * call this once per pair before bt709hip_graph_begin_capture (an encode that finds its tables
+ * missing during a capture returns BT709HIP_ERR_NOT_SETUP).  Idempotent. */
+int bt709hip_encoder_prepare(bt709hip_context *ctx, int input_gamma, int output_gamma);
 
 /* `count` same-sized pictures in ONE launch (the app encodes its frames one call at a time,
  * BGRAToBT709Converter.m:532-569; a 4K frame is a ~12 us kernel, too short to fill the chip).
@@ -293,6 +348,11 @@ int bt709hip_deinterleave_cbcr(bt709hip_context *ctx, const void *cbcr, size_t c
                                void *stream, int wait_until_completed);
 
 /* -------------------------------------------------------------- diagnostics */
+/* Streaming copy of `bytes` (a multiple of 16, both pointers 16-byte aligned) with 16-byte
+ * non-temporal loads and stores, one launch: the bandwidth a plain copy reaches on this device, for
+ * benchmarks that want to report a kernel against the same box's copy rate (no reference twin). */
+int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_t bytes, void *stream);
+
 const char *bt709hip_strerror(int status);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none). */
 int bt709hip_last_hip_error(void);
@@ -303,6 +363,10 @@ const char *bt709hip_last_hip_error_string(void);
  * constants:  8 floats {1/255, M_y, M_cr_r, M_cb_g, M_cr_g, M_cb_b, 16, 128}
  *             (matrix built as BT709.h:386-397). */
 int bt709hip_gamma_thresholds(int gamma, float thresholds[255]);
+/* The kernels' lookup of one saturated channel value x in [0,1], replayed on the host from the
+ * host-built bucket table (same index function, same compare): the byte the GPU would produce, and
+ * optionally the bucket count N and the bucket index.  Returns the byte, or <0 on a bad argument. */
+int bt709hip_gamma_lookup(int gamma, float x, int *bucket_count, int *bucket_index);
 int bt709hip_matrix_constants(float constants[8]);
 /* Name of the kernel the last decode on this thread launched (for profiling). */
 const char *bt709hip_last_kernel_name(void);

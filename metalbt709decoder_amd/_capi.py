@@ -20,7 +20,24 @@ class Frame(C.Structure):  # bt709hip_frame
 
 class Surface(C.Structure):  # bt709hip_surface
     _fields_ = [("bgra", C.c_void_p), ("stride", C.c_size_t),
-                ("width", C.c_int32), ("height", C.c_int32)]
+                ("width", C.c_int32), ("height", C.c_int32),
+                ("format", C.c_int32), ("reserved", C.c_int32)]
+
+
+ABI_VERSION = 200  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
+
+# bt709hip_format
+FORMAT_BGRA8_SRGB = 0
+FORMAT_RGBA16F = 1
+
+# bt709hip_decoder_option / bt709hip_context_option
+OPT_NONTEMPORAL = 1
+OPT_HALF_KERNEL = 2
+OPT_HALF_WORKGROUPS = 3
+OPT_HALF_LDS_KB = 4
+CTX_OPT_GRID_MULT = 1
+CTX_OPT_ENCODE_ROW_PAIRS = 2
+CTX_OPT_ENCODE_THREADS = 3
 
 
 class DeviceInfo(C.Structure):  # bt709hip_device_info
@@ -53,6 +70,8 @@ _P, _I, _Z = C.c_void_p, C.c_int, C.c_size_t
 _FP, _SP = C.POINTER(Frame), C.POINTER(Surface)
 SYMBOLS = {
     "bt709hip_device_count": (_I, []),
+    "bt709hip_abi_version": (_I, []),
+    "bt709hip_context_set_option": (_I, [_P, _I, _I]),
     "bt709hip_context_create": (_I, [_I, c_void_pp]),
     "bt709hip_context_destroy": (_I, [_P]),
     "bt709hip_context_info": (_I, [_P, C.POINTER(DeviceInfo)]),
@@ -68,6 +87,7 @@ SYMBOLS = {
     "bt709hip_pool_destroy": (_I, [_P]),
     "bt709hip_pool_acquire": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "bt709hip_pool_alpha_plane": (_I, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bt709hip_pool_submit": (_I, [_P, _I]),
     "bt709hip_pool_wait": (_I, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bt709hip_graph_begin_capture": (_I, [_P, _P]),
@@ -86,20 +106,26 @@ SYMBOLS = {
     "bt709hip_decoder_set_context": (_I, [_P, _P]),
     "bt709hip_decoder_set_alpha_fill": (_I, [_P, _I]),
     "bt709hip_decoder_get_gamma": (_I, [_P]),
+    "bt709hip_decoder_set_option": (_I, [_P, _I, _I]),
+    "bt709hip_decoder_get_option": (_I, [_P, _I, C.POINTER(C.c_int)]),
     "bt709hip_decoder_setup": (_I, [_P]),
     "bt709hip_decode": (_I, [_P, _FP, _FP, _SP, _I, _I, _P, _I]),
     "bt709hip_decode_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
-    "bt709hip_decode_half": (_I, [_P, _FP, _SP, _P, _I]),
-    "bt709hip_decode_half_batch": (_I, [_P, _I, _FP, _SP, _P, _I]),
-    "bt709hip_decode_scaled": (_I, [_P, _FP, _SP, _P, _I]),
+    "bt709hip_decode_half": (_I, [_P, _FP, _FP, _SP, _P, _I]),
+    "bt709hip_decode_half_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
+    "bt709hip_decode_scaled": (_I, [_P, _FP, _FP, _SP, _P, _I]),
+    "bt709hip_decode_scaled_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
+    "bt709hip_encoder_prepare": (_I, [_P, _I, _I]),
     "bt709hip_encode": (_I, [_P, _SP, _FP, _I, _I, _P, _I]),
     "bt709hip_encode_batch": (_I, [_P, _I, _SP, _FP, _I, _I, _P, _I]),
     "bt709hip_interleave_cbcr": (_I, [_P, _P, _Z, _P, _Z, _P, _Z, _I, _I, _P, _I]),
     "bt709hip_deinterleave_cbcr": (_I, [_P, _P, _Z, _P, _Z, _P, _Z, _I, _I, _P, _I]),
+    "bt709hip_copy_probe": (_I, [_P, _P, _P, _Z, _P]),
     "bt709hip_strerror": (C.c_char_p, [_I]),
     "bt709hip_last_hip_error": (_I, []),
     "bt709hip_last_hip_error_string": (C.c_char_p, []),
     "bt709hip_gamma_thresholds": (_I, [_I, C.POINTER(C.c_float)]),
+    "bt709hip_gamma_lookup": (_I, [_I, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bt709hip_matrix_constants": (_I, [C.POINTER(C.c_float)]),
     "bt709hip_last_kernel_name": (C.c_char_p, []),
 }
@@ -111,20 +137,34 @@ def library_path():
     return _build.LIB
 
 
-def load():
-    """Return the loaded C-ABI library, building it in-tree first if it is stale and a
-    compiler is present.  Raises (never falls back) when the library is unavailable."""
+def load(path=None):
+    """Return the loaded C-ABI library, building it in-tree first if it is stale.  Never runs a
+    library older than its sources or of another ABI version: when the library is stale and no
+    compiler is present, or the loaded library reports a BT709HIP_VERSION other than these
+    bindings', this raises (no fallback of any kind).
+    path: load THIS build of the library instead (A/B runs of tools/build_variant.py; must be the
+    first load of the process); it is not rebuilt, only ABI-checked."""
     global _lib
     if _lib is not None:
+        if path is not None and os.path.realpath(path) != os.path.realpath(_lib._name):
+            raise RuntimeError("another build of the library is already loaded: %s" % _lib._name)
         return _lib
-    path = _build.LIB
-    if _build.is_stale():
+    if path is None and _build.is_stale():
+        path = _build.LIB
         try:
-            _build.build()  # a compile error propagates: never run a library older than its sources
-        except OSError as exc:  # no hipcc on this machine: accept a prebuilt library if one shipped
-            if not os.path.exists(path):
-                raise ImportError("libbt709hip.so is missing and could not be built: %s" % exc)
-    lib = C.CDLL(path)
+            _build.build()  # a compile error propagates
+        except OSError as exc:  # no hipcc on this machine
+            raise ImportError("libbt709hip.so is %s and could not be (re)built: %s"
+                              % ("stale" if os.path.exists(path) else "missing", exc))
+    lib = C.CDLL(path or _build.LIB)
+    path = path or _build.LIB
+    try:
+        lib.bt709hip_abi_version.restype = C.c_int
+        have = lib.bt709hip_abi_version()
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise ImportError("%s reports ABI version %s, these bindings need %d" % (path, have, ABI_VERSION))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args

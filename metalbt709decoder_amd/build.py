@@ -7,6 +7,8 @@ travels to the GPU box with the repo snapshot).  -ffp-contract=off is part of th
 contract, not an optimisation choice: the kernels must not fuse multiply-adds
 (see csrc/bt709_kernels.hip).
 """
+import contextlib
+import fcntl
 import os
 import subprocess
 import sys
@@ -47,19 +49,53 @@ def is_stale(target=LIB):
     return any(os.path.getmtime(f) > t for f in _deps())
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """Exclusive advisory lock around the stale check and the compile.  Every rank of a
+    torch.distributed.run job imports the package at the same moment and may find the library
+    stale together: the first one in builds, the others wait here and then see a fresh file."""
+    fd = os.open(os.path.join(HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+
+
 def build(force=False, verbose=False):
-    """Compile libbt709hip.so if missing or older than its sources; returns its path."""
-    if not force and not is_stale():
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, *FLAGS, "-shared",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
+    """Compile libbt709hip.so if missing or older than its sources; returns its path.
+    Safe to call from several processes at once (file lock; the compiler writes to a private
+    temporary name that is renamed into place only when complete)."""
+    with _build_lock():
+        if not force and not is_stale():
+            return LIB
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, *FLAGS, "-shared",
+               *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return LIB
+
+
+def build_variant(out_path, defines):
+    """A second build of the library with extra -D flags (e.g. BT709_INDEX_RTZ), for same-call A/B
+    runs: bench.py --library <out_path>.  Never replaces the in-tree library."""
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, *FLAGS, *["-D" + d for d in defines], "-shared",
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out_path]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    return out_path
 
 
 def emit_asm(force=False):
@@ -69,7 +105,7 @@ def emit_asm(force=False):
     os.makedirs(os.path.dirname(ASM), exist_ok=True)
     parts = []
     for src in KERNEL_SOURCES:
-        out = ASM + "." + src
+        out = "%s.%d.%s" % (ASM, os.getpid(), src)
         cmd = [_hipcc(), "--offload-arch=" + ARCH, *[f for f in FLAGS if f != "-fPIC"], "-S",
                "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -77,13 +113,18 @@ def emit_asm(force=False):
             raise RuntimeError("hipcc -S failed:\n" + r.stdout + r.stderr)
         parts.append(open(out).read())
         os.remove(out)
-    with open(ASM + ".tmp", "w") as f:
+    tmp = "%s.%d.tmp" % (ASM, os.getpid())
+    with open(tmp, "w") as f:
         f.write("\n".join(parts))
-    os.replace(ASM + ".tmp", ASM)
+    os.replace(tmp, ASM)
     return ASM
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:  # python -m metalbt709decoder_amd.build --variant tools/bin/libbt709hip_rtz.so BT709_INDEX_RTZ
+        i = sys.argv.index("--variant")
+        print("built", build_variant(os.path.abspath(sys.argv[i + 1]), sys.argv[i + 2:]))
+        sys.exit(0)
     path = build(force="--force" in sys.argv, verbose=True)
     print("built", path)
     if "--asm" in sys.argv:

@@ -26,10 +26,10 @@
 //   * byte -> float is v_cvt_f32_ubyteN (4) and the centring a float add (2); left alone, hipcc
 //     rewrites (float)(byte) - 16.0f as an integer SDWA add plus v_cvt_f32_i32 (4 + 4);
 //   * R, G, B are saturated for free by the clamp bit of the add that produces them;
-//   * the bucket index of a saturated x is ONE 2-cycle add (magic_floor12) instead of a 4-cycle
-//     convert: with M = 2^23 / N a float in [M, 2M) has ulp 1/N, so x + M rounded TOWARD ZERO is
-//     M + floor(x N) / N and its bit pattern is bits(M) + floor(x N); a v_lshl_add_u32 turns
-//     that into the LDS byte address (its addend cancels bits(M) << shift).
+//   * the bucket index of a saturated x is ONE 2-cycle add (magic_index12) instead of a 4-cycle
+//     convert: with M = 2^23 / N a float in [M, 2M) has ulp 1/N, so x + M is M + round(x N) / N
+//     and its bit pattern is bits(M) + round(x N); a v_lshl_add_u32 turns that into the LDS byte
+//     address (its addend cancels bits(M) << shift).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -105,11 +105,13 @@ __device__ __forceinline__ float alpha_value(float abyte) {
   return add_sat(__fmul_rn(centre_norm(abyte, 16.0f), kMY), 0.0f);
 }
 
-// t[i] = bits(x[i] + magic) with the add rounded toward zero, for x in [0, 1]: bits(magic) +
-// floor(x N).  One asm statement, so nothing can be scheduled between the two writes of
-// MODE.fp_round's single-precision field (everything else rounds to nearest even); 12 values
-// because an asm statement takes at most 30 operands.
-__device__ __forceinline__ void magic_floor12(const float *x, uint32_t *t, float magic) {
+// t[i] = bits(x[i] + magic) for saturated x: bits(magic) + bucket index (transfer_tables.h).  The
+// default build uses the add as it stands (round to nearest even: bucket q is centred on q / N).
+// -DBT709_INDEX_RTZ builds round 1's floor(x N) form for A/B runs: the adds of a batch sit in one
+// asm statement between two writes of MODE.fp_round's single-precision field (everything else
+// rounds to nearest even); 12 values because an asm statement takes at most 30 operands.
+#if defined(BT709_INDEX_RTZ)
+__device__ __forceinline__ void magic_index12(const float *x, uint32_t *t, float magic) {
   asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
       "v_add_f32 %0, %24, %12\n\tv_add_f32 %1, %24, %13\n\tv_add_f32 %2, %24, %14\n\tv_add_f32 %3, %24, %15\n\t"
       "v_add_f32 %4, %24, %16\n\tv_add_f32 %5, %24, %17\n\tv_add_f32 %6, %24, %18\n\tv_add_f32 %7, %24, %19\n\t"
@@ -121,12 +123,42 @@ __device__ __forceinline__ void magic_floor12(const float *x, uint32_t *t, float
         "v"(x[10]), "v"(x[11]), "s"(magic));
 }
 
-__device__ __forceinline__ void magic_floor4(const float *x, uint32_t *t, float magic) {
+__device__ __forceinline__ void magic_index4(const float *x, uint32_t *t, float magic) {
   asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
       "v_add_f32 %0, %8, %4\n\tv_add_f32 %1, %8, %5\n\tv_add_f32 %2, %8, %6\n\tv_add_f32 %3, %8, %7\n\t"
       "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
       : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
       : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(magic));
+}
+#else
+__device__ __forceinline__ void magic_index12(const float *x, uint32_t *t, float magic) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
+}
+
+__device__ __forceinline__ void magic_index4(const float *x, uint32_t *t, float magic) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
+}
+#endif
+
+// Lookup constants of the byte-valued bucket table (TransferBucket, 8 bytes) held at `lds_table`.
+struct UnitLookup {
+  float magic;      // M = 2^23 / N
+  uint32_t offset;  // LDS address of the table - (bits(M) << 3)
+};
+
+__device__ __forceinline__ UnitLookup unit_lookup(float magic, const void *lds_table) {
+  UnitLookup u;
+  u.magic = magic;
+  u.offset = lds_address(lds_table) - (__float_as_uint(magic) << 3);
+  return u;
+}
+
+// byte of the decoder's gamma for saturated x, t = bits(x + M) from magic_index*
+__device__ __forceinline__ uint32_t bucket_byte(const UnitLookup &u, float x, uint32_t t) {
+  const u32x2 e = *reinterpret_cast<LdsPairPtr>((t << 3) + u.offset);  // {edge bits, base}
+  return e.y + (x >= __uint_as_float(e.x) ? 1u : 0u);
 }
 
 // (A<<24)|(R<<16)|(G<<8)|B in two VALU ops: v_perm_b32 places R and G (bytes 2 and 1, zeros

@@ -43,12 +43,16 @@ struct DecodeParams {
   // sRGB-encode table (transfer_tables.h SplitTable): q = min(qf, (qf >> encode_shift) + encode_offset)
   const void *table_linear;
   const void *table_encode;
+  // alpha decoders, rescale kernels: TransferBucketLinear[N + 1] whose values are byteNorm(byte)
+  // (transfer_tables.h buckets_bytenorm): pass 2 filters the alpha channel as a plain unorm
+  const void *table_alpha;
+  uint32_t table_alpha_bytes;
   uint32_t table_unit_bytes;
   uint32_t table_linear_bytes;
   uint32_t table_encode_bytes;
   float encode_scale;  // n_fine of table_encode
   uint32_t encode_offset, encode_shift;
-  float unit_magic;    // 2^23 / N: floats in [M, 2M) have ulp 1/N (bt709_device.h magic_floor12)
+  float unit_magic;    // 2^23 / N: floats in [M, 2M) have ulp 1/N (bt709_device.h magic_index12)
   uint32_t width;      // luma (source) dimensions
   uint32_t height;
   uint32_t y_stride;
@@ -125,6 +129,8 @@ struct PlaneParams {
   uint32_t wide;     // 1: 8 samples per lane with 8/16-byte accesses
 };
 const char *launch_planes(const PlaneParams &p, bool interleave, hipStream_t stream);
+// 16-byte-per-lane non-temporal streaming copy (bt709_planes.hip): the same-box copy ceiling benchmarks report.
+const char *launch_copy_probe(void *dst, const void *src, size_t bytes, hipStream_t stream);
 
 // Launchers return the kernel's name (static string) for profiling; launch errors
 // are read by the caller with hipGetLastError().
@@ -133,8 +139,8 @@ const char *launch_planes(const PlaneParams &p, bool interleave, hipStream_t str
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
 // half: grid = (grid_x, H/2 output rows, frames) x block_threads.
-const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
-                               uint32_t block_threads, hipStream_t stream);
+const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool has_alpha, bool nontemporal,
+                               uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
 
 // half, conflict-free form: grid = workgroups (<= compute units, one resident per CU) x block_threads,
 // each walking tile rows workgroup, workgroup + grid, ...; fills the rep_*, tiles_x, tile_rows and cursor_*
@@ -146,7 +152,9 @@ constexpr int kRepBlockThreads = 1024;      // one workgroup per CU: 16 waves
 constexpr uint32_t kRepLdsBytes = 160 * 1024;
 
 // scaled: grid = (ceil(OW / kBlockThreads), ceil(OH / rows), frames) x kBlockThreads, rows chosen from the CU count.
-const char *launch_decode_scaled(const DecodeParams &p, int frames, uint32_t compute_units, hipStream_t stream);
+// in_align: largest power of two dividing every input plane pointer, pitch and frame spacing (picks the tap fetch width).
+const char *launch_decode_scaled(const DecodeParams &p, int frames, bool has_alpha, uint32_t in_align,
+                                 uint32_t compute_units, hipStream_t stream);
 
 // Fast-path launch geometry for a frame width: tiles (workgroups) per row pair and the
 // workgroup size -- ceil(quads per tile / kQuadsPerLane) rounded up to a whole wave.

@@ -79,6 +79,27 @@ deinterleave_cbcr(const PlaneParams p) {
   }
 }
 
+// Streaming copy, 16 bytes per lane, non-temporal both ways, one short-lived workgroup per 16 KiB
+// dispatched in address order (the launch shape the decode kernels use): what a plain copy reaches
+// on this device.  n16 = number of 16-byte units.
+__global__ void __launch_bounds__(512)
+copy_probe(u32x4 *__restrict__ dst, const u32x4 *__restrict__ src, size_t n16) {
+  const size_t i0 = static_cast<size_t>(blockIdx.x) * 1024 + threadIdx.x, i1 = i0 + 512;
+  u32x4 a = {}, b = {};
+  if (i0 < n16) a = __builtin_nontemporal_load(src + i0);
+  if (i1 < n16) b = __builtin_nontemporal_load(src + i1);
+  if (i0 < n16) __builtin_nontemporal_store(a, dst + i0);
+  if (i1 < n16) __builtin_nontemporal_store(b, dst + i1);
+}
+
+const char *launch_copy_probe(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+  const size_t n16 = bytes / 16;
+  const size_t blocks = (n16 + 1023) / 1024;
+  hipLaunchKernelGGL(copy_probe, dim3(static_cast<uint32_t>(blocks)), dim3(512), 0, stream, static_cast<u32x4 *>(dst),
+                     static_cast<const u32x4 *>(src), n16);
+  return "copy_probe";
+}
+
 const char *launch_planes(const PlaneParams &p, bool interleave, hipStream_t stream) {
   const uint32_t items = p.wide ? p.chroma_width / 8 : p.chroma_width;
   uint32_t gx = (items + kBlockThreads - 1) / kBlockThreads;

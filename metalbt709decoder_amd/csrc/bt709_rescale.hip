@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t encode_byte(const RescaleLookup &r, float xs
 // linear-light values (times 2^-40) of 12 saturated channel values: 6 buckets in flight per wait
 __device__ __forceinline__ void linearise12(const RescaleLookup &r, const float *x, float *lin) {
   uint32_t t[12];
-  magic_floor12(x, t, r.magic);
+  magic_index12(x, t, r.magic);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     u32x4 e[6];  // {edge, lin(base), lin(base + 1), base}: whole vectors keep the read a ds_read_b128
@@ -96,6 +96,65 @@ __device__ __forceinline__ void linearise12(const RescaleLookup &r, const float 
       lin[6 * h + i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z),
                                                __fadd_rn(x[6 * h + i], -__uint_as_float(e[i].x)));
   }
+}
+
+// Alpha decoders only.  Pass 2 reads the alpha channel of the 8-bit intermediate as a plain unorm
+// (AAPLShaders.metal:411-438 writes it, the sampler of MetalScaleRenderContext.m:55-105 filters
+// it): each tap is byteNorm(decoded alpha byte), the result round(255 v).  The byteNorm table has
+// the decode table's buckets (an alpha decoder runs the sRGB mode, whose composite is round(255 x)),
+// and that same mode's byte table quantises the filtered value.  Both sit behind the two rescale
+// tables in LDS, single copies.
+struct AlphaLookup {
+  uint32_t norm_off;  // LDS address of the byteNorm table - (bits(magic) << 4)
+  UnitLookup unit;    // the decoder's byte table (sRGB mode: the quantiser)
+  float unscale;      // 2^40: the byteNorm values are stored times 2^-40 like the linear ones
+};
+
+__device__ __forceinline__ AlphaLookup stage_alpha_tables(unsigned char *lds, const DecodeParams &p) {
+  const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
+  u32x4 *d = reinterpret_cast<u32x4 *>(lds);
+  const u32x4 *a = reinterpret_cast<const u32x4 *>(p.table_alpha);
+  const u32x4 *u = reinterpret_cast<const u32x4 *>(p.table_unit);
+  const uint32_t na = p.table_alpha_bytes / 16, nu = p.table_unit_bytes / 16;
+  for (uint32_t i = tid; i < na; i += nthreads) d[i] = a[i];
+  for (uint32_t i = tid; i < nu; i += nthreads) d[na + i] = u[i];
+  AlphaLookup r;
+  r.norm_off = lds_address(lds) - (__float_as_uint(p.unit_magic) << 4);
+  r.unit = unit_lookup(p.unit_magic, lds + p.table_alpha_bytes);
+  r.unscale = __uint_as_float(static_cast<uint32_t>(127 - kLinearScaleLog2) << 23);
+  return r;
+}
+
+// byteNorm (times 2^-40) of the alpha bytes of four linear alpha samples
+__device__ __forceinline__ void alpha_norm4(const AlphaLookup &a, float magic, const float *abyte, float *n) {
+  float x[4];
+  uint32_t t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = alpha_value(abyte[i]);
+  magic_index4(x, t, magic);
+  u32x4 e[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<LdsQuadPtr>((t[i] << 4) + a.norm_off);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    n[i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z), __fadd_rn(x[i], -__uint_as_float(e[i].x)));
+}
+
+// (alpha byte << 24) of a filtered alpha value v in [0, 1]: round(255 v)
+__device__ __forceinline__ uint32_t alpha_quantise(const AlphaLookup &a, float v) {
+  const float x[4] = {v, 0.0f, 0.0f, 0.0f};
+  uint32_t t[4];
+  magic_index4(x, t, a.unit.magic);
+  return bucket_byte(a.unit, v, t[0]) << 24;
+}
+
+// alpha word of one 2:1 output pixel from its four alpha samples
+__device__ __forceinline__ uint32_t half_alpha(const AlphaLookup &a, float magic, float a00, float a01, float a10, float a11) {
+  const float ab[4] = {a00, a01, a10, a11};
+  float n[4];
+  alpha_norm4(a, magic, ab, n);
+  const float quarter = __fmul_rn(0.25f, a.unscale);
+  return alpha_quantise(a, __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(n[0], n[1]), n[2]), n[3]), quarter));
 }
 
 // One output pixel of the exact 2:1 rescale: the four source pixels of a 2x2 block share one
@@ -117,14 +176,14 @@ __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, f
   return pack_bgra(encode_byte(r, mr), encode_byte(r, mg), encode_byte(r, mb), alpha_word);
 }
 
-// the two output pixels of a quad (4x2 source pixels)
+// the two output pixels of a quad (4x2 source pixels); aw0 / aw1 = their alpha words
 __device__ __forceinline__ u32x2 half_quad(const RescaleLookup &r, uint32_t ya, uint32_t yb, uint32_t cw,
-                                           uint32_t alpha_word) {
+                                           uint32_t aw0, uint32_t aw1) {
   const Chroma c0 = chroma_terms(byte_of(cw, 0), byte_of(cw, 1));
   const Chroma c1 = chroma_terms(byte_of(cw, 2), byte_of(cw, 3));
   u32x2 v;
-  v.x = half_px(r, byte_of(ya, 0), byte_of(ya, 1), byte_of(yb, 0), byte_of(yb, 1), c0, alpha_word);
-  v.y = half_px(r, byte_of(ya, 2), byte_of(ya, 3), byte_of(yb, 2), byte_of(yb, 3), c1, alpha_word);
+  v.x = half_px(r, byte_of(ya, 0), byte_of(ya, 1), byte_of(yb, 0), byte_of(yb, 1), c0, aw0);
+  v.y = half_px(r, byte_of(ya, 2), byte_of(ya, 3), byte_of(yb, 2), byte_of(yb, 3), c1, aw1);
   return v;
 }
 
@@ -137,7 +196,7 @@ __device__ __forceinline__ u32x2 half_quad(const RescaleLookup &r, uint32_t ya, 
 // Preconditions: width % 4 == 0, planes/strides 4-byte aligned, output 8-byte aligned.
 // !WIDE: one lane per output pixel, byte loads, any layout.
 // ---------------------------------------------------------------------------
-template <bool NT, bool WIDE>
+template <bool NT, bool WIDE, bool HAS_ALPHA>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_half(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -148,39 +207,62 @@ decode_nv12_half(const DecodeParams p) {
   const uint8_t *y0 = f.y + static_cast<size_t>(2 * orow) * p.y_stride;
   const uint8_t *y1 = y0 + p.y_stride;
   const uint8_t *cc = f.cbcr + static_cast<size_t>(orow) * p.cbcr_stride;
+  const uint8_t *a0 = HAS_ALPHA ? f.alpha + static_cast<size_t>(2 * orow) * p.alpha_stride : nullptr;
+  const uint8_t *a1 = HAS_ALPHA ? a0 + p.alpha_stride : nullptr;
   uint8_t *o = f.out + static_cast<size_t>(orow) * p.out_stride;
+  unsigned char *lds_alpha = lds_raw + p.table_linear_bytes + p.table_encode_bytes;
 
   if (WIDE) {
     constexpr int UNROLL = kQuadsPerLane;
     const uint32_t quads = p.width >> 2;
     const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
-    uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL];
+    uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t q = min(q0 + u * blockDim.x, quads - 1);  // clamped load, predicated store (see 1:1 kernel)
       ya[u] = load32<NT>(y0 + 4 * q);
       yb[u] = load32<NT>(y1 + 4 * q);
       cw[u] = load32<NT>(cc + 4 * q);
+      if (HAS_ALPHA) {
+        aa[u] = load32<NT>(a0 + 4 * q);
+        ab[u] = load32<NT>(a1 + 4 * q);
+      }
     }
     const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);  // after the tile's loads are in flight
+    AlphaLookup al = {};
+    if (HAS_ALPHA) al = stage_alpha_tables(lds_alpha, p);
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) asm volatile("" : "+v"(ya[u]), "+v"(yb[u]), "+v"(cw[u]));  // see 1:1 kernel
+    for (int u = 0; u < UNROLL; ++u) {  // see 1:1 kernel
+      asm volatile("" : "+v"(ya[u]), "+v"(yb[u]), "+v"(cw[u]));
+      if (HAS_ALPHA) asm volatile("" : "+v"(aa[u]), "+v"(ab[u]));
+    }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t q = q0 + u * blockDim.x;
-      const u32x2 v = half_quad(r, ya[u], yb[u], cw[u], p.alpha_word);
+      uint32_t aw0 = p.alpha_word, aw1 = p.alpha_word;
+      if (HAS_ALPHA) {
+        aw0 = half_alpha(al, r.magic, byte_of(aa[u], 0), byte_of(aa[u], 1), byte_of(ab[u], 0), byte_of(ab[u], 1));
+        aw1 = half_alpha(al, r.magic, byte_of(aa[u], 2), byte_of(aa[u], 3), byte_of(ab[u], 2), byte_of(ab[u], 3));
+      }
+      const u32x2 v = half_quad(r, ya[u], yb[u], cw[u], aw0, aw1);
       if (q < quads && orow_raw < out_rows) store8<NT>(o + 8 * q, v);
     }
   } else {
     const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);
+    AlphaLookup al = {};
+    if (HAS_ALPHA) al = stage_alpha_tables(lds_alpha, p);
     __syncthreads();
     const uint32_t out_w = p.width >> 1;
     for (uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x; ox < out_w && orow_raw < out_rows;
          ox += gridDim.x * blockDim.x) {
       const Chroma c = chroma_terms(byte_value(cc[2 * ox]), byte_value(cc[2 * ox + 1]));
+      uint32_t aw = p.alpha_word;
+      if (HAS_ALPHA)
+        aw = half_alpha(al, r.magic, byte_value(a0[2 * ox]), byte_value(a0[2 * ox + 1]), byte_value(a1[2 * ox]),
+                        byte_value(a1[2 * ox + 1]));
       reinterpret_cast<uint32_t *>(o)[ox] = half_px(r, byte_value(y0[2 * ox]), byte_value(y0[2 * ox + 1]),
-                                                    byte_value(y1[2 * ox]), byte_value(y1[2 * ox + 1]), c, p.alpha_word);
+                                                    byte_value(y1[2 * ox]), byte_value(y1[2 * ox + 1]), c, aw);
     }
   }
 }
@@ -291,7 +373,7 @@ decode_nv12_half_rep(const DecodeParams p) {
     for (int u = 0; u < U; ++u) {
       const bool have = t + u * G < p.tile_rows;
       const TileCursor c = {have ? cur.tx : first.tx, have ? cur.rp : first.rp, have ? cur.f : first.f};
-      const u32x2 v = half_quad(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word);
+      const u32x2 v = half_quad(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word, p.alpha_word);
       const FramePlanes f = frame_planes(p, c.f);
       uint8_t *o = f.out + static_cast<size_t>(c.rp) * p.out_stride;
       // lanes past the row's end loaded the last quad (clamp), hold its result and store it again
@@ -331,12 +413,14 @@ decode_nv12_half_rep(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 enum : int { TAPS_BYTES = 0, TAPS_PAIRS = 1, TAPS_WIDE = 2 };
 
-template <int TAPS>
+template <int TAPS, bool HAS_ALPHA>
 __global__ void __launch_bounds__(kBlockThreads)
 decode_nv12_scaled(const DecodeParams p) {
   typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);
+  AlphaLookup al = {};
+  if (HAS_ALPHA) al = stage_alpha_tables(lds_raw + p.table_linear_bytes + p.table_encode_bytes, p);
   __syncthreads();
 
   const FramePlanes f = frame_planes(p, blockIdx.z);
@@ -371,9 +455,9 @@ decode_nv12_scaled(const DecodeParams p) {
     rt.ys[1] = min(max(yi + 1, 0), hmax);
     return rt;
   };
-  // the source bytes of one output pixel: [row] = {Y0 | Y1 << 8, Cb0 | Cr0 << 8 | Cb1 << 16 | Cr1 << 24}
+  // the source bytes of one output pixel: [row] = {Y0 | Y1 << 8, Cb0 | Cr0 << 8 | Cb1 << 16 | Cr1 << 24, A0 | A1 << 8}
   struct Fetched {
-    uint32_t yy[2], cc[2];
+    uint32_t yy[2], cc[2], aa[2];
   };
   auto fetch = [&](const RowTaps &rt) {
     Fetched v;
@@ -381,13 +465,20 @@ decode_nv12_scaled(const DecodeParams p) {
     for (int row = 0; row < 2; ++row) {
       const uint8_t *yrow = f.y + static_cast<size_t>(rt.ys[row]) * p.y_stride;
       const uint8_t *crow = f.cbcr + static_cast<size_t>(rt.ys[row] >> 1) * p.cbcr_stride;
+      const uint8_t *arow = HAS_ALPHA ? f.alpha + static_cast<size_t>(rt.ys[row]) * p.alpha_stride : nullptr;
+      v.aa[row] = 0;
       if (TAPS == TAPS_WIDE) {
         const u32x2a4 yw = *reinterpret_cast<const u32x2a4 *>(yrow + ybase);
         const u32x2a4 cw = *reinterpret_cast<const u32x2a4 *>(crow + cbase);
         v.yy[row] = __builtin_amdgcn_perm(yw.y, yw.x, ysel);
         v.cc[row] = __builtin_amdgcn_perm(cw.y, cw.x, csel);
+        if (HAS_ALPHA) {
+          const u32x2a4 aw = *reinterpret_cast<const u32x2a4 *>(arow + ybase);
+          v.aa[row] = __builtin_amdgcn_perm(aw.y, aw.x, ysel);
+        }
       } else {
         v.yy[row] = yrow[xs[0]] | (static_cast<uint32_t>(yrow[xs[1]]) << 8);
+        if (HAS_ALPHA) v.aa[row] = arow[xs[0]] | (static_cast<uint32_t>(arow[xs[1]]) << 8);
         if (TAPS == TAPS_PAIRS) {
           v.cc[row] = *reinterpret_cast<const uint16_t *>(crow + cx[0]) |
                       (static_cast<uint32_t>(*reinterpret_cast<const uint16_t *>(crow + cx[1])) << 16);
@@ -432,7 +523,17 @@ decode_nv12_scaled(const DecodeParams p) {
     const uint32_t R = encode_byte(r, __fmul_rn(acc[0], r.scale));
     const uint32_t G = encode_byte(r, __fmul_rn(acc[1], r.scale));
     const uint32_t B = encode_byte(r, __fmul_rn(acc[2], r.scale));
-    reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, p.alpha_word);
+    uint32_t aw = p.alpha_word;
+    if (HAS_ALPHA) {
+      const float ab[4] = {byte_of(cur.aa[0], 0), byte_of(cur.aa[0], 1), byte_of(cur.aa[1], 0), byte_of(cur.aa[1], 1)};
+      float n[4];
+      alpha_norm4(al, r.magic, ab, n);
+      float av = __fmul_rn(w[0], n[0]);
+#pragma unroll
+      for (int t = 1; t < 4; ++t) av = __fadd_rn(av, __fmul_rn(w[t], n[t]));
+      aw = alpha_quantise(al, add_sat(__fmul_rn(av, al.unscale), 0.0f));
+    }
+    reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, aw);
     cur = nxt;
     rt = nrt;
   }
@@ -445,18 +546,24 @@ decode_nv12_scaled(const DecodeParams p) {
 #define BT709_REP_STEP 2  // tile rows per step of the persistent kernel (loads run one step ahead)
 #endif
 
-const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool nontemporal, uint32_t grid_x,
-                               uint32_t block_threads, hipStream_t stream) {
+const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool has_alpha, bool nontemporal,
+                               uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
   const uint32_t by = wide ? quads_rows_per_block(block_threads, grid_x) : 1;
   const dim3 grid(grid_x, (p.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
   const dim3 block(block_threads, by, 1);
-  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes;
+  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes +
+                     (has_alpha ? static_cast<size_t>(p.table_alpha_bytes) + p.table_unit_bytes : 0);
+  if (has_alpha) {
+    if (wide) hipLaunchKernelGGL((decode_nv12_half<true, true, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((decode_nv12_half<false, false, true>), grid, block, lds, stream, p);
+    return wide ? "decode_nv12_half<wide,alpha>" : "decode_nv12_half<narrow,alpha>";
+  }
   if (wide) {
-    if (nontemporal) hipLaunchKernelGGL((decode_nv12_half<true, true>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((decode_nv12_half<false, true>), grid, block, lds, stream, p);
+    if (nontemporal) hipLaunchKernelGGL((decode_nv12_half<true, true, false>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((decode_nv12_half<false, true, false>), grid, block, lds, stream, p);
     return "decode_nv12_half<wide>";
   }
-  hipLaunchKernelGGL((decode_nv12_half<false, false>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((decode_nv12_half<false, false, false>), grid, block, lds, stream, p);
   return "decode_nv12_half<narrow>";
 }
 
@@ -493,7 +600,8 @@ const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool no
   return "decode_nv12_half_rep";
 }
 
-const char *launch_decode_scaled(const DecodeParams &p_in, int frames, uint32_t compute_units, hipStream_t stream) {
+const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_alpha, uint32_t in_align,
+                                 uint32_t compute_units, hipStream_t stream) {
   DecodeParams p = p_in;
   // rows per workgroup: as many as still leave ~8 workgroups per CU (table staging is per workgroup)
   const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
@@ -502,37 +610,42 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, uint32_t 
   rows = rows < 1 ? 1 : (rows > 32 ? 32 : rows);
   p.scaled_rows = rows;
   const dim3 grid(cols, (p.out_height + rows - 1) / rows, static_cast<uint32_t>(frames));
-  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes;
-  // widest tap fetch the layout allows (see the kernel)
-  uint32_t align = 4;
-  auto fold = [&align](uintptr_t v) { while (align > 1 && v % align) align /= 2; };
-  fold(p.y_stride);
-  fold(p.cbcr_stride);
-  for (int i = 0; i < frames && i < kMaxBatch; ++i) {
-    fold(reinterpret_cast<uintptr_t>(p.frames[i].y));
-    fold(reinterpret_cast<uintptr_t>(p.frames[i].cbcr));
+  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes +
+                     (has_alpha ? static_cast<size_t>(p.table_alpha_bytes) + p.table_unit_bytes : 0);
+  // widest tap fetch the layout allows (see the kernel); the frame spacing of a uniform batch counts too
+  uint32_t align = in_align > 4 ? 4 : in_align;
+  auto fold = [&align](uint64_t v) { while (align > 1 && v % align) align /= 2; };
+  if (p.uniform) fold(static_cast<uint64_t>(p.step_y)), fold(static_cast<uint64_t>(p.step_cbcr)), fold(static_cast<uint64_t>(p.step_alpha));
+  const int taps = (align == 4 && p.width % 4 == 0 && p.width >= 8) ? TAPS_WIDE : (align >= 2 ? TAPS_PAIRS : TAPS_BYTES);
+  const dim3 block(kBlockThreads);
+  if (has_alpha) {
+    if (taps == TAPS_WIDE) hipLaunchKernelGGL((decode_nv12_scaled<TAPS_WIDE, true>), grid, block, lds, stream, p);
+    else if (taps == TAPS_PAIRS) hipLaunchKernelGGL((decode_nv12_scaled<TAPS_PAIRS, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((decode_nv12_scaled<TAPS_BYTES, true>), grid, block, lds, stream, p);
+    return "decode_nv12_scaled<alpha>";
   }
-  if (p.uniform) fold(static_cast<uintptr_t>(p.step_y)), fold(static_cast<uintptr_t>(p.step_cbcr));
-  if (align == 4 && p.width % 4 == 0 && p.width >= 8)
-    hipLaunchKernelGGL(decode_nv12_scaled<TAPS_WIDE>, grid, dim3(kBlockThreads), lds, stream, p);
-  else if (align >= 2 || ((p.cbcr_stride % 2) == 0 && (reinterpret_cast<uintptr_t>(p.frames[0].cbcr) % 2) == 0 && frames == 1))
-    hipLaunchKernelGGL(decode_nv12_scaled<TAPS_PAIRS>, grid, dim3(kBlockThreads), lds, stream, p);
-  else
-    hipLaunchKernelGGL(decode_nv12_scaled<TAPS_BYTES>, grid, dim3(kBlockThreads), lds, stream, p);
+  if (taps == TAPS_WIDE) hipLaunchKernelGGL((decode_nv12_scaled<TAPS_WIDE, false>), grid, block, lds, stream, p);
+  else if (taps == TAPS_PAIRS) hipLaunchKernelGGL((decode_nv12_scaled<TAPS_PAIRS, false>), grid, block, lds, stream, p);
+  else hipLaunchKernelGGL((decode_nv12_scaled<TAPS_BYTES, false>), grid, block, lds, stream, p);
   return "decode_nv12_scaled";
 }
 
 hipError_t prepare_rescale_kernels() {
   const int cap = static_cast<int>(kRepLdsBytes);  // gfx950: 160 KiB LDS per workgroup
   const void *fns[] = {
-      reinterpret_cast<const void *>(&decode_nv12_half<true, true>),
-      reinterpret_cast<const void *>(&decode_nv12_half<false, true>),
-      reinterpret_cast<const void *>(&decode_nv12_half<false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_half<true, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_half<false, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_half<false, false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_half<true, true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_half<false, false, true>),
       reinterpret_cast<const void *>(&decode_nv12_half_rep<true, BT709_REP_STEP>),
       reinterpret_cast<const void *>(&decode_nv12_half_rep<false, BT709_REP_STEP>),
-      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_BYTES>),
-      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_PAIRS>),
-      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_WIDE>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_BYTES, false>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_PAIRS, false>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_WIDE, false>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_BYTES, true>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_PAIRS, true>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_WIDE, true>),
   };
   for (const void *fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

@@ -35,7 +35,9 @@ struct bt709hip_context {
   int device = 0;
   hipDeviceProp_t props;
   hipStream_t default_stream = nullptr;
-  int grid_blocks = 0;  // workgroups a launch aims for (all frames together)
+  int grid_mult = 2;    // BT709HIP_CTX_OPT_GRID_MULT
+  int grid_blocks = 0;  // workgroups a general-path launch aims for (all frames together)
+  int encode_row_pairs = 0, encode_threads = 0;  // BT709HIP_CTX_OPT_ENCODE_*: 0 = sized per launch
   std::mutex encoder_mutex;
   EncoderTables encoders[3][3];  // [input gamma][output gamma], built on first use
 };
@@ -45,8 +47,10 @@ struct bt709hip_decoder {
   int gamma = BT709HIP_GAMMA_APPLE;
   int has_alpha = 0;
   uint32_t alpha_fill = 0xFF;
-  bool nontemporal = true;
-  int half_rep = -1;  // persistent conflict-free rescale kernel: -1 = when the launch is large enough, 0 never, 1 always
+  bool nontemporal = true;  // BT709HIP_OPT_NONTEMPORAL
+  int half_rep = -1;        // BT709HIP_OPT_HALF_KERNEL: persistent conflict-free rescale kernel: -1 = when the launch is large enough, 0 never, 1 always
+  int half_workgroups = 0;  // BT709HIP_OPT_HALF_WORKGROUPS: 0 = one per compute unit
+  int half_lds_kb = 0;      // BT709HIP_OPT_HALF_LDS_KB: 0 = all 160
   std::mutex setup_mutex;
   bool ready = false;
   // device copies (transfer_tables.h)
@@ -55,6 +59,7 @@ struct bt709hip_decoder {
   uint32_t table_unit_bytes = 0;
   void *d_table_linear = nullptr;  // TransferBucketLinear[N + 1] (rescale kernels, decode side)
   uint32_t table_linear_bytes = 0;
+  void *d_table_alpha = nullptr;   // alpha decoders: TransferBucketLinear[N + 1] with byteNorm values (rescale kernels)
   void *d_encode = nullptr;        // LINEAR-mode two-resolution TransferBucket[] (rescale kernels, encode side)
   uint32_t encode_bytes = 0;
   uint32_t encode_n = 0;
@@ -64,7 +69,7 @@ struct bt709hip_decoder {
 struct bt709hip_pool {
   struct Slot {
     hipStream_t stream = nullptr;
-    uint8_t *h_in = nullptr, *h_out = nullptr;  // pinned
+    uint8_t *h_in = nullptr, *h_out = nullptr;  // pinned; h_in = Y, CbCr (and the alpha plane behind them)
     uint8_t *d_in = nullptr, *d_out = nullptr;
     bool busy = false;       // submitted, not yet waited for
     bool acquired = false;   // handed out, not yet submitted
@@ -104,10 +109,10 @@ hipStream_t pick(const bt709hip_context *ctx, void *stream) {
 
 bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-int env_int(const char *name, int fallback) {
-  const char *v = std::getenv(name);
-  return (v && *v) ? std::atoi(v) : fallback;
-}
+int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// gridDim.y / .z limit of a HIP launch: the row-pair dimension of every kernel lives there
+constexpr int kMaxGridYZ = 65535;
 
 // transfer tag the configured gamma insists on (MetalBT709Decoder.m:335-353)
 int required_transfer(int gamma) {
@@ -138,17 +143,43 @@ int validate(const bt709hip_decoder *dec, const bt709hip_frame *f, const bt709hi
   if (f->y_stride < static_cast<size_t>(f->width) || f->cbcr_stride < static_cast<size_t>(f->width))
     return BT709HIP_ERR_STRIDE;
   if (dec->has_alpha && a->y_stride < static_cast<size_t>(a->width)) return BT709HIP_ERR_STRIDE;
-  if (o->stride < static_cast<size_t>(out_w) * 4 || (o->stride & 3) || !aligned(o->bgra, 4))
+  if ((o->format != BT709HIP_FORMAT_BGRA8_SRGB && o->format != BT709HIP_FORMAT_RGBA16F) || o->reserved != 0)
+    return BT709HIP_ERR_INVALID_ARG;
+  const size_t px = o->format == BT709HIP_FORMAT_RGBA16F ? 8 : 4;  // bytes per output pixel
+  if (o->stride < static_cast<size_t>(out_w) * px || (o->stride & (px - 1)) || !aligned(o->bgra, px))
     return BT709HIP_ERR_STRIDE;
   if (f->y_stride > 0xffffffffu || f->cbcr_stride > 0xffffffffu || o->stride > 0xffffffffu)
     return BT709HIP_ERR_STRIDE;
   return BT709HIP_OK;
 }
 
+// Device copy of a host table.  *dst is written only when the copy has succeeded, so a field that
+// doubles as the "already built" marker never points at uninitialised memory.
 int upload_table(const void *src, size_t bytes, void **dst) {
-  HIP_TRY(hipMalloc(dst, bytes));
-  HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  void *d = nullptr;
+  HIP_TRY(hipMalloc(&d, bytes));
+  const hipError_t e = hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return hip_fail(e);
+  }
+  *dst = d;
   return BT709HIP_OK;
+}
+
+// hipMalloc + blocking hipMemcpy are illegal while the calling thread records a graph; lazily
+// built tables must exist before bt709hip_graph_begin_capture.
+bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return s != nullptr && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+// -decodeBT709 calls -setupMetal first (.m:228-231).  The first setup allocates and copies, which a
+// recording stream must not see: set the decoder up before bt709hip_graph_begin_capture.
+int ensure_setup(bt709hip_decoder *dec, void *stream) {
+  if (dec->ready) return BT709HIP_OK;  // benign race: setup itself is serialised by its mutex
+  if (dec->ctx != nullptr && capturing(static_cast<hipStream_t>(stream))) return BT709HIP_ERR_NOT_SETUP;
+  return bt709hip_decoder_setup(dec);
 }
 
 // Table pointers and lookup constants of a launch.
@@ -157,6 +188,8 @@ void set_tables(DecodeParams *p, const bt709hip_decoder *dec) {
   p->table_unit_bytes = dec->table_unit_bytes;
   p->table_linear = dec->d_table_linear;
   p->table_linear_bytes = dec->table_linear_bytes;
+  p->table_alpha = dec->d_table_alpha;
+  p->table_alpha_bytes = dec->d_table_alpha ? dec->table_linear_bytes : 0;
   p->table_encode = dec->d_encode;
   p->table_encode_bytes = dec->encode_bytes;
   p->encode_scale = static_cast<float>(dec->encode_n);
@@ -184,6 +217,36 @@ bool evenly_spaced(int count, const bt709hip_frame *frames, const bt709hip_frame
     if (alphas && byte_step(alphas[0].y, alphas[i].y) != da * i) return false;
   }
   return true;
+}
+
+// Builds (once) the device tables of one (input gamma, output gamma) encoder pair.  Both uploads go
+// into locals and are published together: a failed second upload leaves the pair unbuilt, not half
+// built.  Refused while `s` records a graph (hipMalloc / blocking copies are illegal there): call
+// bt709hip_encoder_prepare before bt709hip_graph_begin_capture.
+int encoder_tables(bt709hip_context *ctx, int input_gamma, int output_gamma, hipStream_t s) {
+  EncoderTables &t = ctx->encoders[input_gamma][output_gamma];
+  std::lock_guard<std::mutex> lock(ctx->encoder_mutex);
+  if (t.d_per_byte != nullptr) return BT709HIP_OK;
+  if (capturing(s)) return BT709HIP_ERR_NOT_SETUP;
+  EncodeTables host;
+  SplitTable fl;
+  if (!build_encode_tables(input_gamma, output_gamma, &host) || !build_split_table(host.from_linear_kind, &fl))
+    return BT709HIP_ERR_UNSUPPORTED;
+  void *d_fl = nullptr, *d_pb = nullptr;
+  const uint32_t fl_bytes = static_cast<uint32_t>(fl.buckets.size() * sizeof(TransferBucket));
+  if (int rc = upload_table(fl.buckets.data(), fl_bytes, &d_fl)) return rc;
+  if (int rc = upload_table(host.per_byte, sizeof host.per_byte, &d_pb)) {
+    (void)hipFree(d_fl);
+    return rc;
+  }
+  t.from_linear_n = fl.n_fine;
+  t.split = fl.split;
+  t.coarse_scale = fl.coarse_scale;
+  t.coarse_offset = fl.coarse_offset;
+  t.from_linear_bytes = fl_bytes;
+  t.d_from_linear = d_fl;
+  t.d_per_byte = d_pb;  // the "built" marker: last
+  return BT709HIP_OK;
 }
 
 uint32_t grid_x_for(const bt709hip_context *ctx, uint32_t rows, int frames) {
@@ -233,9 +296,29 @@ int bt709hip_context_create(int device_ordinal, bt709hip_context **out) {
   }
   // Workgroups per launch: enough to fill every CU at 8 resident blocks, times a
   // small factor so the tail is short; row pairs are grid-strided beyond that.
-  ctx->grid_blocks = ctx->props.multiProcessorCount * 8 * env_int("BT709HIP_GRID_MULT", 2);
+  ctx->grid_blocks = ctx->props.multiProcessorCount * 8 * ctx->grid_mult;
   *out = ctx;
   return BT709HIP_OK;
+}
+
+int bt709hip_abi_version(void) { return BT709HIP_VERSION; }
+
+int bt709hip_context_set_option(bt709hip_context *ctx, int option, int value) {
+  if (ctx == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  switch (option) {
+    case BT709HIP_CTX_OPT_GRID_MULT:
+      ctx->grid_mult = value <= 0 ? 2 : clamp_int(value, 1, 64);
+      ctx->grid_blocks = ctx->props.multiProcessorCount * 8 * ctx->grid_mult;
+      return BT709HIP_OK;
+    case BT709HIP_CTX_OPT_ENCODE_ROW_PAIRS:
+      ctx->encode_row_pairs = clamp_int(value, 0, 64);
+      return BT709HIP_OK;
+    case BT709HIP_CTX_OPT_ENCODE_THREADS:
+      ctx->encode_threads = clamp_int(value, 0, 1024) / 64 * 64;
+      return BT709HIP_OK;
+    default:
+      return BT709HIP_ERR_INVALID_ARG;
+  }
 }
 
 int bt709hip_context_destroy(bt709hip_context *ctx) {
@@ -438,8 +521,6 @@ int bt709hip_decoder_create(bt709hip_context *ctx, int gamma, int has_alpha, bt7
   dec->has_alpha = has_alpha ? 1 : 0;
   // RGBA render supports only the sRGB gamma function (MetalBT709Decoder.m:165-169)
   dec->gamma = has_alpha ? BT709HIP_GAMMA_SRGB : gamma;
-  dec->nontemporal = env_int("BT709HIP_NONTEMPORAL", 1) != 0;
-  dec->half_rep = env_int("BT709HIP_HALF_REP", -1);
   *out = dec;
   return BT709HIP_OK;
 }
@@ -449,6 +530,7 @@ int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
   if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) {
     if (dec->d_table_unit) (void)hipFree(dec->d_table_unit);
     if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
+    if (dec->d_table_alpha) (void)hipFree(dec->d_table_alpha);
     if (dec->d_encode) (void)hipFree(dec->d_encode);
   }
   delete dec;
@@ -473,6 +555,28 @@ int bt709hip_decoder_get_gamma(const bt709hip_decoder *dec) {
   return dec ? dec->gamma : BT709HIP_ERR_INVALID_ARG;
 }
 
+int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value) {
+  if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  switch (option) {
+    case BT709HIP_OPT_NONTEMPORAL: dec->nontemporal = value != 0; return BT709HIP_OK;
+    case BT709HIP_OPT_HALF_KERNEL: dec->half_rep = clamp_int(value, -1, 1); return BT709HIP_OK;
+    case BT709HIP_OPT_HALF_WORKGROUPS: dec->half_workgroups = clamp_int(value, 0, 1 << 20); return BT709HIP_OK;
+    case BT709HIP_OPT_HALF_LDS_KB: dec->half_lds_kb = clamp_int(value, 0, 160); return BT709HIP_OK;
+    default: return BT709HIP_ERR_INVALID_ARG;
+  }
+}
+
+int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *value) {
+  if (dec == nullptr || value == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  switch (option) {
+    case BT709HIP_OPT_NONTEMPORAL: *value = dec->nontemporal ? 1 : 0; return BT709HIP_OK;
+    case BT709HIP_OPT_HALF_KERNEL: *value = dec->half_rep; return BT709HIP_OK;
+    case BT709HIP_OPT_HALF_WORKGROUPS: *value = dec->half_workgroups; return BT709HIP_OK;
+    case BT709HIP_OPT_HALF_LDS_KB: *value = dec->half_lds_kb; return BT709HIP_OK;
+    default: return BT709HIP_ERR_INVALID_ARG;
+  }
+}
+
 int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(dec->setup_mutex);
@@ -492,81 +596,143 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   dec->encode_shift = 0;
   for (float r = enc.coarse_scale; r < 1.0f; r *= 2.0f) ++dec->encode_shift;  // log2(fine buckets per coarse bucket)
   dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
-  if (int rc = upload_table(t.buckets_unit.data(), dec->table_unit_bytes, &dec->d_table_unit)) return rc;
-  if (int rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &dec->d_table_linear)) return rc;
-  if (int rc = upload_table(enc.buckets.data(), dec->encode_bytes, &dec->d_encode)) return rc;
+  void *d_unit = nullptr, *d_linear = nullptr, *d_alpha = nullptr, *d_enc = nullptr;
+  int rc = upload_table(t.buckets_unit.data(), dec->table_unit_bytes, &d_unit);
+  if (rc == BT709HIP_OK) rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &d_linear);
+  if (rc == BT709HIP_OK && dec->has_alpha) rc = upload_table(t.buckets_bytenorm.data(), dec->table_linear_bytes, &d_alpha);
+  if (rc == BT709HIP_OK) rc = upload_table(enc.buckets.data(), dec->encode_bytes, &d_enc);
+  if (rc != BT709HIP_OK) {  // a retry starts from scratch: nothing is published, nothing leaks
+    if (d_unit) (void)hipFree(d_unit);
+    if (d_linear) (void)hipFree(d_linear);
+    if (d_alpha) (void)hipFree(d_alpha);
+    return rc;
+  }
+  dec->d_table_unit = d_unit;
+  dec->d_table_linear = d_linear;
+  dec->d_table_alpha = d_alpha;
+  dec->d_encode = d_enc;
   dec->ready = true;
   return BT709HIP_OK;
 }
 
-int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
-                          const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
-                          int wait_until_completed) {
+namespace {
+
+enum class OutShape { kSame, kHalf, kAny };  // output size relative to the frame: pass 1 / exact 2:1 / view-fit
+
+struct BatchInfo {
+  bool uniform = false;    // frames evenly spaced in memory (no pointer table needed)
+  uint32_t in_align = 16;  // largest power of two <= 16 dividing every input plane pointer and pitch
+  uint32_t out_align = 16; // same for the outputs
+  int format = BT709HIP_FORMAT_BGRA8_SRGB;
+};
+
+void fold_align(uint32_t *a, uintptr_t v) {
+  while (*a > 1 && (v % *a) != 0) *a /= 2;
+}
+
+// Validates `count` frames (+ alpha frames) against their outputs in the reference's order
+// (MetalBT709Decoder.m:265-368), checks that the batch shares one geometry, and fills the pointer
+// table, pitches and frame spacing of `p`.  Returns BT709HIP_OK with p->width == 0 for empty frames.
+int gather_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames, const bt709hip_frame *alphas,
+                 const bt709hip_surface *outs, OutShape shape, void *stream, DecodeParams *p, BatchInfo *info) {
   if (dec == nullptr || frames == nullptr || outs == nullptr || count < 0) return BT709HIP_ERR_INVALID_ARG;
-  const bool uniform = evenly_spaced(count, frames, dec->has_alpha ? alphas : nullptr, outs);
-  if (count > (uniform ? kMaxUniformBatch : kMaxBatch)) return BT709HIP_ERR_UNSUPPORTED;
-  if (int rc = bt709hip_decoder_setup(dec)) return rc;  // -decodeBT709 calls -setupMetal first (.m:228-231)
+  // an alpha buffer handed to an opaque decoder is validated (.m:294-306, 357-368) but not read
+  const bt709hip_frame *planes_a = dec->has_alpha ? alphas : nullptr;
+  info->uniform = evenly_spaced(count, frames, planes_a, outs);
+  if (count > (info->uniform ? kMaxUniformBatch : kMaxBatch)) return BT709HIP_ERR_UNSUPPORTED;
+  if (int rc = ensure_setup(dec, stream)) return rc;
+  std::memset(p, 0, sizeof *p);
   if (count == 0) return BT709HIP_OK;
   if (int rc = bind(dec->ctx)) return rc;
 
   const bt709hip_frame &f0 = frames[0];
   const bt709hip_surface &o0 = outs[0];
-  DecodeParams p;
-  std::memset(&p, 0, sizeof p);
-  bool fast = (f0.width % 4) == 0 && (f0.y_stride % 4) == 0 && (f0.cbcr_stride % 4) == 0 && (o0.stride % 16) == 0;
+  info->format = o0.format;
   for (int i = 0; i < count; ++i) {
+    const bt709hip_frame &f = frames[i];
+    const bt709hip_surface &o = outs[i];
     const bt709hip_frame *a = alphas ? &alphas[i] : nullptr;
-    if (int rc = validate(dec, &frames[i], a, &outs[i], frames[i].width, frames[i].height, outs[i].width,
-                          outs[i].height))
-      return rc;
-    if (frames[i].width != f0.width || frames[i].height != f0.height || frames[i].y_stride != f0.y_stride ||
-        frames[i].cbcr_stride != f0.cbcr_stride || outs[i].stride != o0.stride)
+    if (shape == OutShape::kHalf && ((f.width & 3) || (f.height & 3))) return BT709HIP_ERR_ODD_DIMENSIONS;
+    const int want_w = shape == OutShape::kSame ? f.width : (shape == OutShape::kHalf ? f.width / 2 : o.width);
+    const int want_h = shape == OutShape::kSame ? f.height : (shape == OutShape::kHalf ? f.height / 2 : o.height);
+    if (shape == OutShape::kAny && (o.width < 0 || o.height < 0)) return BT709HIP_ERR_INVALID_ARG;
+    if (int rc = validate(dec, &f, a, &o, want_w, want_h, o.width, o.height)) return rc;
+    if (o.format != BT709HIP_FORMAT_BGRA8_SRGB && (shape != OutShape::kSame || o.format != BT709HIP_FORMAT_RGBA16F))
+      return BT709HIP_ERR_UNSUPPORTED;
+    if (f.width != f0.width || f.height != f0.height || f.y_stride != f0.y_stride || f.cbcr_stride != f0.cbcr_stride ||
+        o.stride != o0.stride || o.width != o0.width || o.height != o0.height || o.format != o0.format)
       return BT709HIP_ERR_SIZE_MISMATCH;
-    if (dec->has_alpha && a->y_stride != alphas[0].y_stride) return BT709HIP_ERR_SIZE_MISMATCH;
+    if (planes_a != nullptr && a->y_stride != alphas[0].y_stride) return BT709HIP_ERR_SIZE_MISMATCH;
     if (i < kMaxBatch) {
-      p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
-      p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
-      p.frames[i].alpha = dec->has_alpha ? static_cast<const uint8_t *>(a->y) : nullptr;
-      p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
+      p->frames[i].y = static_cast<const uint8_t *>(f.y);
+      p->frames[i].cbcr = static_cast<const uint8_t *>(f.cbcr);
+      p->frames[i].alpha = planes_a ? static_cast<const uint8_t *>(a->y) : nullptr;
+      p->frames[i].out = static_cast<uint8_t *>(o.bgra);
     }
-    fast = fast && aligned(frames[i].y, 4) && aligned(frames[i].cbcr, 4) && aligned(outs[i].bgra, 16);
-    if (dec->has_alpha) fast = fast && aligned(a->y, 4) && (a->y_stride % 4) == 0;
+    fold_align(&info->in_align, reinterpret_cast<uintptr_t>(f.y));
+    fold_align(&info->in_align, reinterpret_cast<uintptr_t>(f.cbcr));
+    if (planes_a) fold_align(&info->in_align, reinterpret_cast<uintptr_t>(a->y));
+    fold_align(&info->out_align, reinterpret_cast<uintptr_t>(o.bgra));
   }
-  if (f0.width == 0 || f0.height == 0) return BT709HIP_OK;
+  fold_align(&info->in_align, f0.y_stride);
+  fold_align(&info->in_align, f0.cbcr_stride);
+  if (planes_a) fold_align(&info->in_align, alphas[0].y_stride);
+  fold_align(&info->out_align, o0.stride);
+  // the row-pair / output-row dimension of every kernel is gridDim.y
+  if (f0.height / 2 > kMaxGridYZ || o0.height > 2 * kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;
+  if (f0.width == 0 || f0.height == 0 || o0.width == 0 || o0.height == 0) return BT709HIP_OK;
 
-  if (uniform && count > 1) {
-    p.uniform = 1;
-    p.step_y = byte_step(frames[0].y, frames[1].y);
-    p.step_cbcr = byte_step(frames[0].cbcr, frames[1].cbcr);
-    p.step_alpha = dec->has_alpha ? byte_step(alphas[0].y, alphas[1].y) : 0;
-    p.step_out = byte_step(outs[0].bgra, outs[1].bgra);
+  if (info->uniform && count > 1) {
+    p->uniform = 1;
+    p->step_y = byte_step(frames[0].y, frames[1].y);
+    p->step_cbcr = byte_step(frames[0].cbcr, frames[1].cbcr);
+    p->step_alpha = planes_a ? byte_step(alphas[0].y, alphas[1].y) : 0;
+    p->step_out = byte_step(outs[0].bgra, outs[1].bgra);
   }
-  set_tables(&p, dec);
-  p.width = static_cast<uint32_t>(f0.width);
-  p.height = static_cast<uint32_t>(f0.height);
-  p.y_stride = static_cast<uint32_t>(f0.y_stride);
-  p.cbcr_stride = static_cast<uint32_t>(f0.cbcr_stride);
-  p.alpha_stride = dec->has_alpha ? static_cast<uint32_t>(alphas[0].y_stride) : 0;
-  p.out_stride = static_cast<uint32_t>(o0.stride);
-  p.alpha_word = dec->alpha_fill << 24;
+  set_tables(p, dec);
+  p->width = static_cast<uint32_t>(f0.width);
+  p->height = static_cast<uint32_t>(f0.height);
+  p->y_stride = static_cast<uint32_t>(f0.y_stride);
+  p->cbcr_stride = static_cast<uint32_t>(f0.cbcr_stride);
+  p->alpha_stride = planes_a ? static_cast<uint32_t>(alphas[0].y_stride) : 0;
+  p->out_stride = static_cast<uint32_t>(o0.stride);
+  p->out_width = static_cast<uint32_t>(o0.width);
+  p->out_height = static_cast<uint32_t>(o0.height);
+  p->alpha_word = dec->alpha_fill << 24;
+  return BT709HIP_OK;
+}
 
+int finish_launch(hipStream_t s, int wait_until_completed) {
+  HIP_TRY(hipGetLastError());
+  if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));  // .m:486-489
+  return BT709HIP_OK;
+}
+
+}  // namespace
+
+int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
+                          const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
+                          int wait_until_completed) {
+  DecodeParams p;
+  BatchInfo info;
+  if (int rc = gather_batch(dec, count, frames, alphas, outs, OutShape::kSame, stream, &p, &info)) return rc;
+  if (p.width == 0) return BT709HIP_OK;
   hipStream_t s = pick(dec->ctx, stream);
   // Fast path: one short-lived workgroup per tile of a row pair, dispatched in address order
   // (see the kernel file's header).  General path keeps the grid-strided shape.
+  const bool fast = (p.width % 4) == 0 && info.in_align >= 4 && info.out_align >= 16;
   const uint32_t gx = fast ? quads_tiles(p.width) : grid_x_for(dec->ctx, p.height / 2, count);
   const uint32_t threads = quads_block_threads(p.width);
   tl_kernel_name = launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
                                  dec->nontemporal, gx, threads, s);
-  HIP_TRY(hipGetLastError());
-  if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));  // .m:486-489
-  return BT709HIP_OK;
+  return finish_launch(s, wait_until_completed);
 }
 
 int bt709hip_decode(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_frame *alpha,
                     const bt709hip_surface *out, int render_width, int render_height, void *stream,
                     int wait_until_completed) {
   if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
-  if (int rc = bt709hip_decoder_setup(dec)) return rc;
+  if (int rc = ensure_setup(dec, stream)) return rc;
   // render size is a property of this call only; check it here, the rest in the batch path
   if (int rc = validate(dec, frame, alpha, out, frame ? frame->width : 0, frame ? frame->height : 0, render_width,
                         render_height))
@@ -575,53 +741,15 @@ int bt709hip_decode(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt
 }
 
 int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
-                               const bt709hip_surface *outs, void *stream, int wait_until_completed) {
-  if (dec == nullptr || frames == nullptr || outs == nullptr || count < 0) return BT709HIP_ERR_INVALID_ARG;
-  const bool uniform = evenly_spaced(count, frames, nullptr, outs);
-  if (count > (uniform ? kMaxUniformBatch : kMaxBatch)) return BT709HIP_ERR_UNSUPPORTED;
-  if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;
-  if (int rc = bt709hip_decoder_setup(dec)) return rc;
-  if (count == 0) return BT709HIP_OK;
-  if (int rc = bind(dec->ctx)) return rc;
-
-  const bt709hip_frame &f0 = frames[0];
-  const bt709hip_surface &o0 = outs[0];
+                               const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
+                               int wait_until_completed) {
   DecodeParams p;
-  std::memset(&p, 0, sizeof p);
-  bool wide = (f0.y_stride % 4) == 0 && (f0.cbcr_stride % 4) == 0 && (o0.stride % 8) == 0;
-  for (int i = 0; i < count; ++i) {
-    if ((frames[i].width & 3) || (frames[i].height & 3)) return BT709HIP_ERR_ODD_DIMENSIONS;
-    if (int rc = validate(dec, &frames[i], nullptr, &outs[i], frames[i].width / 2, frames[i].height / 2,
-                          outs[i].width, outs[i].height))
-      return rc;
-    if (frames[i].width != f0.width || frames[i].height != f0.height || frames[i].y_stride != f0.y_stride ||
-        frames[i].cbcr_stride != f0.cbcr_stride || outs[i].stride != o0.stride)
-      return BT709HIP_ERR_SIZE_MISMATCH;
-    if (i < kMaxBatch) {
-      p.frames[i].y = static_cast<const uint8_t *>(frames[i].y);
-      p.frames[i].cbcr = static_cast<const uint8_t *>(frames[i].cbcr);
-      p.frames[i].out = static_cast<uint8_t *>(outs[i].bgra);
-    }
-    wide = wide && aligned(frames[i].y, 4) && aligned(frames[i].cbcr, 4) && aligned(outs[i].bgra, 8);
-  }
-  if (f0.width == 0 || f0.height == 0) return BT709HIP_OK;
-
-  if (uniform && count > 1) {
-    p.uniform = 1;
-    p.step_y = byte_step(frames[0].y, frames[1].y);
-    p.step_cbcr = byte_step(frames[0].cbcr, frames[1].cbcr);
-    p.step_out = byte_step(outs[0].bgra, outs[1].bgra);
-  }
-  set_tables(&p, dec);
-  p.width = static_cast<uint32_t>(f0.width);
-  p.height = static_cast<uint32_t>(f0.height);
-  p.y_stride = static_cast<uint32_t>(f0.y_stride);
-  p.cbcr_stride = static_cast<uint32_t>(f0.cbcr_stride);
-  p.out_stride = static_cast<uint32_t>(o0.stride);
-  p.alpha_word = dec->alpha_fill << 24;
-
+  BatchInfo info;
+  if (int rc = gather_batch(dec, count, frames, alphas, outs, OutShape::kHalf, stream, &p, &info)) return rc;
+  if (p.width == 0) return BT709HIP_OK;
   hipStream_t s = pick(dec->ctx, stream);
   // wide: same tiling as the 1:1 kernel over the source width; narrow: 256 output pixels per workgroup
+  const bool wide = info.in_align >= 4 && info.out_align >= 8;
   const uint32_t gx = wide ? quads_tiles(p.width) : (p.width / 2 + kBlockThreads - 1) / kBlockThreads;
   const uint32_t threads = wide ? quads_block_threads(p.width) : kBlockThreads;
   // Larger launches: persistent workgroups with bank-conflict-free (replicated) LDS tables, one per CU.
@@ -630,53 +758,41 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   const uint32_t cus = static_cast<uint32_t>(dec->ctx->props.multiProcessorCount);
   const uint64_t tile_rows = static_cast<uint64_t>((p.width / 4 + kRepBlockThreads - 1) / kRepBlockThreads) *
                              (p.height / 2) * static_cast<uint32_t>(count);
-  const bool rep = wide && dec->half_rep != 0 && (dec->half_rep > 0 || tile_rows >= 8ull * cus);
-  const char *name = rep ? launch_decode_half_rep(p, count, dec->nontemporal,
-                                                  static_cast<uint32_t>(env_int("BT709HIP_REP_WORKGROUPS", static_cast<int>(cus))),
-                                                  static_cast<uint32_t>(env_int("BT709HIP_REP_LDS_KB", 160)) * 1024u, s)
-                         : nullptr;
-  tl_kernel_name = name ? name : launch_decode_half(p, count, wide, dec->nontemporal, gx, threads, s);
-  HIP_TRY(hipGetLastError());
-  if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
-  return BT709HIP_OK;
+  const bool rep = wide && !dec->has_alpha && dec->half_rep != 0 && (dec->half_rep > 0 || tile_rows >= 8ull * cus);
+  const uint32_t rep_groups = dec->half_workgroups > 0 ? static_cast<uint32_t>(dec->half_workgroups) : cus;
+  const uint32_t rep_lds = (dec->half_lds_kb > 0 ? static_cast<uint32_t>(dec->half_lds_kb) : 160u) * 1024u;
+  const char *name = rep ? launch_decode_half_rep(p, count, dec->nontemporal, rep_groups, rep_lds, s) : nullptr;
+  tl_kernel_name = name ? name : launch_decode_half(p, count, wide, dec->has_alpha != 0, dec->nontemporal, gx, threads, s);
+  return finish_launch(s, wait_until_completed);
 }
 
-int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
-                           void *stream, int wait_until_completed) {
-  if (dec == nullptr || frame == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
-  if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;
-  if (int rc = bt709hip_decoder_setup(dec)) return rc;
-  if (out->width < 0 || out->height < 0) return BT709HIP_ERR_INVALID_ARG;
-  // the frame is validated like any decode input; the surface may have any size
-  if (int rc = validate(dec, frame, nullptr, out, out->width, out->height, out->width, out->height)) return rc;
-  if (frame->width == 0 || frame->height == 0 || out->width == 0 || out->height == 0) return BT709HIP_OK;
-  if (int rc = bind(dec->ctx)) return rc;
+int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_frame *alpha,
+                         const bt709hip_surface *out, void *stream, int wait_until_completed) {
+  if (frame == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  return bt709hip_decode_half_batch(dec, 1, frame, alpha, out, stream, wait_until_completed);
+}
+
+int bt709hip_decode_scaled_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
+                                 const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
+                                 int wait_until_completed) {
   DecodeParams p;
-  std::memset(&p, 0, sizeof p);
-  p.frames[0].y = static_cast<const uint8_t *>(frame->y);
-  p.frames[0].cbcr = static_cast<const uint8_t *>(frame->cbcr);
-  p.frames[0].out = static_cast<uint8_t *>(out->bgra);
-  set_tables(&p, dec);
-  p.width = static_cast<uint32_t>(frame->width);
-  p.height = static_cast<uint32_t>(frame->height);
-  p.y_stride = static_cast<uint32_t>(frame->y_stride);
-  p.cbcr_stride = static_cast<uint32_t>(frame->cbcr_stride);
-  p.out_stride = static_cast<uint32_t>(out->stride);
-  p.out_width = static_cast<uint32_t>(out->width);
-  p.out_height = static_cast<uint32_t>(out->height);
-  p.scale_x = static_cast<float>(frame->width) / static_cast<float>(out->width);
-  p.scale_y = static_cast<float>(frame->height) / static_cast<float>(out->height);
-  p.alpha_word = dec->alpha_fill << 24;
+  BatchInfo info;
+  // the frames are validated like any decode input; the surfaces may have any (common) size
+  if (int rc = gather_batch(dec, count, frames, alphas, outs, OutShape::kAny, stream, &p, &info)) return rc;
+  if (p.width == 0) return BT709HIP_OK;
+  if (p.out_height > static_cast<uint32_t>(kMaxGridYZ)) return BT709HIP_ERR_UNSUPPORTED;
+  p.scale_x = static_cast<float>(p.width) / static_cast<float>(p.out_width);
+  p.scale_y = static_cast<float>(p.height) / static_cast<float>(p.out_height);
   hipStream_t s = pick(dec->ctx, stream);
-  tl_kernel_name = launch_decode_scaled(p, 1, static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), s);
-  HIP_TRY(hipGetLastError());
-  if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
-  return BT709HIP_OK;
+  tl_kernel_name = launch_decode_scaled(p, count, dec->has_alpha != 0, info.in_align,
+                                        static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), s);
+  return finish_launch(s, wait_until_completed);
 }
 
-int bt709hip_decode_half(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_surface *out,
-                         void *stream, int wait_until_completed) {
-  return bt709hip_decode_half_batch(dec, 1, frame, out, stream, wait_until_completed);
+int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_frame *alpha,
+                           const bt709hip_surface *out, void *stream, int wait_until_completed) {
+  if (frame == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  return bt709hip_decode_scaled_batch(dec, 1, frame, alpha, out, stream, wait_until_completed);
 }
 
 // ------------------------------------------------------------------ frame pool
@@ -701,7 +817,6 @@ int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth
   *out = nullptr;
   if (dec == nullptr || width <= 0 || height <= 0 || depth <= 0 || depth > 64) return BT709HIP_ERR_INVALID_ARG;
   if ((width & 1) || (height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;
-  if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;
   if (int rc = bt709hip_decoder_setup(dec)) return rc;
   if (int rc = bind(dec->ctx)) return rc;
   bt709hip_pool *pool = new (std::nothrow) bt709hip_pool();
@@ -709,7 +824,8 @@ int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth
   pool->dec = dec;
   pool->width = width;
   pool->height = height;
-  pool->in_bytes = static_cast<size_t>(width) * height * 3 / 2;
+  // Y + CbCr, plus a full-size alpha plane for a decoder with an alpha channel
+  pool->in_bytes = static_cast<size_t>(width) * height * 3 / 2 + (dec->has_alpha ? static_cast<size_t>(width) * height : 0);
   pool->out_bytes = static_cast<size_t>(width) * height * 4;
   pool->slots.resize(static_cast<size_t>(depth));
   hipError_t e = hipSuccess;
@@ -749,6 +865,17 @@ int bt709hip_pool_acquire(bt709hip_pool *pool, int *slot, void **y, size_t *y_st
   return BT709HIP_OK;
 }
 
+int bt709hip_pool_alpha_plane(bt709hip_pool *pool, int slot, void **alpha, size_t *alpha_stride) {
+  if (pool == nullptr || alpha == nullptr || slot < 0 || static_cast<size_t>(slot) >= pool->slots.size())
+    return BT709HIP_ERR_INVALID_ARG;
+  if (!pool->dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;
+  bt709hip_pool::Slot &s = pool->slots[static_cast<size_t>(slot)];
+  if (!s.acquired) return BT709HIP_ERR_INVALID_ARG;
+  *alpha = s.h_in + static_cast<size_t>(pool->width) * pool->height * 3 / 2;
+  if (alpha_stride) *alpha_stride = static_cast<size_t>(pool->width);
+  return BT709HIP_OK;
+}
+
 int bt709hip_pool_submit(bt709hip_pool *pool, int slot) {
   if (pool == nullptr || slot < 0 || static_cast<size_t>(slot) >= pool->slots.size()) return BT709HIP_ERR_INVALID_ARG;
   bt709hip_pool::Slot &s = pool->slots[static_cast<size_t>(slot)];
@@ -772,7 +899,11 @@ int bt709hip_pool_submit(bt709hip_pool *pool, int slot) {
   o.stride = static_cast<size_t>(w) * 4;
   o.width = w;
   o.height = h;
-  if (int rc = bt709hip_decode(pool->dec, &f, nullptr, &o, w, h, s.stream, 0)) return rc;
+  bt709hip_frame a = f;  // alpha plane: only y is read (cvpbu_wrap_y_plane_as_metal_texture)
+  a.y = s.d_in + static_cast<size_t>(w) * h * 3 / 2;
+  a.cbcr = nullptr;
+  a.transfer = BT709HIP_TRANSFER_LINEAR;
+  if (int rc = bt709hip_decode(pool->dec, &f, pool->dec->has_alpha ? &a : nullptr, &o, w, h, s.stream, 0)) return rc;
   HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, pool->out_bytes, hipMemcpyDeviceToHost, s.stream));
   s.acquired = false;
   s.busy = true;
@@ -813,6 +944,8 @@ int bt709hip_encode_batch(bt709hip_context *ctx, int count, const bt709hip_surfa
     if (in.width < 0 || in.height < 0) return BT709HIP_ERR_INVALID_ARG;
     if (in.width != out.width || in.height != out.height) return BT709HIP_ERR_SIZE_MISMATCH;
     if ((in.width & 1) || (in.height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;  // BGRAToBT709Converter.m:540-541
+    if (in.height / 2 > kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;            // row pairs live in gridDim.y
+    if (in.format != BT709HIP_FORMAT_BGRA8_SRGB || in.reserved != 0) return BT709HIP_ERR_UNSUPPORTED;
     if (in.width != in0.width || in.height != in0.height || in.stride != in0.stride || out.y_stride != out0.y_stride ||
         out.cbcr_stride != out0.cbcr_stride)
       return BT709HIP_ERR_SIZE_MISMATCH;
@@ -837,23 +970,9 @@ int bt709hip_encode_batch(bt709hip_context *ctx, int count, const bt709hip_surfa
   if (in0.width == 0 || in0.height == 0) return BT709HIP_OK;
   if (int rc = bind(ctx)) return rc;
 
+  hipStream_t s = pick(ctx, stream);
   EncoderTables &t = ctx->encoders[input_gamma][output_gamma];
-  {
-    std::lock_guard<std::mutex> lock(ctx->encoder_mutex);
-    if (t.d_per_byte == nullptr) {
-      EncodeTables host;
-      SplitTable fl;
-      if (!build_encode_tables(input_gamma, output_gamma, &host) || !build_split_table(host.from_linear_kind, &fl))
-        return BT709HIP_ERR_UNSUPPORTED;
-      t.from_linear_n = fl.n_fine;
-      t.split = fl.split;
-      t.coarse_scale = fl.coarse_scale;
-      t.coarse_offset = fl.coarse_offset;
-      t.from_linear_bytes = static_cast<uint32_t>(fl.buckets.size() * sizeof(TransferBucket));
-      if (int rc = upload_table(fl.buckets.data(), t.from_linear_bytes, &t.d_from_linear)) return rc;
-      if (int rc = upload_table(host.per_byte, sizeof host.per_byte, &t.d_per_byte)) return rc;
-    }
-  }
+  if (int rc = encoder_tables(ctx, input_gamma, output_gamma, s)) return rc;
 
   if (uniform) {
     p.uniform = 1;
@@ -868,18 +987,24 @@ int bt709hip_encode_batch(bt709hip_context *ctx, int count, const bt709hip_surfa
   p.from_linear_split = t.split;
   p.from_linear_coarse = t.coarse_scale;
   p.from_linear_offset = t.coarse_offset;
-  p.row_pairs_per_block = static_cast<uint32_t>(env_int("BT709HIP_ENCODE_ROWPAIRS", 0));  // 0: sized per launch
-  p.block_threads = static_cast<uint32_t>(env_int("BT709HIP_ENCODE_THREADS", 0)) / 64 * 64;
+  p.row_pairs_per_block = static_cast<uint32_t>(ctx->encode_row_pairs);  // 0: sized per launch
+  p.block_threads = static_cast<uint32_t>(ctx->encode_threads);
   p.width = static_cast<uint32_t>(in0.width);
   p.height = static_cast<uint32_t>(in0.height);
   p.bgra_stride = static_cast<uint32_t>(in0.stride);
   p.y_stride = static_cast<uint32_t>(out0.y_stride);
   p.cbcr_stride = static_cast<uint32_t>(out0.cbcr_stride);
-  hipStream_t s = pick(ctx, stream);
   tl_kernel_name = launch_encode(p, count, fast, s);
   HIP_TRY(hipGetLastError());
   if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;
+}
+
+int bt709hip_encoder_prepare(bt709hip_context *ctx, int input_gamma, int output_gamma) {
+  if (ctx == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (input_gamma < 0 || input_gamma > 2 || output_gamma < 0 || output_gamma > 2) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  return encoder_tables(ctx, input_gamma, output_gamma, nullptr);
 }
 
 int bt709hip_encode(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_frame *out, int input_gamma,
@@ -898,6 +1023,7 @@ static int planes_call(bt709hip_context *ctx, const void *u, size_t u_stride, co
   const size_t w = static_cast<size_t>(cw);
   if (u_stride < w || v_stride < w || cbcr_stride < 2 * w) return BT709HIP_ERR_STRIDE;
   if (u_stride > 0xffffffffu || v_stride > 0xffffffffu || cbcr_stride > 0xffffffffu) return BT709HIP_ERR_STRIDE;
+  if (ch > kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;  // one chroma row per gridDim.y
   if (int rc = bind(ctx)) return rc;
   PlaneParams p;
   std::memset(&p, 0, sizeof p);
@@ -934,6 +1060,16 @@ int bt709hip_deinterleave_cbcr(bt709hip_context *ctx, const void *cbcr, size_t c
 
 // -------------------------------------------------------------- diagnostics
 
+int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+  if (int rc = bind(ctx)) return rc;
+  if (bytes == 0) return BT709HIP_OK;
+  if (dst == nullptr || src == nullptr || (bytes & 15) || !aligned(dst, 16) || !aligned(src, 16))
+    return BT709HIP_ERR_INVALID_ARG;
+  tl_kernel_name = launch_copy_probe(dst, src, bytes, pick(ctx, stream));
+  HIP_TRY(hipGetLastError());
+  return BT709HIP_OK;
+}
+
 const char *bt709hip_strerror(int status) {
   switch (status) {
     case BT709HIP_OK: return "ok";
@@ -962,6 +1098,25 @@ int bt709hip_gamma_thresholds(int gamma, float thresholds[255]) {
   if (!build_transfer_table(gamma, &t)) return BT709HIP_ERR_INVALID_ARG;
   std::memcpy(thresholds, t.thresholds, sizeof t.thresholds);
   return BT709HIP_OK;
+}
+
+int bt709hip_gamma_lookup(int gamma, float x, int *bucket_count, int *bucket_index_out) {
+  // one table per gamma, built on first use (host only: no device involved)
+  static std::mutex mutex;
+  static TransferTable tables[kGammaCount];
+  static bool built[kGammaCount] = {false, false, false, false};
+  if (gamma < 0 || gamma >= kGammaCount || !(x >= 0.0f && x <= 1.0f)) return BT709HIP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(mutex);
+  if (!built[gamma]) {
+    if (!build_transfer_table(gamma, &tables[gamma])) return BT709HIP_ERR_UNSUPPORTED;
+    built[gamma] = true;
+  }
+  const TransferTable &t = tables[gamma];
+  const uint32_t q = bucket_index(x, 8388608.0f / static_cast<float>(t.n));
+  if (bucket_count) *bucket_count = static_cast<int>(t.n);
+  if (bucket_index_out) *bucket_index_out = static_cast<int>(q);
+  const TransferBucket &b = t.buckets_unit[q];
+  return static_cast<int>(b.base + (x >= b.edge ? 1u : 0u));
 }
 
 int bt709hip_matrix_constants(float c[8]) {

@@ -5,6 +5,7 @@
 // in C++ the same spelling would pick the float overload and change results.
 #include "transfer_tables.h"
 
+#include <cfenv>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -95,7 +96,25 @@ float find_threshold(int gamma, int k) {
   return from_bits(lo);
 }
 
+uint32_t to_bits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, sizeof u);
+  return u;
+}
+
 }  // namespace
+
+uint32_t bucket_index(float x, float magic) {
+#if defined(BT709_INDEX_RTZ)
+  const int mode = std::fegetround();
+  std::fesetround(FE_TOWARDZERO);
+  volatile float s = x + magic;
+  std::fesetround(mode);
+#else
+  volatile float s = x + magic;  // binary32 add, round to nearest even (volatile: no excess precision, no folding)
+#endif
+  return to_bits(s) - to_bits(magic);
+}
 
 bool build_transfer_table(int gamma, TransferTable *out) {
   if (gamma < 0 || gamma >= kTableKinds || out == nullptr) return false;
@@ -105,36 +124,47 @@ bool build_transfer_table(int gamma, TransferTable *out) {
   float lin_of_byte[257];
   for (int b = 0; b < 256; ++b) lin_of_byte[b] = srgb_to_linear(b * (1.0f / 255.0f));
   lin_of_byte[256] = lin_of_byte[255];
+  float norm_of_byte[257];  // byteNorm, Renderer/sRGB.h:32-36
+  for (int b = 0; b < 256; ++b) norm_of_byte[b] = b * (1.0f / 255.0f);
+  norm_of_byte[256] = norm_of_byte[255];
 
   const float inf = std::numeric_limits<float>::infinity();
   for (uint32_t n = 256; n <= 65536; n *= 2) {
-    std::vector<TransferBucket> b(n + 1);
+    const float magic = 8388608.0f / static_cast<float>(n);  // 2^23 / N
+    std::vector<TransferBucket> b(n + 1, TransferBucket{inf, 0u});
+    // bucket_index is monotone, so with every threshold filed under its own bucket
+    //   base[q] = number of thresholds in buckets < q,  edge[q] = the threshold filed under q (if any)
+    // gives byte(x) = base[q(x)] + (x >= edge[q(x)]) for every x in [0, 1].
     bool ok = true;
-    int k = 0;  // thresholds <= current bucket start
-    for (uint32_t q = 0; q <= n && ok; ++q) {
-      const float lo = static_cast<float>(q) / static_cast<float>(n);  // exact
-      const float hi = static_cast<float>(q + 1) / static_cast<float>(n);
-      while (k < 255 && out->thresholds[k] <= lo) ++k;
-      b[q].base = static_cast<uint32_t>(k);
-      b[q].edge = inf;
-      if (k < 255 && out->thresholds[k] < hi) {
-        b[q].edge = out->thresholds[k];
-        // a second threshold inside the same bucket would be lost
-        if (k + 1 < 255 && out->thresholds[k + 1] < hi) ok = false;
-      }
+    std::vector<uint32_t> held(n + 2, 0u);
+    for (int k = 0; k < 255 && ok; ++k) {
+      if (out->thresholds[k] == inf) continue;  // byte k + 1 is never reached
+      const uint32_t q = bucket_index(out->thresholds[k], magic);
+      if (q > n || held[q] != 0) ok = false;  // a second threshold in one bucket would be lost
+      else held[q] = 1, b[q].edge = out->thresholds[k];
     }
     if (!ok) continue;
+    uint32_t before = 0;
+    for (uint32_t q = 0; q <= n; ++q) {
+      b[q].base = before;
+      before += held[q];
+    }
     out->n = n;
     out->buckets_unit = b;  // N + 1 buckets, edges in x units
     while ((out->buckets_unit.size() * sizeof(TransferBucket)) % 16 != 0)
       out->buckets_unit.push_back(TransferBucket{inf, 255u});
     out->buckets_linear.resize(b.size());
+    out->buckets_bytenorm.resize(b.size());
     for (size_t q = 0; q < b.size(); ++q) {
       TransferBucketLinear &e = out->buckets_linear[q];
       e.edge_pred = b[q].edge == inf ? inf : std::nextafter(b[q].edge, -inf);
       e.base = b[q].base;
       e.lin_below = std::ldexp(lin_of_byte[b[q].base], kLinearScaleLog2);      // exact: power of two
       e.lin_above = std::ldexp(lin_of_byte[b[q].base + 1], kLinearScaleLog2);
+      TransferBucketLinear &a = out->buckets_bytenorm[q];
+      a = e;
+      a.lin_below = std::ldexp(norm_of_byte[b[q].base], kLinearScaleLog2);
+      a.lin_above = std::ldexp(norm_of_byte[b[q].base + 1], kLinearScaleLog2);
     }
     return true;
   }

@@ -9,13 +9,18 @@
 // composite is a monotone step function of the float in [0,1] (checked for all
 // 1 065 353 217 inputs by tests/test_oracle_golden.py), so it is fully described
 // by 255 thresholds.  The kernel wants O(1) lookup, so the thresholds are laid
-// out in N uniform buckets, N a power of two chosen so no bucket holds two
+// out in N + 1 uniform buckets, N a power of two chosen so no bucket holds two
 // thresholds:
-//     byte(x) = bucket[q].base + (xs >= bucket[q].edge),   xs = N * x,  q = (uint)xs
+//     byte(x) = bucket[q].base + (x >= bucket[q].edge),   q = bucket_index(x)
 // The kernels saturate x to [0,1] first (as the reference does, BT709.h:444-446) and compare in
-// x units, so the table is N + 1 buckets (the last one holds x == 1.0) and `edge` is the
-// threshold itself.  The bucket index floor(x N) comes from a round-toward-zero add of 2^23 / N
-// (csrc/bt709_device.h magic_floor12).
+// x units; `edge` is the threshold itself.  The bucket index costs ONE float add: with
+// M = 2^23 / N a float in [M, 2M) has ulp 1/N, so
+//     bits(x + M) = bits(M) + round(x N)          (round to nearest even, the default mode)
+// and bucket q is the set of x whose sum lands on M + q / N: buckets are 1/N wide and centred on
+// q / N (q = 0 and q = N are half buckets).  Any monotone index function works as long as the
+// builder below and the kernels use the same one; round-to-nearest needs no MODE register switch
+// (round 1 used floor(x N) through a round-toward-zero add between two s_setreg; -DBT709_INDEX_RTZ
+// builds that form for A/B runs in tools/decode_lab).
 #pragma once
 
 #include <cstdint>
@@ -65,7 +70,13 @@ struct TransferTable {
   // buckets 0..N (bucket N: x == 1.0), padded to a 16-byte multiple
   std::vector<TransferBucket> buckets_unit;
   std::vector<TransferBucketLinear> buckets_linear;  // the same N + 1 buckets, linearised outputs
+  // the same buckets with lin_* = 2^-40 * byteNorm(byte) (Renderer/sRGB.h:32-36): how pass 2 reads
+  // the ALPHA channel of the 8-bit intermediate (a plain unorm, no sRGB curve)
+  std::vector<TransferBucketLinear> buckets_bytenorm;
 };
+
+// q of the comment above, computed exactly as the kernels do (csrc/bt709_device.h magic_index).
+uint32_t bucket_index(float x, float magic);
 
 // Scalar transfer functions, float in / float out, C semantics of the reference.
 float srgb_to_linear(float v);      // Renderer/sRGB.h:43-57

@@ -40,7 +40,9 @@ kCVImageBufferTransferFunction_ITU_R_709_2 = 1
 kCVImageBufferTransferFunction_sRGB = 2
 kCVImageBufferTransferFunction_Linear = 3
 
-MTLPixelFormatBGRA8Unorm_sRGB = 81  # the only render target format the HIP path writes
+MTLPixelFormatBGRA8Unorm_sRGB = 81  # default render target format
+MTLPixelFormatRGBA16Float = 115     # linear-light half floats: the reference's pre-10.14 intermediate (AAPLRenderer.m:143-170)
+_FORMAT_OF = {MTLPixelFormatBGRA8Unorm_sRGB: _capi.FORMAT_BGRA8_SRGB, MTLPixelFormatRGBA16Float: _capi.FORMAT_RGBA16F}
 
 
 def _align_up(v, a):
@@ -123,6 +125,13 @@ class InFlightFramePool:
         cv = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_uint8)), shape=(h // 2, cs.value))[:, :w]
         return slot.value, yv, cv
 
+    def alphaPlane(self, slot):
+        """Writable numpy view of the slot's pinned alpha plane (decoders with hasAlphaChannel only);
+        call between acquire and submit."""
+        a, stride = C.c_void_p(), C.c_size_t()
+        _capi.check(self.lib.bt709hip_pool_alpha_plane(self.handle, slot, C.byref(a), C.byref(stride)), "pool alpha plane")
+        return self._np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint8)), shape=(self.height, stride.value))[:, :self.width]
+
     def submit(self, slot):
         _capi.check(self.lib.bt709hip_pool_submit(self.handle, slot), "pool submit")
 
@@ -171,11 +180,14 @@ class CommandQueue:
 
 
 class BGRATexture:
-    """8-bit BGRA sRGB render target in device memory (id<MTLTexture> BGRA8Unorm_sRGB)."""
+    """Render target in device memory (id<MTLTexture>): 8-bit BGRA sRGB by default, or
+    RGBA16Float (pixelFormat=MTLPixelFormatRGBA16Float, 8 bytes per pixel, linear light)."""
 
-    def __init__(self, ctx, width, height, stride=None, ptr=None):
+    def __init__(self, ctx, width, height, stride=None, ptr=None, pixelFormat=MTLPixelFormatBGRA8Unorm_sRGB):
         self.ctx, self.width, self.height = ctx, int(width), int(height)
-        self.stride = int(stride) if stride else _align_up(self.width * 4, 16)
+        self.pixelFormat = pixelFormat
+        self.bytesPerPixel = 8 if pixelFormat == MTLPixelFormatRGBA16Float else 4
+        self.stride = int(stride) if stride else _align_up(self.width * self.bytesPerPixel, 16)
         self._buf = None
         if ptr is None:
             self._buf = DeviceBuffer(ctx, max(self.stride * self.height, 16))
@@ -183,7 +195,7 @@ class BGRATexture:
         self.ptr = ptr
 
     def surface(self):
-        return Surface(self.ptr, self.stride, self.width, self.height)
+        return Surface(self.ptr, self.stride, self.width, self.height, _FORMAT_OF[self.pixelFormat], 0)
 
 
 class CVPixelBuffer:
@@ -273,9 +285,9 @@ class MetalRenderContext:
             self.handle = None
 
     # -- texture helpers (MetalRenderContext.h:62-105)
-    def makeBGRATexture(self, size, pixels=None, stride=None):
+    def makeBGRATexture(self, size, pixels=None, stride=None, pixelFormat=MTLPixelFormatBGRA8Unorm_sRGB):
         w, h = size
-        tex = BGRATexture(self, w, h, stride)
+        tex = BGRATexture(self, w, h, stride, pixelFormat=pixelFormat)
         if pixels is not None:
             self.fillBGRATexture(tex, pixels)
         else:
@@ -289,7 +301,16 @@ class MetalRenderContext:
         self._sync(None)
 
     def getBGRATexturePixels(self, tex, commandBuffer=None):
-        """Read-back as an (H, W) uint32 array of (A<<24)|(R<<16)|(G<<8)|B words."""
+        """Read-back as an (H, W) uint32 array of (A<<24)|(R<<16)|(G<<8)|B words; an RGBA16Float
+        texture reads back as (H, W, 4) float16 in R,G,B,A order."""
+        if tex.bytesPerPixel == 8:
+            raw = np.empty((tex.height, tex.width * 8), dtype=np.uint8)
+            if tex.height and tex.width:
+                stream = commandBuffer.stream if commandBuffer else None
+                _capi.check(self.lib.bt709hip_download(self.handle, raw.ctypes.data, raw.shape[1], tex.ptr, tex.stride,
+                                                       raw.shape[1], tex.height, stream), "download")
+                self._sync(commandBuffer)
+            return raw.view(np.float16).reshape(tex.height, tex.width, 4)
         out = np.empty((tex.height, tex.width * 4), dtype=np.uint8)
         if tex.height and tex.width:
             stream = commandBuffer.stream if commandBuffer else None
@@ -391,6 +412,14 @@ class MetalBT709Decoder:
         self.alphaFill = 0xFF
         self.lastStatus = _capi.OK
         self._handle = None
+        self._options = {}  # bt709hip_decoder_option -> value, applied at setup and on change
+
+    def setOption(self, option, value):
+        """Kernel-selection knob (bt709hip_decoder_set_option; _capi.OPT_*): tuning and test hook."""
+        self._options[int(option)] = int(value)
+        if self._handle:
+            _capi.check(self.metalRenderContext.lib.bt709hip_decoder_set_option(self._handle, int(option), int(value)),
+                        "decoder set option")
 
     def _fail(self, rc, what):
         self.lastStatus = rc
@@ -414,6 +443,8 @@ class MetalBT709Decoder:
             return self._fail(rc, "decoder create")
         self._handle = h.value
         ctx.lib.bt709hip_decoder_set_alpha_fill(self._handle, int(self.alphaFill))
+        for opt, val in self._options.items():
+            _capi.check(ctx.lib.bt709hip_decoder_set_option(self._handle, opt, val), "decoder set option")
         rc = ctx.lib.bt709hip_decoder_setup(self._handle)
         if rc != _capi.OK:
             return self._fail(rc, "decoder setup")
@@ -462,35 +493,44 @@ class MetalBT709Decoder:
         self.lastStatus = _capi.OK
         return True
 
-    def decodeBT709Scaled(self, yCbCrInputTexture, bgraSRGBTexture, commandBuffer=None, waitUntilCompleted=False):
+    def decodeBT709Scaled(self, yCbCrInputTexture, bgraSRGBTexture, commandBuffer=None, waitUntilCompleted=False,
+                          alphaPixelBuffer=None):
         """-decodeBT709 into an intermediate + MetalScaleRenderContext -renderScaled:
         (AAPLRenderer.m:940-977), fused: the tuned kernel for the exact 2:1 ratio, the general
         bilinear kernel for any other view size (bit-identical where both apply)."""
         if not self.setupMetal():
             return False
         frame, surf = yCbCrInputTexture.frame(), bgraSRGBTexture.surface()
+        alpha = alphaPixelBuffer.frame() if alphaPixelBuffer is not None else None
         stream = commandBuffer.stream if commandBuffer is not None else None
         lib = self.metalRenderContext.lib
         exact_half = (2 * surf.width == frame.width and 2 * surf.height == frame.height
                       and frame.width % 4 == 0 and frame.height % 4 == 0)
         fn = lib.bt709hip_decode_half if exact_half else lib.bt709hip_decode_scaled  # any view size
-        rc = fn(self._handle, C.byref(frame), C.byref(surf), stream, int(bool(waitUntilCompleted)))
+        rc = fn(self._handle, C.byref(frame), C.byref(alpha) if alpha is not None else None, C.byref(surf), stream,
+                int(bool(waitUntilCompleted)))
         if rc != _capi.OK:
             return self._fail(rc, "decodeBT709Scaled")
         self.lastStatus = _capi.OK
         return True
 
-    def decodeBT709ScaledBatch(self, pixelBuffers, textures, commandBuffer=None, waitUntilCompleted=False):
-        """Exact 2:1 fused decode + rescale of `count` same-geometry frames in one launch (no
-        reference twin).  Large launches run the persistent conflict-free kernel."""
+    def decodeBT709ScaledBatch(self, pixelBuffers, textures, commandBuffer=None, waitUntilCompleted=False,
+                               alphaPixelBuffers=None):
+        """Fused decode + rescale of `count` same-geometry frames into same-sized outputs in one launch
+        (no reference twin): the 2:1 kernels when every output is exactly half the frame (large launches
+        run the persistent conflict-free kernel), the general bilinear kernel otherwise."""
         if not self.setupMetal():
             return False
         n = len(pixelBuffers)
         frames = (Frame * n)(*[b.frame() for b in pixelBuffers])
         surfs = (Surface * n)(*[t.surface() for t in textures])
+        alphas = (Frame * n)(*[b.frame() for b in alphaPixelBuffers]) if alphaPixelBuffers else None
         stream = commandBuffer.stream if commandBuffer is not None else None
-        rc = self.metalRenderContext.lib.bt709hip_decode_half_batch(self._handle, n, frames, surfs, stream,
-                                                                    int(bool(waitUntilCompleted)))
+        lib = self.metalRenderContext.lib
+        exact_half = n > 0 and all(2 * s.width == f.width and 2 * s.height == f.height and f.width % 4 == 0
+                                   and f.height % 4 == 0 for f, s in zip(frames, surfs))
+        fn = lib.bt709hip_decode_half_batch if exact_half else lib.bt709hip_decode_scaled_batch
+        rc = fn(self._handle, n, frames, alphas, surfs, stream, int(bool(waitUntilCompleted)))
         if rc != _capi.OK:
             return self._fail(rc, "decodeBT709ScaledBatch")
         self.lastStatus = _capi.OK

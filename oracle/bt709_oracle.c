@@ -255,6 +255,7 @@ int bt709o_decode_nv12(int gamma,
 int bt709o_decode_nv12_half(int gamma,
                             const uint8_t *y, size_t y_stride,
                             const uint8_t *uv, size_t uv_stride,
+                            const uint8_t *alpha, size_t alpha_stride,
                             int width, int height,
                             uint8_t *bgra, size_t bgra_stride,
                             int alpha_fill) {
@@ -279,10 +280,20 @@ int bt709o_decode_nv12_half(int gamma,
         float s = (((lin[p[0][c]] + lin[p[1][c]]) + lin[p[2][c]]) + lin[p[3][c]]) * 0.25f;
         q[c] = bt709o_quantize(bt709o_linear_to_srgb(s));
       }
+      int a = alpha_fill;
+      if (alpha) {
+        /* the alpha channel of the 8-bit intermediate is a plain unorm (no sRGB curve): the sampler
+         * reads byteNorm(a), the filtered value is written back as round(255 v)
+         * (AAPLShaders.metal:411-438 writes it; MetalScaleRenderContext.m:55-105 filters it) */
+        const uint8_t *a0 = alpha + (size_t)(2 * orow) * alpha_stride, *a1 = a0 + alpha_stride;
+        float s = (((byte_norm(bt709o_decode_alpha(a0[2 * ocol])) + byte_norm(bt709o_decode_alpha(a0[2 * ocol + 1]))) +
+                    byte_norm(bt709o_decode_alpha(a1[2 * ocol]))) + byte_norm(bt709o_decode_alpha(a1[2 * ocol + 1]))) * 0.25f;
+        a = bt709o_quantize(s);
+      }
       out[4 * ocol + 0] = (uint8_t)q[2];
       out[4 * ocol + 1] = (uint8_t)q[1];
       out[4 * ocol + 2] = (uint8_t)q[0];
-      out[4 * ocol + 3] = (uint8_t)alpha_fill;
+      out[4 * ocol + 3] = (uint8_t)a;
     }
   }
   return 0;
@@ -291,6 +302,7 @@ int bt709o_decode_nv12_half(int gamma,
 int bt709o_decode_nv12_scaled(int gamma,
                               const uint8_t *y, size_t y_stride,
                               const uint8_t *uv, size_t uv_stride,
+                              const uint8_t *alpha, size_t alpha_stride,
                               int width, int height,
                               uint8_t *bgra, size_t bgra_stride,
                               int out_width, int out_height, int alpha_fill) {
@@ -311,9 +323,13 @@ int bt709o_decode_nv12_scaled(int gamma,
       int xs[2] = {(int)x0f, (int)x0f + 1};
       for (int i = 0; i < 2; i++) xs[i] = xs[i] < 0 ? 0 : (xs[i] > width - 1 ? width - 1 : xs[i]);
       const float w[4] = {gx * gy, fx * gy, gx * fy, fx * fy};
-      float acc[3] = {0.0f, 0.0f, 0.0f};
+      float acc[3] = {0.0f, 0.0f, 0.0f}, acc_a = 0.0f;
       for (int t = 0; t < 4; t++) {
         const int xx = xs[t & 1], yy = ys[t >> 1];
+        if (alpha) { /* plain unorm channel, same weights and order */
+          const float term = w[t] * byte_norm(bt709o_decode_alpha(alpha[(size_t)yy * alpha_stride + xx]));
+          acc_a = t ? acc_a + term : term;
+        }
         const uint8_t *c = uv + (size_t)(yy / 2) * uv_stride + 2 * (xx / 2);
         int p[3];
         bt709o_decode_pixel(gamma, y[(size_t)yy * y_stride + xx], c[0], c[1], p);
@@ -327,7 +343,7 @@ int bt709o_decode_nv12_scaled(int gamma,
       out[4 * ox + 0] = (uint8_t)q[2];
       out[4 * ox + 1] = (uint8_t)q[1];
       out[4 * ox + 2] = (uint8_t)q[0];
-      out[4 * ox + 3] = (uint8_t)alpha_fill;
+      out[4 * ox + 3] = (uint8_t)(alpha ? bt709o_quantize(clamp01(acc_a)) : alpha_fill);
     }
   }
   return 0;

@@ -132,10 +132,15 @@ int bt709o_decode_nv12_rows(int gamma,
  * 8a row 9): decode the 4 source pixels to 8-bit sRGB, linearise each byte
  * with sRGB_nonLinearNormToLinear(byteNorm(b)), (((a+b)+c)+d)*0.25f,
  * sRGB_linearNormToNonLinear, quantise.  width/height are SOURCE dimensions
- * and must be multiples of 4 (so the output is even). */
+ * and must be multiples of 4 (so the output is even).
+ * alpha (may be NULL): linear alpha plane of an alpha clip.  Pass 2 reads the alpha channel of the
+ * 8-bit intermediate as a plain unorm (AAPLShaders.metal:411-438 writes it un-premultiplied;
+ * MetalScaleRenderContext.m:55-105 filters all four channels): out alpha =
+ * quantise((((byteNorm(a0)+byteNorm(a1))+byteNorm(a2))+byteNorm(a3))*0.25f), a_i = decoded alpha bytes. */
 int bt709o_decode_nv12_half(int gamma,
                             const uint8_t *y, size_t y_stride,
                             const uint8_t *uv, size_t uv_stride,
+                            const uint8_t *alpha, size_t alpha_stride,
                             int width, int height,
                             uint8_t *bgra, size_t bgra_stride,
                             int alpha_fill);
@@ -151,6 +156,7 @@ int bt709o_decode_nv12_half(int gamma,
 int bt709o_decode_nv12_scaled(int gamma,
                               const uint8_t *y, size_t y_stride,
                               const uint8_t *uv, size_t uv_stride,
+                              const uint8_t *alpha, size_t alpha_stride, /* NULL, or as in bt709o_decode_nv12_half */
                               int width, int height,
                               uint8_t *bgra, size_t bgra_stride,
                               int out_width, int out_height, int alpha_fill);

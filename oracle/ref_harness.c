@@ -195,3 +195,78 @@ void ref_decode_nv12_rows(int gamma, const uint8_t *y, size_t y_stride, const ui
     }
   }
 }
+
+/* ---- pass 2 (MetalScaleRenderContext -renderScaled: + samplingShader), composed ONLY of the
+ * reference's own inlines.  The reference runs pass 2 on sampler hardware and has no CPU twin, so
+ * the composition (its normative definition) is written here once, next to the
+ * functions it is made of, and its outputs pin both the oracle's restatement and the GPU kernels:
+ *   tap    = 8-bit sRGB bytes of pass 1 (ref_decode_pixel above: Apple196_to_sRGB_... etc.)
+ *   sample = sRGB_nonLinearNormToLinear(byteNorm(byte))        Renderer/sRGB.h:32-57 (what sampling an sRGB8 texel yields)
+ *   filter = (((a+b)+c)+d)*0.25f for the exact 2:1 ratio; bilinear weights in general
+ *   store  = (int)round(sRGB_linearNormToNonLinear(v) * 255.0f)  Renderer/sRGB.h:62-74, BT709.h:881-883
+ * The alpha channel of the intermediate is a plain unorm: sample = byteNorm(a), store = round(v*255). */
+static int ref_store_srgb(float linear) { return (int)round(sRGB_linearNormToNonLinear(linear) * 255.0f); }
+static int ref_store_unorm(float v) { return (int)round(saturatef(v) * 255.0f); }
+
+void ref_decode_nv12_half(int gamma, const uint8_t *y, size_t y_stride, const uint8_t *uv, size_t uv_stride,
+                          const uint8_t *alpha, size_t alpha_stride, int width, int height, uint8_t *bgra,
+                          size_t bgra_stride, int alpha_fill) {
+  for (int orow = 0; orow < height / 2; orow++)
+    for (int ocol = 0; ocol < width / 2; ocol++) {
+      const int cb = uv[(size_t)orow * uv_stride + 2 * ocol], cr = uv[(size_t)orow * uv_stride + 2 * ocol + 1];
+      int p[4][3], a[4];
+      for (int t = 0; t < 4; t++) {
+        const size_t row = 2 * orow + (t >> 1), col = 2 * ocol + (t & 1);
+        ref_decode_pixel(gamma, y[row * y_stride + col], cb, cr, p[t]);
+        a[t] = alpha ? ref_decode_alpha(alpha[row * alpha_stride + col]) : alpha_fill;
+      }
+      uint8_t *o = bgra + (size_t)orow * bgra_stride + 4 * ocol;
+      for (int c = 0; c < 3; c++) {
+        const float s = (((sRGB_nonLinearNormToLinear(byteNorm(p[0][c])) + sRGB_nonLinearNormToLinear(byteNorm(p[1][c]))) +
+                          sRGB_nonLinearNormToLinear(byteNorm(p[2][c]))) + sRGB_nonLinearNormToLinear(byteNorm(p[3][c]))) * 0.25f;
+        o[2 - c] = (uint8_t)ref_store_srgb(s);
+      }
+      o[3] = alpha ? (uint8_t)ref_store_unorm((((byteNorm(a[0]) + byteNorm(a[1])) + byteNorm(a[2])) + byteNorm(a[3])) * 0.25f)
+                   : (uint8_t)alpha_fill;
+    }
+}
+
+/* Any output size: texel-centre sampling, clamp to edge, weights w00 = (1-fx)(1-fy) ..., summed
+ * (((w00*a + w01*b) + w10*c) + w11*d).  The sampling geometry is OUR definition (the reference
+ * leaves it to the sampler); every transfer function and the quantisation are the reference's. */
+void ref_decode_nv12_scaled(int gamma, const uint8_t *y, size_t y_stride, const uint8_t *uv, size_t uv_stride,
+                            const uint8_t *alpha, size_t alpha_stride, int width, int height, uint8_t *bgra,
+                            size_t bgra_stride, int out_width, int out_height, int alpha_fill) {
+  const float scale_x = (float)width / (float)out_width, scale_y = (float)height / (float)out_height;
+  for (int oy = 0; oy < out_height; oy++) {
+    const float sy = ((float)oy + 0.5f) * scale_y - 0.5f;
+    const float y0f = floorf(sy), fy = sy - y0f, gy = 1.0f - fy;
+    int ys[2] = {(int)y0f, (int)y0f + 1};
+    for (int i = 0; i < 2; i++) ys[i] = ys[i] < 0 ? 0 : (ys[i] > height - 1 ? height - 1 : ys[i]);
+    for (int ox = 0; ox < out_width; ox++) {
+      const float sx = ((float)ox + 0.5f) * scale_x - 0.5f;
+      const float x0f = floorf(sx), fx = sx - x0f, gx = 1.0f - fx;
+      int xs[2] = {(int)x0f, (int)x0f + 1};
+      for (int i = 0; i < 2; i++) xs[i] = xs[i] < 0 ? 0 : (xs[i] > width - 1 ? width - 1 : xs[i]);
+      const float w[4] = {gx * gy, fx * gy, gx * fy, fx * fy};
+      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int t = 0; t < 4; t++) {
+        const int xx = xs[t & 1], yy = ys[t >> 1];
+        const uint8_t *c = uv + (size_t)(yy / 2) * uv_stride + 2 * (xx / 2);
+        int p[3];
+        ref_decode_pixel(gamma, y[(size_t)yy * y_stride + xx], c[0], c[1], p);
+        for (int k = 0; k < 3; k++) {
+          const float term = w[t] * sRGB_nonLinearNormToLinear(byteNorm(p[k]));
+          acc[k] = t ? acc[k] + term : term;
+        }
+        if (alpha) {
+          const float term = w[t] * byteNorm(ref_decode_alpha(alpha[(size_t)yy * alpha_stride + xx]));
+          acc[3] = t ? acc[3] + term : term;
+        }
+      }
+      uint8_t *o = bgra + (size_t)oy * bgra_stride + 4 * ox;
+      for (int k = 0; k < 3; k++) o[2 - k] = (uint8_t)ref_store_srgb(acc[k]);
+      o[3] = alpha ? (uint8_t)ref_store_unorm(acc[3]) : (uint8_t)alpha_fill;
+    }
+  }
+}

@@ -62,3 +62,9 @@ def bt709():
     (no CPU fallback) if the HIP library is missing."""
     import metalbt709decoder_amd as pkg
     return pkg
+
+
+@pytest.fixture(scope="session")
+def pass2():
+    """Decode + pass 2 computed by the reference's own inlines (tests/golden/make_golden.py)."""
+    return json.load(open(os.path.join(GOLDEN, "pass2.json")))

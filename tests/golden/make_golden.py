@@ -15,6 +15,9 @@ Outputs (all committed):
                     running the reference headers (oracle/_ref)
   patterns.npz      crops of the bundled test images as NV12 (reference encoder) with the
                     reference decode of each crop in every gamma mode
+  pass2.json        sha256 of decode + pass 2 (2:1 and any-ratio rescale) composed of the reference's
+                    own inlines (oracle/ref_harness.c) on seeded frames and on the pattern crops;
+                    pass2_small.npz holds the small outputs themselves
 """
 import hashlib
 import json
@@ -241,6 +244,40 @@ def collect_patterns(ref):
     return arrays, meta
 
 
+# ----------------------------------------------------------------- pass 2 (reference-composed)
+
+def collect_pass2(ref, pattern_arrays):
+    """sha256 (+ a few stored outputs) of decode + pass 2 computed by oracle/ref_harness.c's composition
+    of the reference's own inlines: the pin for the oracle's and the GPU's fused rescale."""
+    import pass2_cases as pc
+    out = {"note": "ref_decode_nv12_half / ref_decode_nv12_scaled of oracle/ref_harness.c: pass 1 bytes by the "
+                   "reference's per-pixel functions, sampler-side sRGB decode by sRGB_nonLinearNormToLinear(byteNorm(b)), "
+                   "(((a+b)+c)+d)*0.25f or bilinear weights, sRGB_linearNormToNonLinear, (int)round(v*255.0f)",
+           "cases": {}, "patterns": {}}
+    stored = {}
+    for kind, gamma, src, dst, seed, with_alpha in pc.CASES:
+        y, c, a = pc.seeded_frame(src, seed, with_alpha)
+        got = (ref.decode_nv12_half(gamma, y, c, alpha=a) if kind == "half"
+               else ref.decode_nv12_scaled(gamma, y, c, dst[0], dst[1], alpha=a))
+        key = pc.case_key(kind, gamma, src, dst, seed, with_alpha)
+        out["cases"][key] = hashlib.sha256(got.tobytes()).hexdigest()
+        if got.size <= 4096:
+            stored[key] = got
+    tags = sorted({k[:-2] for k in pattern_arrays if k.endswith("_y")})
+    for tag in tags:
+        y, c = pattern_arrays[tag + "_y"], pattern_arrays[tag + "_uv"]
+        h, w = y.shape
+        rec = {}
+        for gamma in range(4):
+            rec["half/g%d" % gamma] = hashlib.sha256(ref.decode_nv12_half(gamma, y, c).tobytes()).hexdigest()
+            for (ow, oh) in pc.PATTERN_SIZES["scaled"]:
+                rec["scaled/g%d/%dx%d" % (gamma, ow, oh)] = hashlib.sha256(
+                    ref.decode_nv12_scaled(gamma, y, c, ow, oh).tobytes()).hexdigest()
+        out["patterns"][tag] = rec
+        print("pass2", tag, flush=True)
+    return out, stored
+
+
 def main():
     ref = Reference()
     vec = collect_vectors()
@@ -254,6 +291,11 @@ def main():
     json.dump(r, open(os.path.join(HERE, "reference.json"), "w"), indent=1)
     np.savez_compressed(os.path.join(HERE, "patterns.npz"), **arrays)
     print("patterns.npz", os.path.getsize(os.path.join(HERE, "patterns.npz")), "bytes")
+
+    p2, stored = collect_pass2(ref, arrays)
+    json.dump(p2, open(os.path.join(HERE, "pass2.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(HERE, "pass2_small.npz"), **{k.replace("/", "_"): v for k, v in stored.items()})
+    print("pass2.json", len(p2["cases"]), "cases,", len(p2["patterns"]), "patterns")
 
 
 if __name__ == "__main__":

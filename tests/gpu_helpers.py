@@ -25,12 +25,15 @@ def context():
     return _ctx
 
 
-def make_decoder(gamma=mb.MetalBT709GammaApple, has_alpha=False, alpha_fill=0xFF):
+def make_decoder(gamma=mb.MetalBT709GammaApple, has_alpha=False, alpha_fill=0xFF, options=None):
+    """options: {_capi.OPT_*: value} kernel-selection knobs (bt709hip_decoder_set_option)."""
     d = mb.MetalBT709Decoder()
     d.metalRenderContext = context()
     d.gamma = gamma
     d.hasAlphaChannel = has_alpha
     d.alphaFill = alpha_fill
+    for opt, val in (options or {}).items():
+        d.setOption(opt, val)
     assert d.setupMetal(), d.lastStatus
     return d
 
@@ -73,15 +76,21 @@ def gpu_decode(y, cbcr, gamma=mb.MetalBT709GammaApple, alpha=None, alpha_fill=0x
     return ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(h, w * 4)
 
 
-def gpu_decode_half(y, cbcr, gamma=mb.MetalBT709GammaApple, decoder=None):
+def gpu_decode_half(y, cbcr, gamma=mb.MetalBT709GammaApple, decoder=None, alpha=None):
+    return gpu_decode_scaled(y, cbcr, (y.shape[1] // 2, y.shape[0] // 2), gamma, decoder, alpha)
+
+
+def gpu_decode_scaled(y, cbcr, out_size, gamma=mb.MetalBT709GammaApple, decoder=None, alpha=None):
+    """Fused decode + rescale to out_size = (OW, OH) (the 2:1 kernels when that is exactly half)."""
     ctx = context()
-    h, w = y.shape
-    dec = decoder or make_decoder(gamma)
+    ow, oh = out_size
+    dec = decoder or make_decoder(gamma, has_alpha=alpha is not None)
     buf = make_buffer(y, cbcr, dec.gamma)
-    tex = ctx.makeBGRATexture((w // 2, h // 2))
-    if not dec.decodeBT709Scaled(buf, tex, ctx.commandQueue.commandBuffer(), True):
+    abuf = make_alpha_buffer(alpha) if alpha is not None else None
+    tex = ctx.makeBGRATexture((ow, oh))
+    if not dec.decodeBT709Scaled(buf, tex, ctx.commandQueue.commandBuffer(), True, alphaPixelBuffer=abuf):
         return None
-    return ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(h // 2, (w // 2) * 4)
+    return ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(oh, ow * 4)
 
 
 def random_nv12(w, h, seed, legal=False):

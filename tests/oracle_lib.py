@@ -61,7 +61,7 @@ class Oracle:
             C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t, C.c_int]
         L.bt709o_decode_nv12_half.restype = C.c_int
         L.bt709o_decode_nv12_half.argtypes = [
-            C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int,
+            C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int,
             _u8p, C.c_size_t, C.c_int]
         L.bt709o_unconvert_packed.restype = C.c_int
         L.bt709o_unconvert_packed.argtypes = [C.c_int, _u32p, _u32p, C.c_int, C.c_int]
@@ -138,26 +138,30 @@ class Oracle:
             return None
         return out
 
-    def decode_nv12_half(self, gamma, y, uv, alpha_fill=0xFF):
+    def decode_nv12_half(self, gamma, y, uv, alpha_fill=0xFF, alpha=None):
         y, width = _plane(y)
         uv, _ = _plane(uv)
+        a = _plane(alpha)[0] if alpha is not None else None
         height = y.shape[0]
         out = np.zeros((height // 2, (width // 2) * 4), dtype=np.uint8)
         rc = self.lib.bt709o_decode_nv12_half(
             gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1],
+            _ptr(a, _u8p) if a is not None else None, a.shape[1] if a is not None else 0,
             width, height, _ptr(out, _u8p), out.shape[1], alpha_fill)
         return out if rc == 0 else None
 
-    def decode_nv12_scaled(self, gamma, y, uv, out_width, out_height, alpha_fill=0xFF):
+    def decode_nv12_scaled(self, gamma, y, uv, out_width, out_height, alpha_fill=0xFF, alpha=None):
         y, width = _plane(y)
         uv, _ = _plane(uv)
+        a = _plane(alpha)[0] if alpha is not None else None
         height = y.shape[0]
         out = np.zeros((out_height, out_width * 4), dtype=np.uint8)
         fn = self.lib.bt709o_decode_nv12_scaled
         fn.restype = C.c_int
-        fn.argtypes = [C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t,
-                       C.c_int, C.c_int, C.c_int]
-        rc = fn(gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1], width, height,
+        fn.argtypes = [C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p,
+                       C.c_size_t, C.c_int, C.c_int, C.c_int]
+        rc = fn(gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1],
+                _ptr(a, _u8p) if a is not None else None, a.shape[1] if a is not None else 0, width, height,
                 _ptr(out, _u8p), out.shape[1], out_width, out_height, alpha_fill)
         return out if rc == 0 else None
 
@@ -274,6 +278,37 @@ class Reference:
         r0, r1 = rows if rows is not None else (0, height)
         self.lib.ref_decode_nv12_rows(gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1],
                                       width, r0, r1, _ptr(out, _u8p), out.shape[1], alpha_fill)
+        return out
+
+    def decode_nv12_half(self, gamma, y, uv, alpha_fill=0xFF, alpha=None):
+        """Pass 1 + exact 2:1 pass 2, composed of the reference's own inlines (oracle/ref_harness.c)."""
+        y, width = _plane(y)
+        uv, _ = _plane(uv)
+        a = _plane(alpha)[0] if alpha is not None else None
+        height = y.shape[0]
+        out = np.zeros((height // 2, (width // 2) * 4), dtype=np.uint8)
+        fn = self.lib.ref_decode_nv12_half
+        fn.restype = None
+        fn.argtypes = [C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p,
+                       C.c_size_t, C.c_int]
+        fn(gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1],
+           _ptr(a, _u8p) if a is not None else None, a.shape[1] if a is not None else 0, width, height,
+           _ptr(out, _u8p), out.shape[1], alpha_fill)
+        return out
+
+    def decode_nv12_scaled(self, gamma, y, uv, out_width, out_height, alpha_fill=0xFF, alpha=None):
+        y, width = _plane(y)
+        uv, _ = _plane(uv)
+        a = _plane(alpha)[0] if alpha is not None else None
+        height = y.shape[0]
+        out = np.zeros((out_height, out_width * 4), dtype=np.uint8)
+        fn = self.lib.ref_decode_nv12_scaled
+        fn.restype = None
+        fn.argtypes = [C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p,
+                       C.c_size_t, C.c_int, C.c_int, C.c_int]
+        fn(gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1],
+           _ptr(a, _u8p) if a is not None else None, a.shape[1] if a is not None else 0, width, height,
+           _ptr(out, _u8p), out.shape[1], out_width, out_height, alpha_fill)
         return out
 
     def decode_pixel(self, gamma, Y, Cb, Cr):

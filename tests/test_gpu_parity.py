@@ -374,9 +374,30 @@ def test_in_flight_frame_pool(gh, oracle, gamma):
     assert lib.bt709hip_pool_submit(pool.handle, 0) == _capi.ERR_INVALID_ARG      # not acquired
     assert lib.bt709hip_pool_submit(pool.handle, 99) == _capi.ERR_INVALID_ARG
     pool.release()
-    da = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
-    hnd = C.c_void_p()
-    assert lib.bt709hip_pool_create(da._handle, 64, 32, 2, C.byref(hnd)) == _capi.ERR_UNSUPPORTED
+
+
+def test_in_flight_frame_pool_with_alpha(gh, oracle):
+    """An alpha clip through the pool: every slot also owns an alpha plane (the reference hands
+    -decodeBT709: a second CVPixelBuffer, MetalBT709Decoder.h:65-72)."""
+    dec = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
+    w, h, depth = 72, 20, 2
+    pool = mb.InFlightFramePool(dec, (w, h), depth)
+    rng = np.random.default_rng(12)
+    frames = [gh.random_nv12(w, h, seed=800 + i) + (rng.integers(0, 256, (h, w), dtype=np.uint8),) for i in range(5)]
+    for i, (y, c, a) in enumerate(frames):
+        slot, ybuf, cbuf = pool.acquire()
+        ybuf[:], cbuf[:] = y, c
+        pool.alphaPlane(slot)[:] = a
+        pool.submit(slot)
+        assert np.array_equal(pool.wait(slot), oracle.decode_nv12(mb.MetalBT709GammaSRGB, y, c, alpha=a)), i
+    lib = gh.context().lib
+    p, st = C.c_void_p(), C.c_size_t()
+    assert lib.bt709hip_pool_alpha_plane(pool.handle, 0, C.byref(p), C.byref(st)) == _capi.ERR_INVALID_ARG  # not acquired
+    pool.release()
+    opaque = mb.InFlightFramePool(gh.make_decoder(mb.MetalBT709GammaApple), (w, h), 1)
+    slot, _, _ = opaque.acquire()
+    assert lib.bt709hip_pool_alpha_plane(opaque.handle, slot, C.byref(p), C.byref(st)) == _capi.ERR_UNSUPPORTED
+    opaque.release()
 
 
 def test_recorded_command_buffer_replays(gh, oracle):
@@ -427,15 +448,13 @@ def test_half_scale(gh, oracle, gamma, size):
 @pytest.mark.parametrize("workgroups", [1, 3, 256])
 @pytest.mark.parametrize("gamma", GAMMAS)
 @pytest.mark.parametrize("size", [(4, 4), (40, 12), (256, 64), (1920, 1080 - 1080 % 4), (4104, 8), (8200, 12)])
-def test_half_scale_persistent_kernel(gh, oracle, monkeypatch, gamma, size, workgroups):
+def test_half_scale_persistent_kernel(gh, oracle, gamma, size, workgroups):
     """The persistent conflict-free form of the 2:1 kernel (replicated LDS tables, one workgroup per
     CU walking tile rows) forced on frames of every shape: rows narrower than a workgroup, rows
     of 2 and 3 tiles, more / fewer workgroups than tile rows, odd tile-row counts."""
-    monkeypatch.setenv("BT709HIP_HALF_REP", "1")
-    monkeypatch.setenv("BT709HIP_REP_WORKGROUPS", str(workgroups))
     w, h = size
     y, c = gh.random_nv12(w, h, seed=w + h + gamma)
-    dec = gh.make_decoder(gamma)
+    dec = gh.make_decoder(gamma, options={_capi.OPT_HALF_KERNEL: 1, _capi.OPT_HALF_WORKGROUPS: workgroups})
     out = gh.gpu_decode_half(y, c, gamma, decoder=dec)
     assert gh.context().lib.bt709hip_last_kernel_name() == b"decode_nv12_half_rep"
     assert np.array_equal(out, oracle.decode_nv12_half(gamma, y, c))
@@ -443,12 +462,10 @@ def test_half_scale_persistent_kernel(gh, oracle, monkeypatch, gamma, size, work
 
 @pytest.mark.parametrize("rep", [0, 1])
 @pytest.mark.parametrize("count", [2, 5])
-def test_half_scale_batch(gh, oracle, monkeypatch, rep, count):
+def test_half_scale_batch(gh, oracle, rep, count):
     """Several frames per launch (pointer table; the persistent kernel's cursor crosses frames)."""
-    monkeypatch.setenv("BT709HIP_HALF_REP", str(rep))
-    monkeypatch.setenv("BT709HIP_REP_WORKGROUPS", "7")
     ctx = gh.context()
-    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    dec = gh.make_decoder(mb.MetalBT709GammaApple, options={_capi.OPT_HALF_KERNEL: rep, _capi.OPT_HALF_WORKGROUPS: 7})
     w, h = 72, 20
     frames = [gh.random_nv12(w, h, seed=900 + i) for i in range(count)]
     bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
@@ -465,6 +482,161 @@ def test_half_scale_flat_frame_is_identity(gh):
     full = gh.gpu_decode(y, c)
     half = gh.gpu_decode_half(y, c)
     assert (half.reshape(-1, 4) == full.reshape(-1, 4)[0]).all()
+
+
+@pytest.mark.parametrize("size", [(8, 4), (72, 20), (256, 64), (1028, 8)])
+def test_half_scale_with_alpha(gh, oracle, size):
+    """Alpha clips go through both passes in the reference (AAPLShaders.metal:411-438 into the
+    intermediate, then MetalScaleRenderContext.m:55-105): rgb as for an opaque clip, alpha filtered
+    as a plain unorm.  Aligned layouts take the wide kernel, everything else the narrow one."""
+    w, h = size
+    y, c = gh.random_nv12(w, h, seed=w + h)
+    a = np.random.default_rng(w).integers(0, 256, (h, w), dtype=np.uint8)
+    out = gh.gpu_decode_half(y, c, alpha=a)
+    assert b"alpha" in gh.context().lib.bt709hip_last_kernel_name()
+    assert np.array_equal(out, oracle.decode_nv12_half(mb.MetalBT709GammaSRGB, y, c, alpha=a))
+    # all 256 alpha codes in flat 2x2 blocks come back unchanged
+    a2 = np.repeat(np.repeat(np.arange(256, dtype=np.uint8).reshape(4, 64), 2, axis=0), 2, axis=1)
+    y2, c2 = gh.random_nv12(128, 8, seed=3)
+    out2 = gh.gpu_decode_half(y2, c2, alpha=a2).reshape(4, 64, 4)
+    full = gh.gpu_decode(y2, c2, alpha=a2, decoder=gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)).reshape(8, 128, 4)
+    assert np.array_equal(out2[..., 3], full[::2, ::2, 3])
+
+
+def test_pass2_equals_reference_composed_fixture(gh, pass2, patterns):
+    """GPU fused rescale against tests/golden/pass2.json: outputs of the REFERENCE's own inlines
+    composed per SURVEY 8(a) row 9 (oracle/ref_harness.c), not of our restatement."""
+    import hashlib
+    import pass2_cases as pc
+    decs = {}
+
+    def dec_for(gamma, alpha):
+        if (gamma, alpha) not in decs:
+            decs[(gamma, alpha)] = gh.make_decoder(gamma, has_alpha=alpha)
+        return decs[(gamma, alpha)]
+
+    for kind, gamma, src, dst, seed, with_alpha in pc.CASES:
+        y, c, a = pc.seeded_frame(src, seed, with_alpha)
+        got = gh.gpu_decode_scaled(y, c, dst, gamma, dec_for(gamma, with_alpha), alpha=a)
+        key = pc.case_key(kind, gamma, src, dst, seed, with_alpha)
+        assert got is not None and hashlib.sha256(got.tobytes()).hexdigest() == pass2["cases"][key], key
+    for tag, rec in pass2["patterns"].items():
+        y, c = patterns[tag + "_y"], patterns[tag + "_uv"]
+        for gamma in GAMMAS:
+            got = gh.gpu_decode_half(y, c, gamma, dec_for(gamma, False))
+            assert hashlib.sha256(got.tobytes()).hexdigest() == rec["half/g%d" % gamma], (tag, gamma)
+            for (ow, oh) in pc.PATTERN_SIZES["scaled"]:
+                got = gh.gpu_decode_scaled(y, c, (ow, oh), gamma, dec_for(gamma, False))
+                assert hashlib.sha256(got.tobytes()).hexdigest() == rec["scaled/g%d/%dx%d" % (gamma, ow, oh)], (tag, gamma)
+
+
+# ------------------------------------------------------------------ BASELINE configs at full size
+
+def test_config4_8k_to_4k_full_size(gh, oracle):
+    """BASELINE config 4 as written: 7680x4320 NV12 -> 3840x2160 through bt709hip_decode_half with
+    default options.  The shim must pick the persistent conflict-free kernel at this geometry
+    (17 tile rows per CU); the frame is a tiling of a small tile, so its decode must be the tiling
+    of the tile's decode (size-independent property), the tile itself checked against the oracle."""
+    ty, tc = gh.random_nv12(256, 16, seed=84)
+    y, c = np.tile(ty, (270, 30)), np.tile(tc, (270, 30))
+    out = gh.gpu_decode_half(y, c, mb.MetalBT709GammaApple)
+    assert gh.context().lib.bt709hip_last_kernel_name() == b"decode_nv12_half_rep"
+    tile = oracle.decode_nv12_half(0, ty, tc)
+    assert out.shape == (2160, 3840 * 4) and np.array_equal(out, np.tile(tile, (270, 30)))
+    # and the top rows of a NON-periodic 8K frame straight against the oracle
+    y2, c2 = gh.random_nv12(7680, 4320, seed=85)
+    out2 = gh.gpu_decode_half(y2, c2, mb.MetalBT709GammaApple)
+    for r0 in (0, 2000, 4256):
+        assert np.array_equal(out2[r0 // 2:r0 // 2 + 32], oracle.decode_nv12_half(0, y2[r0:r0 + 64], c2[r0 // 2:r0 // 2 + 32]))
+
+
+def test_config4_batch_of_16_like_the_bench(gh, oracle):
+    """bench.py's config-4 launch shape: 16 evenly spaced 8K frames, one decode_half_batch call."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    n, w, h = 16, 7680, 4320
+    in_pitch, out_pitch = w * h * 3 // 2, (w // 2) * (h // 2) * 4
+    slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
+    tiles = [gh.random_nv12(512, 8, seed=870 + i) for i in range(n)]
+    bufs, texs = [], []
+    for i, (ty, tc) in enumerate(tiles):
+        base = slab_in.ptr + i * in_pitch
+        b = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h))
+        mb.BGRAToBT709Converter.setBT709Attributes(b)
+        b.upload_planes(np.tile(ty, (540, 15)), np.tile(tc, (540, 15)))
+        bufs.append(b)
+        texs.append(mb.BGRATexture(ctx, w // 2, h // 2, (w // 2) * 4, ptr=slab_out.ptr + i * out_pitch))
+    assert dec.decodeBT709ScaledBatch(bufs, texs, ctx.commandQueue.commandBuffer(), True), dec.lastStatus
+    assert ctx.lib.bt709hip_last_kernel_name() == b"decode_nv12_half_rep"
+    for (ty, tc), t in zip(tiles, texs):
+        got = ctx.getBGRATexturePixels(t).view(np.uint8).reshape(h // 2, (w // 2) * 4)
+        assert np.array_equal(got, np.tile(oracle.decode_nv12_half(0, ty, tc), (540, 15)))
+
+
+def test_config2_600_frame_1080p_stream(gh, oracle):
+    """BASELINE config 2: a 1920x1080 stream of 600 frames (10 s at 60 fps) from a ring of 64
+    distinct frames, host memory in, host memory out, through the in-flight frame pool (one HIP
+    stream per in-flight frame); every 50th frame is byte-compared with the oracle, all of them by
+    a checksum against the first decode of the same ring entry."""
+    import zlib
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    w, h, depth, ring, total = 1920, 1080, 4, 64, 600
+    pool = mb.InFlightFramePool(dec, (w, h), depth)
+    frames = [gh.random_nv12(w, h, seed=6000 + i) for i in range(ring)]
+    first_crc, pending, checked = {}, [], 0
+
+    def collect(i, slot):
+        nonlocal checked
+        out = pool.wait(slot)
+        crc = zlib.crc32(out.tobytes())
+        assert first_crc.setdefault(i % ring, crc) == crc, i  # decoding is stateless: same frame, same bytes
+        if i % 50 == 0:
+            from concurrent.futures import ThreadPoolExecutor
+            y, c = frames[i % ring]
+            want = np.zeros((h, w * 4), np.uint8)
+            with ThreadPoolExecutor(8) as ex:
+                list(ex.map(lambda b: oracle.decode_nv12(0, y, c, rows=b, out=want), [(r, r + 108) for r in range(0, h, 108)]))
+            assert np.array_equal(out, want), i
+            checked += 1
+
+    for i in range(total):
+        if len(pending) == depth:
+            collect(*pending.pop(0))
+        slot, ybuf, cbuf = pool.acquire()
+        ybuf[:], cbuf[:] = frames[i % ring]
+        pool.submit(slot)
+        pending.append((i, slot))
+    for item in pending:
+        collect(*item)
+    assert checked == 12 and len(first_crc) == ring
+    pool.release()
+
+
+def test_config5_per_gpu_unit_8_x_4k(gh, oracle):
+    """BASELINE config 5's step on one GPU: 8 x 4K frames, (a) as one decode_batch launch, (b) as 8
+    single-frame launches on 8 streams (one HIP stream per in-flight frame); sampled row bands of
+    every frame against the oracle, and (a) == (b) byte for byte."""
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    n, w, h = 8, 3840, 2160
+    frames = [gh.random_nv12(w, h, seed=5000 + i) for i in range(n)]
+    bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
+    texs_a = [ctx.makeBGRATexture((w, h)) for _ in range(n)]
+    texs_b = [ctx.makeBGRATexture((w, h)) for _ in range(n)]
+    assert dec.decodeBT709Batch(bufs, texs_a, waitUntilCompleted=True), dec.lastStatus
+    cbs = [ctx.commandQueue.commandBuffer(new_stream=True) for _ in range(n)]
+    for b, t, cb in zip(bufs, texs_b, cbs):
+        assert dec.decodeBT709(b, None, t, cb, None, w, h, False)
+    for cb in cbs:
+        cb.waitUntilCompleted()
+    for i, ((y, c), ta, tb, cb) in enumerate(zip(frames, texs_a, texs_b, cbs)):
+        a = ctx.getBGRATexturePixels(ta).view(np.uint8).reshape(h, w * 4)
+        b = ctx.getBGRATexturePixels(tb).view(np.uint8).reshape(h, w * 4)
+        assert np.array_equal(a, b), i
+        for r0 in (0, 2 * (137 * (i + 1) % 1000), h - 16):
+            assert np.array_equal(a[r0:r0 + 16], oracle.decode_nv12(0, y, c, rows=(r0, r0 + 16))[r0:r0 + 16]), (i, r0)
+        cb.release()
 
 
 # ------------------------------------------------------------------ error behaviour
@@ -538,6 +710,21 @@ def test_output_padding_is_untouched(gh):
     _capi.check(ctx.lib.bt709hip_download(ctx.handle, raw.ctypes.data, stride, tex.ptr, stride, stride, h, None))
     ctx._sync(None)
     assert (raw[:, w * 4:] == 0xAB).all()
+
+
+def test_cpp_host_mirror_host_memory_overload(gh, vectors, tmp_path):
+    """The unchanged 8-argument selector for a caller whose CVPixelBuffer and texture are in HOST
+    memory (what AAPLRenderer.m:927-957 and MetalBT709DecoderTests.m:248-255 hold): the C++ mirror's
+    overload moves them through the in-flight pool, three frames in flight; the 28 reference vectors."""
+    import subprocess
+    from test_host_cpu import build_cpp_selftest
+    exe = build_cpp_selftest(tmp_path)
+    args = ["--host"]
+    for r in vectors["metal_decode"]:
+        args += [str(v) for v in r["ycbcr"] + r["rgb_out"]]
+    res = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "28 host vectors, 0 failures" in res.stdout
 
 
 def test_cpp_host_mirror_reference_vectors(gh, vectors, tmp_path):

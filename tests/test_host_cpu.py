@@ -83,6 +83,63 @@ def test_host_built_thresholds_equal_reference(lib, refdata, oracle, gamma):
     assert lib.bt709hip_gamma_thresholds(7, t.ctypes.data_as(C.POINTER(C.c_float))) == _capi.ERR_INVALID_ARG
 
 
+@pytest.mark.parametrize("gamma", [0, 1, 2, 3])
+def test_host_bucket_lookup_is_exact_at_every_breakpoint(lib, oracle, gamma):
+    """The kernels' lookup (bucket index by one float add, then one compare) replayed on the host:
+    a piecewise-constant function can only be wrong next to a breakpoint, and its breakpoints are
+    the 255 thresholds and the bucket boundaries -- every float within 2 ulps of each is checked
+    against the oracle's composite (double pow inside), plus a strided sweep of [0, 1]."""
+    n, q = C.c_int(), C.c_int()
+    assert lib.bt709hip_gamma_lookup(gamma, 0.0, C.byref(n), C.byref(q)) == oracle.transfer_to_byte(gamma, 0.0)
+    N = n.value
+    assert N in (256, 512, 1024, 2048, 4096) and q.value == 0
+    pts = set()
+    thr = oracle.thresholds(gamma)
+    for t in thr[np.isfinite(thr)].view(np.uint32):
+        pts.update(range(max(int(t) - 2, 0), int(t) + 3))
+    for k in range(N + 1):  # boundaries sit near (k +- 0.5) / N (and k / N for the round-1 floor form)
+        for c in (np.float32(k / N), np.float32((k + 0.5) / N)):
+            b = int(np.array([min(c, np.float32(1.0))], np.float32).view(np.uint32)[0])
+            pts.update(range(max(b - 2, 0), b + 3))
+    pts.update(range(0, 0x3F800000, 104729))
+    one = 0x3F800000
+    xs = np.array(sorted(p for p in pts if p <= one), dtype=np.uint32).view(np.float32)
+    last_q = -1
+    for x in xs:
+        got = lib.bt709hip_gamma_lookup(gamma, float(x), None, C.byref(q))
+        assert got == oracle.transfer_to_byte(gamma, float(x)), (gamma, float(x).hex())
+        assert last_q <= q.value <= N  # the index function is monotone
+        last_q = q.value
+    assert last_q == N  # x == 1.0 lands in the last bucket
+    assert lib.bt709hip_gamma_lookup(gamma, 1.5, None, None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_gamma_lookup(9, 0.5, None, None) == _capi.ERR_INVALID_ARG
+
+
+def test_decoder_and_context_options(lib):
+    """Tuning knobs are per-object options, not environment variables; values are clamped."""
+    d, v = C.c_void_p(), C.c_int()
+    assert lib.bt709hip_decoder_create(None, 0, 0, C.byref(d)) == 0
+    for opt, default in ((_capi.OPT_NONTEMPORAL, 1), (_capi.OPT_HALF_KERNEL, -1), (_capi.OPT_HALF_WORKGROUPS, 0),
+                         (_capi.OPT_HALF_LDS_KB, 0)):
+        assert lib.bt709hip_decoder_get_option(d, opt, C.byref(v)) == 0 and v.value == default
+    assert lib.bt709hip_decoder_set_option(d, _capi.OPT_HALF_KERNEL, 7) == 0
+    assert lib.bt709hip_decoder_get_option(d, _capi.OPT_HALF_KERNEL, C.byref(v)) == 0 and v.value == 1
+    assert lib.bt709hip_decoder_set_option(d, _capi.OPT_HALF_WORKGROUPS, -5) == 0
+    assert lib.bt709hip_decoder_get_option(d, _capi.OPT_HALF_WORKGROUPS, C.byref(v)) == 0 and v.value == 0
+    assert lib.bt709hip_decoder_set_option(d, _capi.OPT_HALF_LDS_KB, 9999) == 0
+    assert lib.bt709hip_decoder_get_option(d, _capi.OPT_HALF_LDS_KB, C.byref(v)) == 0 and v.value == 160
+    assert lib.bt709hip_decoder_set_option(d, 99, 1) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_decoder_get_option(d, 99, C.byref(v)) == _capi.ERR_INVALID_ARG
+    lib.bt709hip_decoder_destroy(d)
+    assert lib.bt709hip_context_set_option(None, _capi.CTX_OPT_GRID_MULT, 2) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_abi_version() == _capi.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    assert "#define BT709HIP_VERSION %d" % _capi.ABI_VERSION in hdr
+    src = "".join(open(os.path.join(os.path.dirname(mb.__file__), "csrc", f)).read()
+                  for f in os.listdir(os.path.join(os.path.dirname(mb.__file__), "csrc")))
+    assert "getenv" not in src  # no knob is read from the environment, least of all per launch
+
+
 def test_no_device_fails_loudly(lib):
     """No GPU here: nothing silently falls back to a CPU path."""
     import torch  # noqa: F401  (only to learn whether a GPU exists)
@@ -200,7 +257,7 @@ def test_isa_has_no_fused_multiply_add(asm):
         for body in _kernel_bodies(asm, kernel):
             assert not re.search(r"\bv_(pk_)?(fma|fmac|mad|mac)_(f32|legacy_f32|f16)", body), kernel
             n += 1
-    assert n == 13  # every instantiation the launchers can pick
+    assert n == 18  # every instantiation the launchers can pick
 
 
 def test_isa_memory_shape(asm):
@@ -224,15 +281,21 @@ def test_isa_memory_shape(asm):
 def test_isa_valu_budget_contract(asm):
     """The cycle-count decisions of DESIGN 6.0 hold in the generated code: bytes become floats with
     v_cvt_f32_ubyte (not the integer SDWA add + v_cvt_f32_i32 hipcc prefers), bucket indices come
-    from the round-toward-zero magic add (no v_cvt_u32_f32 in the 1:1 kernel), and every switch
-    of the rounding mode is undone inside the same asm statement."""
+    from a plain float add (no v_cvt_u32_f32 in the 1:1 kernel), the decode kernels never touch the
+    MODE register (round-to-nearest bucket index), and in the encoder every switch of the rounding
+    mode is undone inside the same asm statement."""
     quads = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1EE")
     assert len(re.findall(r"\bv_cvt_f32_ubyte[0-3]", quads)) == 24          # 16 luma + 8 chroma bytes per 16 pixels
     assert not re.search(r"\bv_cvt_f32_i32|\bv_cvt_u32_f32|\bv_add_u32_sdwa", quads)
     assert len(re.findall(r"v_add_f32_e64 .* clamp", quads)) == 48            # saturation rides on the adds
     n = 0
     for kernel in ("17decode_nv12_quads", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
-                   "18decode_nv12_scaled", "16encode_bgra_nv12", "23encode_bgra_nv12_blocks"):
+                   "18decode_nv12_scaled"):
+        for body in _kernel_bodies(asm, kernel):
+            assert "s_setreg" not in body, kernel
+            n += 1
+    assert n == 18
+    for kernel in ("16encode_bgra_nv12", "23encode_bgra_nv12_blocks"):
         for body in _kernel_bodies(asm, kernel):
             to_zero = len(re.findall(r"s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 0, 2\), 3", body))
             to_even = len(re.findall(r"s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 0, 2\), 0", body))
@@ -241,8 +304,6 @@ def test_isa_valu_budget_contract(asm):
             for block in re.findall(r"HW_REG_MODE, 0, 2\), 3\n(.*?)s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 0, 2\), 0", body, flags=re.S):
                 ops = {line.split()[0] for line in block.strip().split("\n") if line.strip()}
                 assert ops <= {"v_add_f32", "v_cvt_pk_u8_f32"}, (kernel, ops)
-            n += 1
-    assert n == 15
     rep = _kernel_body(asm, "20decode_nv12_half_repILb1E")
     assert "ds_read_b128" in rep and not re.search(r"\bv_cvt_u32_f32\b.*\n.*v_and_or", rep)
     enc = _kernel_body(asm, "16encode_bgra_nv12E")
@@ -282,12 +343,31 @@ def test_bench_two_ranks_gloo_dry_run():
     assert len(lines) == 1
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
+    assert res["repeats"] >= 5 and res["value_min"] <= res["value"] <= res["value_max"]
     assert res["unit"] == "Gpixel/s" and res["roofline"]["bound"] == "hbm"
     # 2 ranks x 5 steps x 64 x 4K pixels over >= 5 x 2 ms (dry run sleeps 2 ms per step)
     px = 2 * 5 * 64 * 3840 * 2160
     assert res["value"] <= px / (5 * 0.002) / 1e9
     assert abs(res["value"] - px / (res["ms_per_step"] * 5e-3) / 1e9) / res["value"] < 1e-3
     assert "cpu_baseline" not in res
+
+
+def test_bench_two_ranks_gloo_dry_run_batch8():
+    """BASELINE config 5's shape on 2 ranks: a step is 8 frames over the whole job, each rank one
+    launch of 4; strong scaling; the median of >= 5 repeats is reported."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run",
+           "--workload", "4k-batch8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["frames_per_step_per_gpu"] == 4
+    assert res["repeats"] >= 5 and res["value_min"] <= res["value"] <= res["value_max"]
+    px = 5 * 8 * 3840 * 2160  # 5 steps x 8 frames, whatever the rank count
+    assert abs(res["value"] - px / (res["ms_per_step"] * 5e-3) / 1e9) / res["value"] < 1e-3
 
 
 def test_bench_geometry():
@@ -305,6 +385,10 @@ def test_bench_geometry():
     assert g["bytes_per_frame"] == 82_944_000 and (g["OW"], g["OH"]) == (3840, 2160)
     g = bench.geometry("4k", 40, 32)
     assert g["ring"] == 32 and g["launches"] == 1
+    for world, share in ((1, 8), (2, 4), (4, 2), (8, 1)):  # BASELINE config 5: frame i -> GPU i mod n
+        g = bench.geometry("4k-batch8", 0, 65535, 0, world)
+        assert (g["per_launch"], g["launches"], g["frames_per_step"], g["ring"]) == (share, 1, share, 64)
+    assert bench.geometry("4k-batch8", 0, 65535, 0, 1, 2)["per_launch"] == 2  # --share: one GPU plays a rank of a 4-GPU job
 
 
 def build_cpp_selftest(tmpdir):

@@ -10,6 +10,8 @@ CPU only.  The oracle is the checker for the GPU parity tests, so it is pinned f
 """
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -226,3 +228,49 @@ def test_half_scale_definition(oracle):
     y2 = np.tile(np.array([[16, 235], [235, 16]], np.uint8), (4, 4))
     half2 = oracle.decode_nv12_half(GAMMA_APPLE, y2, uv).reshape(4, 4, 4)
     assert (half2[..., :3] == 188).all()
+
+
+# ------------------------------------------------------------------ pass 2 pinned to the reference's own arithmetic
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_pass2_oracle_equals_reference_composed_fixture(oracle, pass2, patterns):
+    """The oracle's fused rescale (2:1 and any ratio, with and without an alpha plane) against
+    tests/golden/pass2.json = outputs of oracle/ref_harness.c's composition of the REFERENCE's
+    inlines (pass 1 bytes, sRGB_nonLinearNormToLinear(byteNorm(b)), the float sum, sRGB_linearNormToNonLinear,
+    (int)round(v*255.0f)).  This is what pins SURVEY 8(a) row 9 to reference-executed arithmetic."""
+    import pass2_cases as pc
+    small = np.load(os.path.join(os.path.dirname(__file__), "golden", "pass2_small.npz"))
+    for kind, gamma, src, dst, seed, with_alpha in pc.CASES:
+        y, c, a = pc.seeded_frame(src, seed, with_alpha)
+        got = (oracle.decode_nv12_half(gamma, y, c, alpha=a) if kind == "half"
+               else oracle.decode_nv12_scaled(gamma, y, c, dst[0], dst[1], alpha=a))
+        key = pc.case_key(kind, gamma, src, dst, seed, with_alpha)
+        assert _sha(got) == pass2["cases"][key], key
+        if key.replace("/", "_") in small:
+            assert np.array_equal(got, small[key.replace("/", "_")]), key
+    assert len(pass2["patterns"]) == 7
+    for tag, rec in pass2["patterns"].items():
+        y, c = patterns[tag + "_y"], patterns[tag + "_uv"]
+        for gamma in range(4):
+            assert _sha(oracle.decode_nv12_half(gamma, y, c)) == rec["half/g%d" % gamma], (tag, gamma)
+            for (ow, oh) in pc.PATTERN_SIZES["scaled"]:
+                assert _sha(oracle.decode_nv12_scaled(gamma, y, c, ow, oh)) == rec["scaled/g%d/%dx%d" % (gamma, ow, oh)]
+
+
+def test_pass2_oracle_equals_reference_live(oracle, reference):
+    """Container only: the same comparison against the reference library itself on fresh frames."""
+    rng = np.random.default_rng(77)
+    for case in range(12):
+        w, h = 4 * int(rng.integers(1, 40)), 4 * int(rng.integers(1, 12))
+        gamma = int(rng.integers(0, 4))
+        y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        c = rng.integers(0, 256, (h // 2, w), dtype=np.uint8)
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8) if case % 3 == 0 else None
+        assert np.array_equal(oracle.decode_nv12_half(gamma, y, c, alpha=a), reference.decode_nv12_half(gamma, y, c, alpha=a))
+        ow, oh = int(rng.integers(1, 2 * w)), int(rng.integers(1, 2 * h))
+        assert np.array_equal(oracle.decode_nv12_scaled(gamma, y, c, ow, oh, alpha=a),
+                              reference.decode_nv12_scaled(gamma, y, c, ow, oh, alpha=a))

@@ -50,13 +50,10 @@ def gh():
     return gpu_helpers
 
 
-def gpu_scaled(gh, y, c, ow, oh, gamma):
-    ctx = gh.context()
-    dec = gh.make_decoder(gamma)
-    buf = gh.make_buffer(y, c, dec.gamma)
-    tex = ctx.makeBGRATexture((ow, oh))
-    assert dec.decodeBT709Scaled(buf, tex, ctx.commandQueue.commandBuffer(), True), dec.lastStatus
-    return ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(oh, ow * 4)
+def gpu_scaled(gh, y, c, ow, oh, gamma, alpha=None):
+    got = gh.gpu_decode_scaled(y, c, (ow, oh), gamma, alpha=alpha)
+    assert got is not None
+    return got
 
 
 @pytest.mark.gpu
@@ -95,7 +92,7 @@ def test_gpu_view_fit_like_the_renderer(gh, oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_scaled_rejects_alpha_decoder_and_bad_tags(gh):
+def test_gpu_scaled_bad_tags_and_missing_alpha(gh):
     ctx = gh.context()
     y, c = _frame(16, 8, 1)
     dec = gh.make_decoder(mb.MetalBT709GammaApple)
@@ -103,13 +100,59 @@ def test_gpu_scaled_rejects_alpha_decoder_and_bad_tags(gh):
     assert not dec.decodeBT709Scaled(srgb_tagged, ctx.makeBGRATexture((5, 3)), None, True)
     assert dec.lastStatus == _capi.ERR_TRANSFER
     da = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
-    assert not da.decodeBT709Scaled(srgb_tagged, ctx.makeBGRATexture((5, 3)), None, True)
-    assert da.lastStatus == _capi.ERR_UNSUPPORTED
+    assert not da.decodeBT709Scaled(srgb_tagged, ctx.makeBGRATexture((5, 3)), None, True)  # an alpha decoder needs its alpha buffer
+    assert da.lastStatus == _capi.ERR_INVALID_ARG
+    rgba16 = ctx.makeBGRATexture((5, 3), pixelFormat=mb.MTLPixelFormatRGBA16Float)
+    assert not dec.decodeBT709Scaled(gh.make_buffer(y, c, dec.gamma), rgba16, None, True)  # pass 2 writes the 8-bit view
+    assert dec.lastStatus == _capi.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [((64, 32), (40, 20)), ((30, 18), (64, 40)), ((1920, 64), (1280, 43)), ((48, 24), (24, 12)),
+                                   ((50, 22), (1, 1))])
+def test_gpu_scaled_with_alpha(gh, oracle, shape):
+    """Alpha clips through the view-fit path: the alpha channel is filtered as a plain unorm with the
+    same taps and weights (AAPLShaders.metal:411-438 -> MetalScaleRenderContext.m:55-105)."""
+    (w, h), (ow, oh) = shape
+    y, c = _frame(w, h, w + ow)
+    a = np.random.default_rng(h + oh).integers(0, 256, (h, w), dtype=np.uint8)
+    got = gpu_scaled(gh, y, c, ow, oh, mb.MetalBT709GammaSRGB, alpha=a)
+    assert np.array_equal(got, oracle.decode_nv12_scaled(mb.MetalBT709GammaSRGB, y, c, ow, oh, alpha=a))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [2, 5, 40])
+def test_gpu_scaled_batch(gh, oracle, count):
+    """bt709hip_decode_scaled_batch: `count` same-geometry frames into same-sized views, one launch
+    (pointer table up to 32 frames, evenly spaced ring beyond)."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    (w, h), (ow, oh) = (96, 40), (61, 27)
+    in_pitch, out_pitch = w * h * 3 // 2, ow * oh * 4
+    slab_in, slab_out = DeviceBuffer(ctx, count * in_pitch), DeviceBuffer(ctx, count * out_pitch)
+    frames = [_frame(w, h, 40 + i) for i in range(count)]
+    bufs, texs = [], []
+    for i, (y, c) in enumerate(frames):
+        base = slab_in.ptr + i * in_pitch
+        b = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h))
+        mb.BGRAToBT709Converter.setBT709Attributes(b)
+        b.upload_planes(y, c)
+        bufs.append(b)
+        texs.append(mb.BGRATexture(ctx, ow, oh, ow * 4, ptr=slab_out.ptr + i * out_pitch))
+    assert dec.decodeBT709ScaledBatch(bufs, texs, ctx.commandQueue.commandBuffer(), True), dec.lastStatus
+    assert ctx.lib.bt709hip_last_kernel_name() == b"decode_nv12_scaled"
+    for (y, c), t in zip(frames, texs):
+        got = ctx.getBGRATexturePixels(t).view(np.uint8).reshape(oh, ow * 4)
+        assert np.array_equal(got, oracle.decode_nv12_scaled(0, y, c, ow, oh))
+    if count > _capi.MAX_BATCH:  # not evenly spaced any more: the pointer-table limit applies
+        bufs[1], bufs[2] = bufs[2], bufs[1]
+        assert not dec.decodeBT709ScaledBatch(bufs, texs, None, True) and dec.lastStatus == _capi.ERR_UNSUPPORTED
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rep", ["0", "1"])
-def test_fuzzed_rescale_geometry(gh, oracle, monkeypatch, rep):
+def test_fuzzed_rescale_geometry(gh, oracle, rep):
     """Seeded fuzz over the rescale entry points: any 4-multiple source size, any plane pitch and
     byte alignment, any output pitch; exact 2:1 through the per-tile kernel (rep=0) or the persistent
     one with a random workgroup count (rep=1), and an arbitrary output size through the bilinear
@@ -118,7 +161,6 @@ def test_fuzzed_rescale_geometry(gh, oracle, monkeypatch, rep):
     ctx = gh.context()
     lib, h = ctx.lib, ctx.handle
     rng = np.random.default_rng(709 + int(rep))
-    monkeypatch.setenv("BT709HIP_HALF_REP", rep)
     for case in range(40):
         w = 4 * int(rng.integers(1, 120))
         hgt = 4 * int(rng.integers(1, 12))
@@ -131,9 +173,12 @@ def test_fuzzed_rescale_geometry(gh, oracle, monkeypatch, rep):
         ow, oh = (w // 2, hgt // 2) if exact else (int(rng.integers(1, 2 * w)), int(rng.integers(1, 3 * hgt)))
         os_ = 4 * ow + (int(rng.integers(0, 3)) * 8 if aligned else 4 * int(rng.integers(0, 9)))
         oo = 0 if aligned else 4 * int(rng.integers(0, 4))
-        monkeypatch.setenv("BT709HIP_REP_WORKGROUPS", str(int(rng.integers(1, 300))))
-        dec = gh.make_decoder(gamma)
+        use_alpha = bool(rng.integers(0, 4) == 0)
+        dec = gh.make_decoder(gamma, has_alpha=use_alpha, options={_capi.OPT_HALF_KERNEL: int(rep),
+                                                                  _capi.OPT_HALF_WORKGROUPS: int(rng.integers(1, 300))})
+        gamma = dec.gamma  # an alpha decoder runs the sRGB mode
         y, c = _frame(w, hgt, 2000 + case)
+        a = rng.integers(0, 256, (hgt, w), dtype=np.uint8) if use_alpha else None
 
         def plane(arr, pitch, off):
             buf = DeviceBuffer(ctx, pitch * arr.shape[0] + off + 64)
@@ -145,17 +190,23 @@ def test_fuzzed_rescale_geometry(gh, oracle, monkeypatch, rep):
         src = mb.CVPixelBuffer(ctx, w, hgt, ys, cs, planes=(py, pc))
         src.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2)
         src.setAttachment("TransferFunction", gh.TRANSFER_FOR_GAMMA[dec.gamma])
+        abuf = None
+        if use_alpha:
+            ba, pa = plane(a, ys, int(rng.integers(0, 16)) if not aligned else 0)
+            abuf = mb.CVPixelBuffer(ctx, w, hgt, ys, cs, planes=(pa, pc))
+            abuf.setAttachment("TransferFunction", mb.kCVImageBufferTransferFunction_Linear)
         out_bytes = os_ * oh + oo + 64
         bo = DeviceBuffer(ctx, out_bytes)
         _capi.check(lib.bt709hip_memset(h, bo.ptr, 0x5A, out_bytes, None))
         ctx._sync(None)
         tex = mb.BGRATexture(ctx, ow, oh, os_, ptr=bo.ptr + oo)
-        assert dec.decodeBT709Scaled(src, tex, None, True), (case, dec.lastStatus)
+        assert dec.decodeBT709Scaled(src, tex, None, True, alphaPixelBuffer=abuf), (case, dec.lastStatus)
         raw = np.empty(out_bytes, np.uint8)
         _capi.check(lib.bt709hip_download(h, raw.ctypes.data, out_bytes, bo.ptr, out_bytes, out_bytes, 1, None))
         ctx._sync(None)
         rows = raw[oo:oo + os_ * oh].reshape(oh, os_)
-        want = oracle.decode_nv12_half(gamma, y, c) if exact else oracle.decode_nv12_scaled(gamma, y, c, ow, oh)
-        info = (case, w, hgt, ow, oh, gamma, exact, ys, cs, os_, oy, oc, oo, lib.bt709hip_last_kernel_name())
+        want = (oracle.decode_nv12_half(gamma, y, c, alpha=a) if exact
+                else oracle.decode_nv12_scaled(gamma, y, c, ow, oh, alpha=a))
+        info = (case, w, hgt, ow, oh, gamma, use_alpha, exact, ys, cs, os_, oy, oc, oo, lib.bt709hip_last_kernel_name())
         assert np.array_equal(rows[:, :4 * ow], want), info
         assert (rows[:, 4 * ow:] == 0x5A).all() and (raw[:oo] == 0x5A).all() and (raw[oo + os_ * oh:] == 0x5A).all(), info

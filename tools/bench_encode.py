@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=0, help="extra untimed steps after the 0.4 s pre-warm")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--threads", type=int, default=0, help="bt709hip_context_option ENCODE_THREADS (0 = from the width)")
+    ap.add_argument("--row-pairs", type=int, default=0, help="bt709hip_context_option ENCODE_ROW_PAIRS (0 = sized per launch)")
     ap.add_argument("--frames-per-launch", type=int, default=1,
                     help="> 1: bt709hip_encode_batch over a ring carved from one allocation")
     args = ap.parse_args()
@@ -36,6 +38,9 @@ def main():
     ctx = mb.MetalRenderContext(0)
     assert ctx.setupMetal()
     lib, h = ctx.lib, ctx.handle
+    from metalbt709decoder_amd import _capi
+    _capi.check(lib.bt709hip_context_set_option(h, _capi.CTX_OPT_ENCODE_THREADS, args.threads))
+    _capi.check(lib.bt709hip_context_set_option(h, _capi.CTX_OPT_ENCODE_ROW_PAIRS, args.row_pairs))
     rng = np.random.default_rng(0x709)
     from metalbt709decoder_amd.decoder import DeviceBuffer
     fpl = max(1, args.frames_per_launch)

@@ -24,11 +24,34 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "bt709_device.h"
 
 namespace bt709 {
 namespace {
+
+struct UnitLookup {
+  float magic;      // M = 2^23 / N
+  uint32_t offset;  // LDS address of the table - (bits(M) << 3)
+};
+
+__device__ __forceinline__ UnitLookup unit_lookup(const DecodeParams &p, const void *lds_table) {
+  UnitLookup u;
+  u.magic = p.unit_magic;
+  u.offset = lds_address(lds_table) - (__float_as_uint(u.magic) << 3);
+  return u;
+}
+
+// byte of the decoder's gamma for saturated x, t = bits(x + M) from magic_floor*
+__device__ __forceinline__ uint32_t bucket_byte(const UnitLookup &u, float x, uint32_t t) {
+#if defined(BT709_LAB_NO_LDS)  // tools/decode_lab only: price of the LDS lookups (wrong output)
+  return (t & 0xffu) + (x >= 0.3f ? 1u : 0u);
+#else
+  const u32x2 e = *reinterpret_cast<LdsPairPtr>((t << 3) + u.offset);  // {edge bits, base}
+  return e.y + (x >= __uint_as_float(e.x) ? 1u : 0u);
+#endif
+}
 
 // One 4x2 quad: 8 pixels x (R, G, B) = 24 lookups.  Pixel p = 0..3 top row, 4..7 bottom row.
 template <bool HAS_ALPHA>
@@ -41,8 +64,8 @@ __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, ui
   for (int px = 0; px < 8; ++px)
     pixel_rgb(byte_of(px < 4 ? ya : yb, px & 3), (px & 2) ? c1 : c0, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
   uint32_t t[24];
-  magic_index12(x, t, u.magic);
-  magic_index12(x + 12, t + 12, u.magic);
+  magic_floor12(x, t, u.magic);
+  magic_floor12(x + 12, t + 12, u.magic);
   uint32_t byte[24];
 #pragma unroll
   for (int i = 0; i < 24; ++i) byte[i] = bucket_byte(u, x[i], t[i]);
@@ -57,7 +80,7 @@ __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, ui
     for (int px = 0; px < 8; ++px) a[px] = alpha_value(byte_of(px < 4 ? aa : ab, px & 3));
 #pragma unroll
     for (int i = 8; i < 12; ++i) a[i] = 0.0f;
-    magic_index12(a, ta, u.magic);
+    magic_floor12(a, ta, u.magic);
 #pragma unroll
     for (int px = 0; px < 8; ++px) al[px] = bucket_byte(u, a[px], ta[px]) << 24;
   }
@@ -80,14 +103,14 @@ __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[
 #pragma unroll
   for (int px = 0; px < 4; ++px) pixel_rgb(y[px], c, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
   uint32_t t[12];
-  magic_index12(x, t, u.magic);
+  magic_floor12(x, t, u.magic);
   uint32_t al[4] = {alpha_word, alpha_word, alpha_word, alpha_word};
   if (HAS_ALPHA) {
     float av[4];
     uint32_t ta[4];
 #pragma unroll
     for (int px = 0; px < 4; ++px) av[px] = alpha_value(a[px]);
-    magic_index4(av, ta, u.magic);
+    magic_floor4(av, ta, u.magic);
 #pragma unroll
     for (int px = 0; px < 4; ++px) al[px] = bucket_byte(u, av[px], ta[px]) << 24;
   }
@@ -120,9 +143,13 @@ decode_nv12_quads(const DecodeParams p) {
   // address arithmetic).
   const uint32_t rp_raw = blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
   const uint32_t rp = min(rp_raw, row_pairs - 1);
-  // quad u of this lane: consecutive lanes own consecutive quads (a store instruction must fill whole
-  // lines: a lane owning ADJACENT quads measured 3x slower, tools/lab_quads_variants.hip)
+#if defined(BT709_LAB_ADJACENT)  // tools/decode_lab only: a lane owns UNROLL ADJACENT quads (8-byte loads, 32-byte store runs)
+  const uint32_t q0 = (blockIdx.x * blockDim.x + threadIdx.x) * UNROLL;
+#define BT709_QUAD_OF(u) (q0 + (u))
+#else
   const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
+#define BT709_QUAD_OF(u) (q0 + (u) * blockDim.x)
+#endif
 
   const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
   const uint8_t *y1 = y0 + p.y_stride;
@@ -138,17 +165,39 @@ decode_nv12_quads(const DecodeParams p) {
   uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
-    const uint32_t q = min((q0 + u * blockDim.x), quads - 1);
+    const uint32_t q = min(BT709_QUAD_OF(u), quads - 1);
     ya[u] = load32<NT>(y0 + 4 * q);
     yb[u] = load32<NT>(y1 + 4 * q);
+#if !defined(BT709_LAB_LDS_CHROMA)
     cw[u] = load32<NT>(cc + 4 * q);
+#endif
     if (HAS_ALPHA) {
       aa[u] = *reinterpret_cast<const uint32_t *>(a0 + 4 * q);
       ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
     }
   }
+#if defined(BT709_LAB_LDS_CHROMA)
+  // tools/decode_lab only: the north-star's "LDS-staged chroma tile" -- the CbCr row segment of
+  // the tile is fetched with 16-byte loads by a quarter of the lanes, parked in LDS behind the
+  // table, and every lane reads its dword(s) back after the barrier.  (Needs quads % 4 == 0.)
+  // Measured 5 % slower than the register-owned form: the lane that loads a CbCr pair is its
+  // only consumer, so the LDS round trip buys nothing.
+  uint32_t *chroma_lds = reinterpret_cast<uint32_t *>(lds_raw + p.table_unit_bytes);
+  {
+    const uint32_t span = blockDim.x * UNROLL;                  // dwords of CbCr this tile needs
+    const uint32_t base = blockIdx.x * span;
+    for (uint32_t i = threadIdx.x; i < span / 4; i += blockDim.x) {
+      const uint32_t qd = min(base + 4 * i, quads - 4);
+      reinterpret_cast<u32x4 *>(chroma_lds)[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(cc + 4 * qd));
+    }
+  }
+#endif
   stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
   __syncthreads();
+#if defined(BT709_LAB_LDS_CHROMA)
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) cw[u] = chroma_lds[threadIdx.x + u * blockDim.x];
+#endif
   // Pin every loaded dword here: hipcc then waits for all of the tile's loads once, before any
   // store is issued, instead of emitting s_waitcnt vmcnt(0) between the first quad's stores and
   // the second quad's arithmetic (which would wait for the stores' write acknowledgements).
@@ -158,10 +207,10 @@ decode_nv12_quads(const DecodeParams p) {
     if (HAS_ALPHA) asm volatile("" : "+v"(aa[u]), "+v"(ab[u]));
   }
 
-  const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
+  const UnitLookup ul = unit_lookup(p, lds_raw);
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
-    const uint32_t q = (q0 + u * blockDim.x);
+    const uint32_t q = BT709_QUAD_OF(u);
     u32x4 top, bot;
     decode_quad<HAS_ALPHA>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
                            bot);
@@ -184,7 +233,7 @@ decode_nv12_blocks(const DecodeParams p) {
   stage_table(lds_raw, p.table_unit, p.table_unit_bytes);
   __syncthreads();
 
-  const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
+  const UnitLookup ul = unit_lookup(p, lds_raw);
   const FramePlanes f = frame_planes(p, blockIdx.y);
   const uint32_t bw = p.width >> 1;
   const uint32_t row_pairs = p.height >> 1;
@@ -222,7 +271,13 @@ decode_nv12_blocks(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
-  const size_t lds = p.table_unit_bytes;
+  size_t lds = p.table_unit_bytes;
+#if defined(BT709_LAB_LDS_CHROMA)
+  lds += 4 * block_threads * kQuadsPerLane;  // + the staged CbCr segment
+#endif
+#if defined(BT709_LAB_LDS_PAD)  // tools/decode_lab only: unused LDS to cap the workgroups resident per CU
+  if (const char *pad = std::getenv("BT709_LAB_LDS_PAD")) lds += static_cast<size_t>(std::atoi(pad)) * 1024;
+#endif
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
     const uint32_t by = quads_rows_per_block(block_threads, grid_x);

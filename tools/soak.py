@@ -8,6 +8,7 @@ import numpy as np
 import gpu_helpers as gh
 from oracle_lib import Oracle
 import metalbt709decoder_amd as mb
+from metalbt709decoder_amd import _capi
 oracle = Oracle()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ctx = gh.context()
@@ -22,9 +23,9 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
         got = gh.gpu_decode(y, c, gamma if a is None else mb.MetalBT709GammaSRGB, alpha=a)
         want = oracle.decode_nv12(gamma if a is None else mb.MetalBT709GammaSRGB, y, c, alpha=a)
     elif kind == 1:
-        os.environ["BT709HIP_HALF_REP"] = str(int(rng.integers(0, 2)))
-        os.environ["BT709HIP_REP_WORKGROUPS"] = str(int(rng.integers(1, 400)))
-        got = gh.gpu_decode_half(y, c, gamma); want = oracle.decode_nv12_half(gamma, y, c)
+        dec = gh.make_decoder(gamma, options={_capi.OPT_HALF_KERNEL: int(rng.integers(0, 2)),
+                                              _capi.OPT_HALF_WORKGROUPS: int(rng.integers(1, 400))})
+        got = gh.gpu_decode_half(y, c, gamma, decoder=dec); want = oracle.decode_nv12_half(gamma, y, c)
     else:
         ow, oh = int(rng.integers(1, 2 * w)), int(rng.integers(1, 2 * h))
         dec = gh.make_decoder(gamma); buf = gh.make_buffer(y, c, dec.gamma); tex = ctx.makeBGRATexture((ow, oh))
