@@ -171,6 +171,92 @@ bool build_transfer_table(int gamma, TransferTable *out) {
   return false;
 }
 
+uint16_t float_to_half(float v) {
+  const uint32_t u = to_bits(v), sign = (u >> 16) & 0x8000u;
+  const uint32_t a = u & 0x7fffffffu;
+  if (a >= 0x7f800000u) return static_cast<uint16_t>(sign | 0x7c00u | ((a > 0x7f800000u) ? 0x200u : 0u));  // inf / nan
+  if (a >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);  // >= 65520 rounds to infinity
+  if (a < 0x33000001u) return static_cast<uint16_t>(sign);             // <= 2^-25 rounds to zero (ties to even)
+  const int exp = static_cast<int>(a >> 23) - 127;
+  uint32_t mant = (a & 0x7fffffu) | 0x800000u;  // 24 bits, hidden one explicit
+  int shift;                                     // bits to drop
+  uint32_t base;
+  if (exp >= -14) {  // normal half
+    shift = 13;
+    base = static_cast<uint32_t>(exp + 15 - 1) << 10;  // exponent field minus the hidden one, which the mantissa adds back
+  } else {           // subnormal half: value = mant * 2^(exp-23), unit 2^-24
+    shift = 13 + (-14 - exp);
+    base = 0;
+  }
+  const uint32_t kept = mant >> shift, rest = mant & ((1u << shift) - 1u), half_ulp = 1u << (shift - 1);
+  uint32_t h = base + kept;
+  if (rest > half_ulp || (rest == half_ulp && (kept & 1u))) ++h;  // nearest, ties to even (carry into the exponent is correct)
+  return static_cast<uint16_t>(sign | h);
+}
+
+float curve_to_linear(int gamma, float v) {
+  switch (gamma) {
+    case kGammaApple: return apple196_to_linear(v);
+    case kGammaSRGB: return srgb_to_linear(v);
+    case kGammaITU709: return itu709_to_linear(v);
+    default: return v;  // kGammaLinear: LinearToLinearSRGBKernel applies no curve (AAPLShaders.metal:387-407)
+  }
+}
+
+bool build_half_table(int gamma, HalfTable *out) {
+  if (gamma < 0 || gamma >= kGammaCount || out == nullptr) return false;
+  const float inf = std::numeric_limits<float>::infinity();
+  out->gamma = gamma;
+  out->pre_add = 0.0f;
+  out->pre_scale = 1.0f;
+  out->exponent = 1.0f;
+  out->low_scale = 1.0f;
+  out->thresholds.clear();
+  switch (gamma) {
+    case kGammaApple:
+      out->split = 0.05583828f;  // x < split (BT709.h:131)
+      out->low_scale = 1.0f / 16.0f;
+      out->exponent = 1.960938f;
+      break;
+    case kGammaSRGB:
+      out->split = std::nextafter(0.04045f, 1.0f);  // x <= 0.04045f takes the linear piece (sRGB.h:45)
+      out->low_scale = 1.0f / 12.92f;
+      out->pre_add = 0.055f;
+      out->pre_scale = 1.0f / (1.0f + 0.055f);
+      out->exponent = 2.4f;
+      break;
+    case kGammaITU709:
+      out->split = 0.081f;  // x < 0.081f (BT709.h:71)
+      out->low_scale = 1.0f / 4.5f;
+      out->pre_add = 0.099f;
+      out->pre_scale = 1.0f / (1.0f + 0.099f);
+      out->exponent = 1.0f / 0.45f;
+      break;
+    default:  // no curve: the hardware conversion alone is exact
+      out->split = 2.0f;
+      out->h_min = 0;
+      out->thresholds.assign(4, inf);
+      return true;
+  }
+  auto H = [gamma](float x) { return static_cast<uint32_t>(float_to_half(curve_to_linear(gamma, x))); };
+  const uint32_t lo_bits = to_bits(out->split), hi_bits = 0x3f800000u;
+  out->h_min = H(out->split);
+  const uint32_t h_max = H(1.0f);
+  out->thresholds.push_back(0.0f);  // T[h_min]: every x of the segment reaches it
+  for (uint32_t h = out->h_min + 1; h <= h_max; ++h) {
+    uint32_t lo = lo_bits, hi = hi_bits;  // H is monotone: bisect on the bit pattern
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (H(from_bits(mid)) >= h) hi = mid;
+      else lo = mid + 1;
+    }
+    out->thresholds.push_back(from_bits(lo));
+  }
+  out->thresholds.push_back(inf);  // T[h_max + 1]
+  while (out->thresholds.size() % 4 != 0) out->thresholds.push_back(inf);
+  return true;
+}
+
 bool build_split_table(int kind, SplitTable *out) {
   if (kind < 0 || kind >= kTableKinds || out == nullptr) return false;
   float thr[255];

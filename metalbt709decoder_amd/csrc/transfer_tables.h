@@ -125,4 +125,29 @@ bool build_split_table(int kind, SplitTable *out);
 // single-threshold-per-bucket property cannot be met with N <= 65536.
 bool build_transfer_table(int gamma, TransferTable *out);
 
+// ---- RGBA16Float render targets (Renderer/AAPLRenderer.m:143-170: where sRGB texture writes are
+// unavailable the reference renders pass 1 into RGBA16Float, i.e. the shader's LINEAR-light float
+// goes to the texture as an IEEE binary16, round to nearest even).  Per channel that is
+//     H(x) = half(curve_to_linear(x))        curve = Apple 1.961 / sRGB / none / ITU (BT709.h:68-137, sRGB.h:43-57)
+// a monotone step function of the saturated x with up to 15 360 steps: too many for a bucket table
+// that must sit in LDS beside resident workgroups.  Below the curve's split point the reference
+// multiplies by an exact constant and the hardware conversion gives H directly; above it the
+// kernel takes a CANDIDATE h0 from a fast exp2(g log2 x) (good to ~2^-20, so h0 is H or a
+// neighbour) and settles it against the two thresholds next to it:
+//     H = h0 + (x >= T[h0 + 1]) - (x < T[h0]),   T[h] = smallest float x with H(x) >= h
+// T is indexed by the OUTPUT code, so it holds exactly one entry per step (8-9 k entries, ~34 KiB).
+struct HalfTable {
+  int gamma = 0;
+  float split = 0.0f;      // x < split: H(x) = half(x * low_scale) (exact product); kGammaLinear: split = 2 (always)
+  float low_scale = 1.0f;  // 1/16, 1/12.92f, 1, 1/4.5f (float constants of the reference)
+  // candidate: base = (x + pre_add) * pre_scale; h0 = half(exp2(exponent * log2(base)))
+  float pre_add = 0.0f, pre_scale = 1.0f, exponent = 1.0f;
+  uint32_t h_min = 0;      // H(split): first code the table covers
+  // T[i] = smallest x >= split with H(x) >= h_min + i; T[0] = 0; one +inf entry past H(1.0); padded to 16 bytes
+  std::vector<float> thresholds;
+};
+uint16_t float_to_half(float v);               // IEEE binary32 -> binary16, round to nearest even
+float curve_to_linear(int gamma, float v);     // the per-gamma video curve alone (what pass 1 writes to a float target)
+bool build_half_table(int gamma, HalfTable *out);
+
 }  // namespace bt709
