@@ -285,6 +285,19 @@ int bt709hip_decode_scaled_batch(bt709hip_decoder *dec, int count, const bt709hi
                                  const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
                                  int wait_until_completed);
 
+/* Pass 2 on its own: -[MetalScaleRenderContext renderScaled:...] (MetalScaleRenderContext.h:34-40,
+ * .m:55-105) + samplingShader (AAPLShaders.metal:73-85).  `in` is the intermediate pass 1 rendered
+ * -- BGRA8_SRGB (each tap linearised as the sRGB8 sampler does) or RGBA16F (taps are linear light
+ * already) -- `out` a BGRA8_SRGB surface of any size.  Bilinear, texel-centre sampling, clamp to edge,
+ * weights and summation order as bt709hip_decode_scaled, so decode + render_scaled through a BGRA8
+ * intermediate equals the fused call bit for bit.  The alpha channel is filtered as a plain unorm. */
+int bt709hip_render_scaled(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_surface *out,
+                           void *stream, int wait_until_completed);
+/* The tables of bt709hip_render_scaled (and of RGBA16F decodes: bt709hip_decoder_prepare_format) are
+ * built on first use; call these before bt709hip_graph_begin_capture.  Idempotent. */
+int bt709hip_render_scaled_prepare(bt709hip_context *ctx);
+int bt709hip_decoder_prepare_format(bt709hip_decoder *dec, int format);
+
 /* --------------------------------------------------------------- frame pool */
 /* Frames that live in HOST memory.  The reference hands the decoder CVPixelBuffers the GPU reads
  * in place (unified memory) and keeps MaxBuffersInFlight = 3 frames in flight behind a semaphore
@@ -368,6 +381,14 @@ int bt709hip_gamma_thresholds(int gamma, float thresholds[255]);
  * optionally the bucket count N and the bucket index.  Returns the byte, or <0 on a bad argument. */
 int bt709hip_gamma_lookup(int gamma, float x, int *bucket_count, int *bucket_index);
 int bt709hip_matrix_constants(float constants[8]);
+/* RGBA16F targets: the threshold table of the half-float composite H(x) = half(curve_to_linear(x))
+ * (host memory out).  thresholds: up to `capacity` floats, T[i] = smallest x with H(x) >= first_code + i;
+ * returns the number of entries the table has (0: the gamma has no curve), or <0. */
+int bt709hip_half_thresholds(int gamma, float *thresholds, int capacity);
+/* The kernels' settlement of one saturated x replayed on the host: the candidate is the exact code
+ * H(x) moved by candidate_offset (-1, 0, +1: what a fast exp2/log2 may land on), then corrected against
+ * the two thresholds around it.  Returns the half code; *table_entries (optional) as above. */
+int bt709hip_half_lookup(int gamma, float x, int candidate_offset, int *table_entries);
 /* Name of the kernel the last decode on this thread launched (for profiling). */
 const char *bt709hip_last_kernel_name(void);
 

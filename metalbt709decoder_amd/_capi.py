@@ -115,6 +115,9 @@ SYMBOLS = {
     "bt709hip_decode_half_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
     "bt709hip_decode_scaled": (_I, [_P, _FP, _FP, _SP, _P, _I]),
     "bt709hip_decode_scaled_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
+    "bt709hip_render_scaled": (_I, [_P, _SP, _SP, _P, _I]),
+    "bt709hip_render_scaled_prepare": (_I, [_P]),
+    "bt709hip_decoder_prepare_format": (_I, [_P, _I]),
     "bt709hip_encoder_prepare": (_I, [_P, _I, _I]),
     "bt709hip_encode": (_I, [_P, _SP, _FP, _I, _I, _P, _I]),
     "bt709hip_encode_batch": (_I, [_P, _I, _SP, _FP, _I, _I, _P, _I]),
@@ -127,6 +130,8 @@ SYMBOLS = {
     "bt709hip_gamma_thresholds": (_I, [_I, C.POINTER(C.c_float)]),
     "bt709hip_gamma_lookup": (_I, [_I, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bt709hip_matrix_constants": (_I, [C.POINTER(C.c_float)]),
+    "bt709hip_half_thresholds": (_I, [_I, C.POINTER(C.c_float), _I]),
+    "bt709hip_half_lookup": (_I, [_I, C.c_float, _I, C.POINTER(C.c_int)]),
     "bt709hip_last_kernel_name": (C.c_char_p, []),
 }
 

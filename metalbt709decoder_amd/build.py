@@ -17,9 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbt709hip.so")
 ASM = os.path.join(HERE, "build", "bt709_kernels.s")  # decode + rescale + encode kernels, concatenated
-SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_encode.hip", "bt709_planes.hip", "bt709hip.cpp",
+SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_rgba16f.hip", "bt709_encode.hip", "bt709_planes.hip", "bt709hip.cpp",
            "transfer_tables.cpp"]
-KERNEL_SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_encode.hip"]
+KERNEL_SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_rgba16f.hip", "bt709_encode.hip"]
 HEADERS = ["bt709_kernels.h", "bt709_device.h", "bt709_constants.h", "transfer_tables.h"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: hipcc otherwise pairs scalar f32 multiplies/adds into v_pk_* ops, which run

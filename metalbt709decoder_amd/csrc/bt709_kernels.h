@@ -77,6 +77,38 @@ struct DecodeParams {
   uint32_t cursor_tx, cursor_rp, cursor_f;
 };
 
+// Pass 1 into an RGBA16Float target (bt709_rgba16f.hip): the threshold table of transfer_tables.h
+// HalfTable and the constants of the candidate.  Travels beside DecodeParams (frames, pitches).
+struct HalfParams {
+  const void *table;     // float T[]: T[i] = smallest x with H(x) >= h_min + i; nullptr: no curve (LINEAR)
+  uint32_t table_bytes;  // 0 without a table
+  uint32_t h_min, h_max; // codes the table covers
+  float split, low_scale, pre_add, pre_scale, exponent;
+  uint32_t row_pairs_per_block;  // filled by the launcher
+  uint32_t wide_store;           // 16-byte stores (target 16-byte aligned), else 8-byte
+};
+const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp, int frames, bool has_alpha,
+                                  uint32_t in_align, uint32_t out_align, uint32_t compute_units, hipStream_t stream);
+hipError_t prepare_rgba16f_kernels();  // bt709_rgba16f.hip
+
+// Pass 2 alone (bt709_rescale.hip render_scaled): an intermediate surface -> a BGRA8 sRGB surface of any size.
+struct RenderParams {
+  const uint8_t *in;   // BGRA8 sRGB words or RGBA16Float texels
+  uint8_t *out;        // BGRA8 sRGB
+  uint32_t in_stride, out_stride;
+  uint32_t width, height, out_width, out_height;
+  float scale_x, scale_y;
+  uint32_t rows;       // output rows a workgroup walks (filled by the launcher)
+  // tables (device): two-resolution sRGB-encode buckets, the sRGB-mode byte table (round(255 v): the alpha
+  // quantiser) and lin[256] = sRGB_nonLinearNormToLinear(byteNorm(b))
+  const void *table_encode, *table_unit, *table_lin;
+  uint32_t table_encode_bytes, table_unit_bytes;
+  float encode_scale;  // n_fine of table_encode
+  uint32_t encode_offset, encode_shift;
+  float unit_magic;    // 2^23 / N of table_unit
+};
+const char *launch_render_scaled(const RenderParams &p, bool in_rgba16f, uint32_t compute_units, hipStream_t stream);
+
 // BGRA -> NV12 encoder (bt709_encode.hip).  One frame per launch.
 struct EncodeFrame {
   const uint8_t *bgra;  // W x H words (A<<24)|(R<<16)|(G<<8)|B, alpha ignored

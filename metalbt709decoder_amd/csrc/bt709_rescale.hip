@@ -540,6 +540,110 @@ decode_nv12_scaled(const DecodeParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Pass 2 ALONE: -[MetalScaleRenderContext renderScaled:...] + samplingShader
+// (Renderer/MetalScaleRenderContext.m:55-105, AAPLShaders.metal:73-85) for a caller that keeps the
+// reference's two passes, or whose pass 1 rendered into RGBA16Float.  Same sampling geometry,
+// weights and summation order as decode_nv12_scaled, so pass 1 into a BGRA8 intermediate followed by
+// this kernel equals the fused kernel bit for bit.  One lane per output column walking `rows` rows.
+//   IN_RGBA16F = false: a tap is a BGRA8 word; rgb linearised through lin[256] (the sRGB8 sampler's
+//                decode), alpha a plain unorm (byte * (1/255f))
+//   IN_RGBA16F = true:  a tap is four halves, linear light already (v_cvt_f32_f16)
+// The sum is saturated (a unorm render target clamps), rgb goes through the sRGB-encode table,
+// alpha through the round(255 v) table.
+// ---------------------------------------------------------------------------
+template <bool IN_RGBA16F>
+__global__ void __launch_bounds__(kBlockThreads)
+render_scaled(const RenderParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  {  // stage: encode buckets | byte table | lin[256]
+    const uint32_t tid = threadIdx.x, n = blockDim.x;
+    u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
+    const u32x4 *e = reinterpret_cast<const u32x4 *>(p.table_encode), *u = reinterpret_cast<const u32x4 *>(p.table_unit);
+    const u32x4 *l = reinterpret_cast<const u32x4 *>(p.table_lin);
+    const uint32_t ne = p.table_encode_bytes / 16, nu = p.table_unit_bytes / 16;
+    for (uint32_t i = tid; i < ne; i += n) d[i] = e[i];
+    for (uint32_t i = tid; i < nu; i += n) d[ne + i] = u[i];
+    for (uint32_t i = tid; i < 64; i += n) d[ne + nu + i] = l[i];
+  }
+  __syncthreads();
+  RescaleLookup r = {};
+  r.enc_shift = 3;
+  r.enc_off = lds_address(lds_raw);
+  r.split_offset = p.encode_offset;
+  r.split_shift = p.encode_shift;
+  const UnitLookup unit = unit_lookup(p.unit_magic, lds_raw + p.table_encode_bytes);
+  const uint32_t lin_off = lds_address(lds_raw + p.table_encode_bytes + p.table_unit_bytes);
+  typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
+
+  const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ox >= p.out_width) return;
+  const float sx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ox), 0.5f), p.scale_x), -0.5f);
+  const float x0f = __builtin_floorf(sx);
+  const float fx = __fadd_rn(sx, -x0f), gx = __fadd_rn(1.0f, -fx);
+  const int wmax = static_cast<int>(p.width) - 1, hmax = static_cast<int>(p.height) - 1;
+  const int xi = static_cast<int>(x0f);
+  const uint32_t xs[2] = {static_cast<uint32_t>(min(max(xi, 0), wmax)), static_cast<uint32_t>(min(max(xi + 1, 0), wmax))};
+  constexpr uint32_t kTexel = IN_RGBA16F ? 8u : 4u;
+
+  const uint32_t oy0 = blockIdx.y * p.rows, oy1 = min(oy0 + p.rows, p.out_height);
+  for (uint32_t oy = oy0; oy < oy1; ++oy) {
+    const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy), 0.5f), p.scale_y), -0.5f);
+    const float y0f = __builtin_floorf(sy);
+    const float fy = __fadd_rn(sy, -y0f), gy = __fadd_rn(1.0f, -fy);
+    const int yi = static_cast<int>(y0f);
+    const uint32_t ys[2] = {static_cast<uint32_t>(min(max(yi, 0), hmax)), static_cast<uint32_t>(min(max(yi + 1, 0), hmax))};
+    const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // R, G, B, A
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint8_t *px = p.in + static_cast<size_t>(ys[t >> 1]) * p.in_stride + static_cast<size_t>(xs[t & 1]) * kTexel;
+      float s[4];
+      if (IN_RGBA16F) {
+        const u32x2 v = *reinterpret_cast<const u32x2 *>(px);
+        s[0] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v.x & 0xffffu)));
+        s[1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v.x >> 16)));
+        s[2] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v.y & 0xffffu)));
+        s[3] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v.y >> 16)));
+      } else {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(px);
+        s[0] = *reinterpret_cast<LdsFloatPtr>(((v >> 14) & 0x3fcu) + lin_off);  // R: byte 2
+        s[1] = *reinterpret_cast<LdsFloatPtr>(((v >> 6) & 0x3fcu) + lin_off);   // G: byte 1
+        s[2] = *reinterpret_cast<LdsFloatPtr>(((v << 2) & 0x3fcu) + lin_off);   // B: byte 0
+        s[3] = __fmul_rn(byte_of(v, 3), kInv255);                                // byteNorm
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float term = __fmul_rn(w[t], s[k]);
+        acc[k] = t ? __fadd_rn(acc[k], term) : term;
+      }
+    }
+    const uint32_t R = encode_byte(r, __fmul_rn(add_sat(acc[0], 0.0f), p.encode_scale));
+    const uint32_t G = encode_byte(r, __fmul_rn(add_sat(acc[1], 0.0f), p.encode_scale));
+    const uint32_t B = encode_byte(r, __fmul_rn(add_sat(acc[2], 0.0f), p.encode_scale));
+    const float av = add_sat(acc[3], 0.0f);
+    const float ax[4] = {av, 0.f, 0.f, 0.f};
+    uint32_t at[4];
+    magic_index4(ax, at, unit.magic);
+    const uint32_t A = bucket_byte(unit, av, at[0]) << 24;
+    reinterpret_cast<uint32_t *>(p.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, A);
+  }
+}
+
+const char *launch_render_scaled(const RenderParams &p_in, bool in_rgba16f, uint32_t compute_units, hipStream_t stream) {
+  RenderParams p = p_in;
+  const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
+  const uint64_t want = 8ull * (compute_units ? compute_units : 256u);
+  uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height / want);
+  rows = rows < 1 ? 1 : (rows > 32 ? 32 : rows);
+  p.rows = rows;
+  const dim3 grid(cols, (p.out_height + rows - 1) / rows, 1);
+  const size_t lds = static_cast<size_t>(p.table_encode_bytes) + p.table_unit_bytes + 1024;
+  if (in_rgba16f) hipLaunchKernelGGL(render_scaled<true>, grid, dim3(kBlockThreads), lds, stream, p);
+  else hipLaunchKernelGGL(render_scaled<false>, grid, dim3(kBlockThreads), lds, stream, p);
+  return in_rgba16f ? "render_scaled<rgba16f>" : "render_scaled<bgra8>";
+}
+
+// ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
 #ifndef BT709_REP_STEP
@@ -646,6 +750,8 @@ hipError_t prepare_rescale_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_BYTES, true>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_PAIRS, true>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_WIDE, true>),
+      reinterpret_cast<const void *>(&render_scaled<true>),
+      reinterpret_cast<const void *>(&render_scaled<false>),
   };
   for (const void *fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

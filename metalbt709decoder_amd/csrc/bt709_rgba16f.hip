@@ -1,0 +1,180 @@
+// CDNA4 (gfx950) kernel of pass 1 into an RGBA16Float render target.
+//
+// Where sRGB texture writes are unavailable the reference renders BT709ToLinearSRGBKernel & siblings
+// into an RGBA16Float intermediate (Renderer/AAPLRenderer.m:143-170): the shader's LINEAR-light
+// float4 is stored as four IEEE binary16 values, R,G,B,A, 8 bytes per pixel -- "about 2x slower
+// for IO bound shader" (:157).  Per channel that is
+//       H(x) = half(curve_to_linear(x)),   x = the saturated non-linear value of bt709_device.h
+// with the reference's double-precision pow inside the curve.  No GPU pow is bit-identical to libm's, so:
+//   * below the curve's split point the reference multiplies by a constant: one exact float multiply
+//     and the hardware conversion (v_cvt_f16_f32, round to nearest even) give H directly;
+//   * above it, exp2(g * log2(base)) from v_log_f32 / v_exp_f32 is good to ~2^-20 -- far finer than a
+//     half's 2^-11 spacing -- so its half h0 is H or a neighbour, and the two thresholds around h0
+//     settle it exactly:  H = h0 + (x >= T[h0 + 1]) - (x < T[h0])   (transfer_tables.h HalfTable).
+// T is indexed by the OUTPUT code: one entry per step of H, 24-34 KiB in LDS, staged once per
+// workgroup; a workgroup therefore walks several row pairs (the 8-bit kernel's 4 KiB table allows
+// one short-lived workgroup per row pair, this one's does not).
+//
+// Memory plan (HBM-bound: 1.5 B read + 8 B written per pixel): a lane owns a 2x2 block -- two
+// 16-byte stores, one per output row, consecutive lanes writing consecutive 16 bytes (a store
+// instruction must fill whole lines) -- and reads its 4 luma bytes and one CbCr pair with 2-byte
+// loads where the layout allows.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bt709_device.h"
+
+namespace bt709 {
+namespace {
+
+struct HalfLookup {
+  float split, low_scale, pre_add, pre_scale, exponent;
+  uint32_t h_min, h_max;
+  uint32_t table_off;  // LDS address of T - 4 * h_min
+};
+
+__device__ __forceinline__ uint32_t half_bits(float v) {
+  const _Float16 h = static_cast<_Float16>(v);  // v_cvt_f16_f32, round to nearest even
+  return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h));
+}
+
+// H(x) for a saturated x in [0, 1]
+template <bool HAS_TABLE>
+__device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
+  // The product is rounded to binary32 first, THEN to binary16, as on the CPU: the empty asm keeps hipcc
+  // from fusing multiply and conversion into v_fma_mixlo_f16 (one rounding instead of two).
+  float lowv = __fmul_rn(x, t.low_scale);  // exact below the split for 1/16; x itself when there is no curve
+  asm("" : "+v"(lowv));
+  const uint32_t low = half_bits(lowv);
+  if (!HAS_TABLE) return low;
+  float xb;  // max(x, split): keeps the candidate inside the table whatever x is
+  asm("v_max_f32 %0, %1, %2" : "=v"(xb) : "v"(x), "s"(t.split));
+  const float base = __fmul_rn(__fadd_rn(xb, t.pre_add), t.pre_scale);
+  const float p = __builtin_amdgcn_exp2f(__fmul_rn(t.exponent, __builtin_amdgcn_logf(base)));  // v_log_f32 is log2
+  const uint32_t h0 = min(max(half_bits(p), t.h_min), t.h_max);
+  typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
+  const LdsFloatPtr e = reinterpret_cast<LdsFloatPtr>((h0 << 2) + t.table_off);
+  const uint32_t h = h0 + (xb >= e[1] ? 1u : 0u) - (xb < e[0] ? 1u : 0u);
+  return x < t.split ? low : h;
+}
+
+}  // namespace
+
+// grid = (tiles of blockDim 2x2 blocks, groups of row_pairs_per_block row pairs, frames)
+template <bool HAS_TABLE, bool HAS_ALPHA, bool PAIRS>
+__global__ void __launch_bounds__(kMaxBlockThreads)
+decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  if (HAS_TABLE) stage_table(lds_raw, hp.table, hp.table_bytes);
+  __syncthreads();
+  HalfLookup t;
+  t.split = hp.split;
+  t.low_scale = hp.low_scale;
+  t.pre_add = hp.pre_add;
+  t.pre_scale = hp.pre_scale;
+  t.exponent = hp.exponent;
+  t.h_min = hp.h_min;
+  t.h_max = hp.h_max;
+  t.table_off = lds_address(lds_raw) - (hp.h_min << 2);
+
+  const FramePlanes f = frame_planes(p, blockIdx.z);
+  const uint32_t blocks = p.width >> 1, row_pairs = p.height >> 1;
+  const uint32_t bx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bx >= blocks) return;
+  const uint32_t rp0 = blockIdx.y * hp.row_pairs_per_block, rp1 = min(rp0 + hp.row_pairs_per_block, row_pairs);
+  const uint32_t opaque = 0x3c00u << 16;  // A = 1.0
+
+  for (uint32_t rp = rp0; rp < rp1; ++rp) {
+    const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride + 2 * bx;
+    const uint8_t *y1 = y0 + p.y_stride;
+    const uint8_t *cc = f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride + 2 * bx;
+    float yv[4], cb, cr, av[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PAIRS) {
+      const uint32_t a = *reinterpret_cast<const uint16_t *>(y0), b = *reinterpret_cast<const uint16_t *>(y1);
+      const uint32_t c = *reinterpret_cast<const uint16_t *>(cc);
+      yv[0] = byte_of(a, 0), yv[1] = byte_of(a, 1), yv[2] = byte_of(b, 0), yv[3] = byte_of(b, 1);
+      cb = byte_of(c, 0), cr = byte_of(c, 1);
+    } else {
+      yv[0] = byte_value(y0[0]), yv[1] = byte_value(y0[1]), yv[2] = byte_value(y1[0]), yv[3] = byte_value(y1[1]);
+      cb = byte_value(cc[0]), cr = byte_value(cc[1]);
+    }
+    if (HAS_ALPHA) {
+      const uint8_t *a0 = f.alpha + static_cast<size_t>(2 * rp) * p.alpha_stride + 2 * bx;
+      const uint8_t *a1 = a0 + p.alpha_stride;
+      av[0] = byte_value(a0[0]), av[1] = byte_value(a0[1]), av[2] = byte_value(a1[0]), av[3] = byte_value(a1[1]);
+    }
+    const Chroma c = chroma_terms(cb, cr);
+    uint32_t w[8];  // per pixel {R | G << 16, B | A << 16}
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float r, g, b;
+      pixel_rgb(yv[px], c, r, g, b);
+      const uint32_t hr = half_code<HAS_TABLE>(t, r), hg = half_code<HAS_TABLE>(t, g), hb = half_code<HAS_TABLE>(t, b);
+      const uint32_t ha = HAS_ALPHA ? (half_bits(alpha_value(av[px])) << 16) : opaque;  // linear alpha, unquantised
+      w[2 * px] = hr | (hg << 16);
+      w[2 * px + 1] = hb | ha;
+    }
+    uint8_t *o0 = f.out + static_cast<size_t>(2 * rp) * p.out_stride + 16 * bx;
+    uint8_t *o1 = o0 + p.out_stride;
+    if (hp.wide_store) {
+      store16<true>(o0, u32x4{w[0], w[1], w[2], w[3]});
+      store16<true>(o1, u32x4{w[4], w[5], w[6], w[7]});
+    } else {  // 8-byte aligned target
+      store8<true>(o0, u32x2{w[0], w[1]});
+      store8<true>(o0 + 8, u32x2{w[2], w[3]});
+      store8<true>(o1, u32x2{w[4], w[5]});
+      store8<true>(o1 + 8, u32x2{w[6], w[7]});
+    }
+  }
+}
+
+const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp_in, int frames, bool has_alpha,
+                                  uint32_t in_align, uint32_t out_align, uint32_t compute_units, hipStream_t stream) {
+  HalfParams hp = hp_in;
+  const uint32_t blocks = p.width / 2, row_pairs = p.height / 2;
+  uint32_t threads = (blocks + 63) / 64 * 64;
+  if (threads > static_cast<uint32_t>(kMaxBlockThreads)) threads = kMaxBlockThreads;
+  const uint32_t tiles = (blocks + threads - 1) / threads;
+  // row pairs per workgroup: as many (<= 16) as still leave ~4 workgroups per CU; table staging is per workgroup
+  const uint64_t want = 4ull * (compute_units ? compute_units : 256u);
+  uint32_t rpb = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * row_pairs * static_cast<uint32_t>(frames) / want);
+  rpb = rpb < 1 ? 1 : (rpb > 16 ? 16 : rpb);
+  hp.row_pairs_per_block = rpb;
+  hp.wide_store = out_align >= 16 ? 1 : 0;
+  const dim3 grid(tiles, (row_pairs + rpb - 1) / rpb, static_cast<uint32_t>(frames));
+  const dim3 block(threads);
+  const bool table = hp.table_bytes != 0, pairs = in_align >= 2;
+  const size_t lds = table ? hp.table_bytes : 16;
+#define BT709_LAUNCH_RGBA16F(T, A, P) hipLaunchKernelGGL((decode_nv12_rgba16f<T, A, P>), grid, block, lds, stream, p, hp)
+  if (table) {
+    if (has_alpha) { if (pairs) BT709_LAUNCH_RGBA16F(true, true, true); else BT709_LAUNCH_RGBA16F(true, true, false); }
+    else { if (pairs) BT709_LAUNCH_RGBA16F(true, false, true); else BT709_LAUNCH_RGBA16F(true, false, false); }
+  } else {
+    if (has_alpha) { if (pairs) BT709_LAUNCH_RGBA16F(false, true, true); else BT709_LAUNCH_RGBA16F(false, true, false); }
+    else { if (pairs) BT709_LAUNCH_RGBA16F(false, false, true); else BT709_LAUNCH_RGBA16F(false, false, false); }
+  }
+#undef BT709_LAUNCH_RGBA16F
+  return has_alpha ? "decode_nv12_rgba16f<alpha>" : "decode_nv12_rgba16f";
+}
+
+hipError_t prepare_rgba16f_kernels() {
+  const int cap = 160 * 1024;
+  const void *fns[] = {
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<true, true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<true, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<true, false, true>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<true, false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<false, true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<false, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<false, false, true>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<false, false, false>),
+  };
+  for (const void *fn : fns) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+}  // namespace bt709

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <vector>
 #include <mutex>
 #include <new>
@@ -40,6 +41,10 @@ struct bt709hip_context {
   int encode_row_pairs = 0, encode_threads = 0;  // BT709HIP_CTX_OPT_ENCODE_*: 0 = sized per launch
   std::mutex encoder_mutex;
   EncoderTables encoders[3][3];  // [input gamma][output gamma], built on first use
+  // bt709hip_render_scaled (pass 2 alone): built on first use under encoder_mutex
+  void *d_render_encode = nullptr, *d_render_unit = nullptr, *d_render_lin = nullptr;
+  uint32_t render_encode_bytes = 0, render_unit_bytes = 0, render_encode_n = 0, render_encode_offset = 0,
+           render_encode_shift = 0, render_unit_n = 0;
 };
 
 struct bt709hip_decoder {
@@ -64,6 +69,10 @@ struct bt709hip_decoder {
   uint32_t encode_bytes = 0;
   uint32_t encode_n = 0;
   uint32_t encode_offset = 0, encode_shift = 0;
+  // RGBA16F targets: threshold table of the half-float composite (transfer_tables.h HalfTable), built on
+  // first use under setup_mutex; half.table_bytes == 0 with half_ready: the gamma has no curve
+  bool half_ready = false;
+  HalfParams half = {};
 };
 
 struct bt709hip_pool {
@@ -182,6 +191,35 @@ int ensure_setup(bt709hip_decoder *dec, void *stream) {
   return bt709hip_decoder_setup(dec);
 }
 
+// Threshold table of the RGBA16F composite, built on the first decode into such a target (or by
+// bt709hip_decoder_prepare_format; not while recording a graph).
+int ensure_half_table(bt709hip_decoder *dec, void *stream) {
+  std::lock_guard<std::mutex> lock(dec->setup_mutex);
+  if (dec->half_ready) return BT709HIP_OK;
+  if (capturing(static_cast<hipStream_t>(stream))) return BT709HIP_ERR_NOT_SETUP;
+  HalfTable t;
+  if (!build_half_table(dec->gamma, &t)) return BT709HIP_ERR_UNSUPPORTED;
+  HalfParams hp = {};
+  hp.split = t.split;
+  hp.low_scale = t.low_scale;
+  hp.pre_add = t.pre_add;
+  hp.pre_scale = t.pre_scale;
+  hp.exponent = t.exponent;
+  hp.h_min = t.h_min;
+  if (t.split <= 1.0f) {  // a curve: the table covers [h_min, H(1.0)]; its last real entry is followed by +inf
+    size_t real = t.thresholds.size();
+    while (real > 0 && t.thresholds[real - 1] == std::numeric_limits<float>::infinity()) --real;
+    hp.h_max = t.h_min + static_cast<uint32_t>(real) - 1;
+    hp.table_bytes = static_cast<uint32_t>(t.thresholds.size() * sizeof(float));
+    void *d = nullptr;
+    if (int rc = upload_table(t.thresholds.data(), hp.table_bytes, &d)) return rc;
+    hp.table = d;
+  }
+  dec->half = hp;
+  dec->half_ready = true;
+  return BT709HIP_OK;
+}
+
 // Table pointers and lookup constants of a launch.
 void set_tables(DecodeParams *p, const bt709hip_decoder *dec) {
   p->table_unit = dec->d_table_unit;
@@ -290,6 +328,7 @@ int bt709hip_context_create(int device_ordinal, bt709hip_context **out) {
   if (e == hipSuccess) e = prepare_kernels();
   if (e == hipSuccess) e = prepare_rescale_kernels();
   if (e == hipSuccess) e = prepare_encode_kernels();
+  if (e == hipSuccess) e = prepare_rgba16f_kernels();
   if (e != hipSuccess) {
     delete ctx;
     return hip_fail(e);
@@ -331,6 +370,9 @@ int bt709hip_context_destroy(bt709hip_context *ctx) {
         if (t.d_per_byte) (void)hipFree(t.d_per_byte);
         if (t.d_from_linear) (void)hipFree(t.d_from_linear);
       }
+    if (ctx->d_render_encode) (void)hipFree(ctx->d_render_encode);
+    if (ctx->d_render_unit) (void)hipFree(ctx->d_render_unit);
+    if (ctx->d_render_lin) (void)hipFree(ctx->d_render_lin);
   }
   delete ctx;
   return BT709HIP_OK;
@@ -532,6 +574,7 @@ int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
     if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
     if (dec->d_table_alpha) (void)hipFree(dec->d_table_alpha);
     if (dec->d_encode) (void)hipFree(dec->d_encode);
+    if (dec->half.table) (void)hipFree(const_cast<void *>(dec->half.table));
   }
   delete dec;
   return BT709HIP_OK;
@@ -718,6 +761,12 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
   if (int rc = gather_batch(dec, count, frames, alphas, outs, OutShape::kSame, stream, &p, &info)) return rc;
   if (p.width == 0) return BT709HIP_OK;
   hipStream_t s = pick(dec->ctx, stream);
+  if (info.format == BT709HIP_FORMAT_RGBA16F) {  // the reference's pre-10.14 intermediate: linear-light halves
+    if (int rc = ensure_half_table(dec, stream)) return rc;
+    tl_kernel_name = launch_decode_rgba16f(p, dec->half, count, dec->has_alpha != 0, info.in_align, info.out_align,
+                                           static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), s);
+    return finish_launch(s, wait_until_completed);
+  }
   // Fast path: one short-lived workgroup per tile of a row pair, dispatched in address order
   // (see the kernel file's header).  General path keeps the grid-strided shape.
   const bool fast = (p.width % 4) == 0 && info.in_align >= 4 && info.out_align >= 16;
@@ -793,6 +842,104 @@ int bt709hip_decode_scaled(bt709hip_decoder *dec, const bt709hip_frame *frame, c
                            const bt709hip_surface *out, void *stream, int wait_until_completed) {
   if (frame == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
   return bt709hip_decode_scaled_batch(dec, 1, frame, alpha, out, stream, wait_until_completed);
+}
+
+int bt709hip_decoder_prepare_format(bt709hip_decoder *dec, int format) {
+  if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bt709hip_decoder_setup(dec)) return rc;
+  if (format == BT709HIP_FORMAT_BGRA8_SRGB) return BT709HIP_OK;
+  if (format != BT709HIP_FORMAT_RGBA16F) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(dec->ctx)) return rc;
+  return ensure_half_table(dec, nullptr);
+}
+
+namespace {
+
+// Tables of the stand-alone pass 2, built once per context: the two-resolution sRGB-encode buckets
+// (as a decoder's), the sRGB-mode byte table (round(255 v): quantises the filtered alpha) and
+// lin[256] = sRGB_nonLinearNormToLinear(byteNorm(b)) (the sRGB8 sampler's decode).
+int render_tables(bt709hip_context *ctx, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(ctx->encoder_mutex);
+  if (ctx->d_render_lin != nullptr) return BT709HIP_OK;
+  if (capturing(s)) return BT709HIP_ERR_NOT_SETUP;
+  SplitTable enc;
+  TransferTable unit;
+  if (!build_split_table(kGammaLinear, &enc) || !build_transfer_table(kGammaSRGB, &unit)) return BT709HIP_ERR_UNSUPPORTED;
+  float lin[256];
+  for (int b = 0; b < 256; ++b) lin[b] = srgb_to_linear(b * (1.0f / 255.0f));
+  void *d_enc = nullptr, *d_unit = nullptr, *d_lin = nullptr;
+  const uint32_t enc_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
+  const uint32_t unit_bytes = static_cast<uint32_t>(unit.buckets_unit.size() * sizeof(TransferBucket));
+  int rc = upload_table(enc.buckets.data(), enc_bytes, &d_enc);
+  if (rc == BT709HIP_OK) rc = upload_table(unit.buckets_unit.data(), unit_bytes, &d_unit);
+  if (rc == BT709HIP_OK) rc = upload_table(lin, sizeof lin, &d_lin);
+  if (rc != BT709HIP_OK) {
+    if (d_enc) (void)hipFree(d_enc);
+    if (d_unit) (void)hipFree(d_unit);
+    return rc;
+  }
+  ctx->render_encode_bytes = enc_bytes;
+  ctx->render_unit_bytes = unit_bytes;
+  ctx->render_encode_n = enc.n_fine;
+  ctx->render_encode_offset = enc.coarse_offset;
+  ctx->render_encode_shift = 0;
+  for (float r = enc.coarse_scale; r < 1.0f; r *= 2.0f) ++ctx->render_encode_shift;
+  ctx->render_unit_n = unit.n;
+  ctx->d_render_encode = d_enc;
+  ctx->d_render_unit = d_unit;
+  ctx->d_render_lin = d_lin;  // the "built" marker: last
+  return BT709HIP_OK;
+}
+
+}  // namespace
+
+int bt709hip_render_scaled_prepare(bt709hip_context *ctx) {
+  if (int rc = bind(ctx)) return rc;
+  return render_tables(ctx, nullptr);
+}
+
+int bt709hip_render_scaled(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_surface *out, void *stream,
+                           int wait_until_completed) {
+  if (ctx == nullptr || in == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (in->width < 0 || in->height < 0 || out->width < 0 || out->height < 0 || in->reserved != 0 || out->reserved != 0)
+    return BT709HIP_ERR_INVALID_ARG;
+  if (in->format != BT709HIP_FORMAT_BGRA8_SRGB && in->format != BT709HIP_FORMAT_RGBA16F) return BT709HIP_ERR_INVALID_ARG;
+  if (out->format != BT709HIP_FORMAT_BGRA8_SRGB) return BT709HIP_ERR_UNSUPPORTED;  // the view is an 8-bit sRGB drawable
+  if (in->width == 0 || in->height == 0 || out->width == 0 || out->height == 0) return BT709HIP_OK;
+  if (in->bgra == nullptr || out->bgra == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  const size_t ipx = in->format == BT709HIP_FORMAT_RGBA16F ? 8 : 4;
+  if (in->stride < static_cast<size_t>(in->width) * ipx || (in->stride & (ipx - 1)) || !aligned(in->bgra, ipx) ||
+      out->stride < static_cast<size_t>(out->width) * 4 || (out->stride & 3) || !aligned(out->bgra, 4) ||
+      in->stride > 0xffffffffu || out->stride > 0xffffffffu)
+    return BT709HIP_ERR_STRIDE;
+  if (out->height > kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;
+  if (int rc = bind(ctx)) return rc;
+  hipStream_t s = pick(ctx, stream);
+  if (int rc = render_tables(ctx, s)) return rc;
+  RenderParams p;
+  std::memset(&p, 0, sizeof p);
+  p.in = static_cast<const uint8_t *>(in->bgra);
+  p.out = static_cast<uint8_t *>(out->bgra);
+  p.in_stride = static_cast<uint32_t>(in->stride);
+  p.out_stride = static_cast<uint32_t>(out->stride);
+  p.width = static_cast<uint32_t>(in->width);
+  p.height = static_cast<uint32_t>(in->height);
+  p.out_width = static_cast<uint32_t>(out->width);
+  p.out_height = static_cast<uint32_t>(out->height);
+  p.scale_x = static_cast<float>(in->width) / static_cast<float>(out->width);
+  p.scale_y = static_cast<float>(in->height) / static_cast<float>(out->height);
+  p.table_encode = ctx->d_render_encode;
+  p.table_unit = ctx->d_render_unit;
+  p.table_lin = ctx->d_render_lin;
+  p.table_encode_bytes = ctx->render_encode_bytes;
+  p.table_unit_bytes = ctx->render_unit_bytes;
+  p.encode_scale = static_cast<float>(ctx->render_encode_n);
+  p.encode_offset = ctx->render_encode_offset;
+  p.encode_shift = ctx->render_encode_shift;
+  p.unit_magic = 8388608.0f / static_cast<float>(ctx->render_unit_n);
+  tl_kernel_name = launch_render_scaled(p, in->format == BT709HIP_FORMAT_RGBA16F,
+                                        static_cast<uint32_t>(ctx->props.multiProcessorCount), s);
+  return finish_launch(s, wait_until_completed);
 }
 
 // ------------------------------------------------------------------ frame pool
@@ -1117,6 +1264,46 @@ int bt709hip_gamma_lookup(int gamma, float x, int *bucket_count, int *bucket_ind
   if (bucket_index_out) *bucket_index_out = static_cast<int>(q);
   const TransferBucket &b = t.buckets_unit[q];
   return static_cast<int>(b.base + (x >= b.edge ? 1u : 0u));
+}
+
+namespace {
+const HalfTable *host_half_table(int gamma) {
+  static std::mutex mutex;
+  static HalfTable tables[kGammaCount];
+  static bool built[kGammaCount] = {false, false, false, false};
+  if (gamma < 0 || gamma >= kGammaCount) return nullptr;
+  std::lock_guard<std::mutex> lock(mutex);
+  if (!built[gamma]) {
+    if (!build_half_table(gamma, &tables[gamma])) return nullptr;
+    built[gamma] = true;
+  }
+  return &tables[gamma];
+}
+}  // namespace
+
+int bt709hip_half_thresholds(int gamma, float *thresholds, int capacity) {
+  const HalfTable *t = host_half_table(gamma);
+  if (t == nullptr || capacity < 0 || (thresholds == nullptr && capacity > 0)) return BT709HIP_ERR_INVALID_ARG;
+  if (t->split > 1.0f) return 0;
+  const int n = static_cast<int>(t->thresholds.size());
+  for (int i = 0; i < n && i < capacity; ++i) thresholds[i] = t->thresholds[static_cast<size_t>(i)];
+  return n;
+}
+
+int bt709hip_half_lookup(int gamma, float x, int candidate_offset, int *table_entries) {
+  const HalfTable *t = host_half_table(gamma);
+  if (t == nullptr || !(x >= 0.0f && x <= 1.0f) || candidate_offset < -1 || candidate_offset > 1)
+    return BT709HIP_ERR_INVALID_ARG;
+  if (table_entries) *table_entries = t->split > 1.0f ? 0 : static_cast<int>(t->thresholds.size());
+  const int low = float_to_half(x * t->low_scale);
+  if (t->split > 1.0f || x < t->split) return low;
+  size_t real = t->thresholds.size();
+  while (real > 0 && t->thresholds[real - 1] == std::numeric_limits<float>::infinity()) --real;
+  const int h_min = static_cast<int>(t->h_min), h_max = h_min + static_cast<int>(real) - 1;
+  int h0 = static_cast<int>(float_to_half(curve_to_linear(gamma, x))) + candidate_offset;
+  h0 = h0 < h_min ? h_min : (h0 > h_max ? h_max : h0);
+  const float *e = &t->thresholds[static_cast<size_t>(h0 - h_min)];
+  return h0 + (x >= e[1] ? 1 : 0) - (x < e[0] ? 1 : 0);
 }
 
 int bt709hip_matrix_constants(float c[8]) {

@@ -296,7 +296,7 @@ class MetalRenderContext:
         return tex
 
     def fillBGRATexture(self, tex, pixels):
-        a = np.ascontiguousarray(pixels).view(np.uint8).reshape(tex.height, tex.width * 4)
+        a = np.ascontiguousarray(pixels).view(np.uint8).reshape(tex.height, tex.width * tex.bytesPerPixel)
         self._upload(tex.ptr, tex.stride, a, None)
         self._sync(None)
 
@@ -330,6 +330,39 @@ class MetalRenderContext:
     def _sync(self, commandBuffer):
         stream = commandBuffer.stream if commandBuffer else None
         _capi.check(self.lib.bt709hip_stream_synchronize(self.handle, stream), "stream sync")
+
+
+class MetalScaleRenderContext:
+    """Pass 2 on its own (Renderer/MetalScaleRenderContext.h:17-40): rescale an intermediate texture
+    into a view.  The view's drawable is a BGRATexture here (there is no MTKView)."""
+
+    def __init__(self):
+        self.fragmentFunction = "samplingShader"  # AAPLShaders.metal:73-85, the only one the reference binds
+        self.pipelineState = None
+        self.lastStatus = _capi.OK
+
+    def setupRenderPipelines(self, mrc, mtkView=None):
+        """-setupRenderPipelines:mtkView: (MetalScaleRenderContext.m:31-51): builds the pass's tables."""
+        self.lastStatus = mrc.lib.bt709hip_render_scaled_prepare(mrc.handle)
+        self.pipelineState = self.lastStatus == _capi.OK
+        return self.pipelineState
+
+    def renderScaled(self, mrc, mtkView, renderWidth, renderHeight, commandBuffer=None, renderPassDescriptor=None,
+                     bgraTexture=None, waitUntilCompleted=False):
+        """-renderScaled:mtkView:renderWidth:renderHeight:commandBuffer:renderPassDescriptor:bgraTexture:
+        (MetalScaleRenderContext.h:34-40).  mtkView: the BGRATexture standing for the view's drawable;
+        renderWidth x renderHeight must be its size (the reference sets the viewport to it, .m:80);
+        bgraTexture: the intermediate pass 1 rendered (BGRA8 sRGB or RGBA16Float)."""
+        if mtkView is None or bgraTexture is None or (renderWidth, renderHeight) != (mtkView.width, mtkView.height):
+            self.lastStatus = _capi.ERR_SIZE_MISMATCH if mtkView is not None and bgraTexture is not None else _capi.ERR_INVALID_ARG
+            return False
+        src, dst = bgraTexture.surface(), mtkView.surface()
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        self.lastStatus = mrc.lib.bt709hip_render_scaled(mrc.handle, C.byref(src), C.byref(dst), stream,
+                                                         int(bool(waitUntilCompleted)))
+        if self.lastStatus != _capi.OK:
+            log.error("renderScaled: %s", _capi.strerror(self.lastStatus))
+        return self.lastStatus == _capi.OK
 
 
 class BGRAToBT709Converter:

@@ -349,6 +349,109 @@ int bt709o_decode_nv12_scaled(int gamma,
   return 0;
 }
 
+/* ---- RGBA16Float render targets and the stand-alone pass 2 ------------------------------- */
+
+/* IEEE binary32 -> binary16, round to nearest even, by exact integer arithmetic on the value:
+ * the nearest multiple of the target's unit in the last place, ties to the even one. */
+uint16_t bt709o_float_to_half(float v) {
+  if (v != v) return 0x7e00;
+  const uint16_t sign = signbit(v) ? 0x8000u : 0u;
+  const double a = fabs((double)v);
+  if (a >= 65520.0) return (uint16_t)(sign | 0x7c00u); /* halfway to 2^16 and beyond rounds to infinity */
+  int e;
+  (void)frexp(a, &e);                 /* a = m * 2^e, m in [0.5, 1) */
+  int ulp_exp = (e - 1) - 10;         /* unit of a normal half with that exponent */
+  if (ulp_exp < -24) ulp_exp = -24;   /* subnormal halves share the unit 2^-24 */
+  const double q = nearbyint(ldexp(a, -ulp_exp)); /* default rounding mode: nearest, ties to even */
+  const double r = ldexp(q, ulp_exp);             /* the rounded value, exact */
+  if (r == 0.0) return sign;
+  int re;
+  const double rm = frexp(r, &re);    /* r may have carried into the next binade */
+  if (re - 1 < -14) return (uint16_t)(sign | (uint16_t)ldexp(r, 24)); /* subnormal: r / 2^-24 */
+  return (uint16_t)(sign | ((uint16_t)(re - 1 + 15) << 10) | ((uint16_t)ldexp(rm, 11) & 0x3ffu));
+}
+
+float bt709o_half_to_float(uint16_t h) {
+  const int e = (h >> 10) & 0x1f, m = h & 0x3ff;
+  double v;
+  if (e == 0) v = ldexp((double)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else v = ldexp((double)(m | 0x400), e - 25);
+  return (float)((h & 0x8000) ? -v : v);
+}
+
+float bt709o_curve_to_linear(int gamma, float v) {
+  switch (gamma) {
+    case BT709O_GAMMA_APPLE: return bt709o_apple196_to_linear(v);  /* BT709ToLinearSRGBKernel, AAPLShaders.metal:336-357 */
+    case BT709O_GAMMA_SRGB: return bt709o_srgb_to_linear(v);       /* sRGBToLinearSRGBKernel, :361-382 */
+    case BT709O_GAMMA_ITU709: return bt709o_itu709_to_linear(v);
+    default: return v;                                             /* LinearToLinearSRGBKernel, :387-407 */
+  }
+}
+
+int bt709o_decode_nv12_rgba16f(int gamma, const uint8_t *y, size_t y_stride, const uint8_t *uv, size_t uv_stride,
+                               const uint8_t *alpha, size_t alpha_stride, int width, int height, uint8_t *rgba,
+                               size_t rgba_stride) {
+  if ((width & 1) || (height & 1)) return -1;
+  for (int row = 0; row < height; row++) {
+    uint16_t *o = (uint16_t *)(rgba + (size_t)row * rgba_stride);
+    for (int col = 0; col < width; col++) {
+      const uint8_t *c = uv + (size_t)(row / 2) * uv_stride + 2 * (col / 2);
+      float n[3], a = 1.0f;
+      bt709o_ycbcr_to_rgbn(y[(size_t)row * y_stride + col], c[0], c[1], n);
+      if (alpha) { /* BT709_decodeAlpha: the luma term alone, saturated; linear */
+        float an[3];
+        bt709o_ycbcr_to_rgbn(alpha[(size_t)row * alpha_stride + col], 128, 128, an);
+        a = an[0];
+      }
+      for (int k = 0; k < 3; k++) o[4 * col + k] = bt709o_float_to_half(bt709o_curve_to_linear(gamma, n[k]));
+      o[4 * col + 3] = bt709o_float_to_half(a);
+    }
+  }
+  return 0;
+}
+
+int bt709o_render_scaled(int in_format, const uint8_t *in, size_t in_stride, int width, int height, uint8_t *bgra,
+                         size_t bgra_stride, int out_width, int out_height) {
+  if (width <= 0 || height <= 0 || out_width <= 0 || out_height <= 0 || (in_format != 0 && in_format != 1)) return -1;
+  float lin[256];
+  for (int b = 0; b < 256; b++) lin[b] = bt709o_srgb_to_linear(byte_norm(b));
+  const float scale_x = (float)width / (float)out_width;
+  const float scale_y = (float)height / (float)out_height;
+  for (int oy = 0; oy < out_height; oy++) {
+    const float sy = ((float)oy + 0.5f) * scale_y - 0.5f;
+    const float y0f = floorf(sy), fy = sy - y0f, gy = 1.0f - fy;
+    int ys[2] = {(int)y0f, (int)y0f + 1};
+    for (int i = 0; i < 2; i++) ys[i] = ys[i] < 0 ? 0 : (ys[i] > height - 1 ? height - 1 : ys[i]);
+    uint8_t *out = bgra + (size_t)oy * bgra_stride;
+    for (int ox = 0; ox < out_width; ox++) {
+      const float sx = ((float)ox + 0.5f) * scale_x - 0.5f;
+      const float x0f = floorf(sx), fx = sx - x0f, gx = 1.0f - fx;
+      int xs[2] = {(int)x0f, (int)x0f + 1};
+      for (int i = 0; i < 2; i++) xs[i] = xs[i] < 0 ? 0 : (xs[i] > width - 1 ? width - 1 : xs[i]);
+      const float w[4] = {gx * gy, fx * gy, gx * fy, fx * fy};
+      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}; /* R, G, B, A */
+      for (int t = 0; t < 4; t++) {
+        const uint8_t *px = in + (size_t)ys[t >> 1] * in_stride + (size_t)xs[t & 1] * (in_format ? 8 : 4);
+        float s[4];
+        if (in_format == 0) { /* BGRA8 sRGB texel: rgb decoded by the sampler, alpha a plain unorm */
+          s[0] = lin[px[2]], s[1] = lin[px[1]], s[2] = lin[px[0]], s[3] = byte_norm(px[3]);
+        } else {              /* RGBA16Float texel: linear light already */
+          const uint16_t *h = (const uint16_t *)px;
+          for (int k = 0; k < 4; k++) s[k] = bt709o_half_to_float(h[k]);
+        }
+        for (int k = 0; k < 4; k++) {
+          const float term = w[t] * s[k];
+          acc[k] = t ? acc[k] + term : term;
+        }
+      }
+      for (int k = 0; k < 3; k++) out[4 * ox + 2 - k] = (uint8_t)bt709o_quantize(bt709o_linear_to_srgb(clamp01(acc[k])));
+      out[4 * ox + 3] = (uint8_t)bt709o_quantize(clamp01(acc[3]));
+    }
+  }
+  return 0;
+}
+
 int bt709o_unconvert_packed(int gamma, const uint32_t *ycbcr, uint32_t *bgra,
                             int width, int height) {
   if ((width & 1) || (height & 1)) return -1;

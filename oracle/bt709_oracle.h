@@ -161,6 +161,26 @@ int bt709o_decode_nv12_scaled(int gamma,
                               uint8_t *bgra, size_t bgra_stride,
                               int out_width, int out_height, int alpha_fill);
 
+/* ---- RGBA16Float render targets (Renderer/AAPLRenderer.m:143-170: the intermediate the reference
+ * falls back to where sRGB texture writes are unavailable) and the stand-alone pass 2.
+ * PARITY: the reference has no CPU twin of either; the definition below is the shader's arithmetic
+ * with BT709.h's CPU constants and transfer functions, pinned through oracle/ref_harness.c. */
+uint16_t bt709o_float_to_half(float v); /* IEEE binary32 -> binary16, round to nearest even (a float4 stored to RGBA16Float) */
+float bt709o_half_to_float(uint16_t h);
+float bt709o_curve_to_linear(int gamma, float v); /* what BT709ToLinearSRGBKernel & siblings apply before the store */
+/* Pass 1 into an RGBA16Float target: per pixel R,G,B = half(curve_to_linear(saturated non-linear
+ * value)), A = half(linear alpha) or 1.0; 8 bytes per pixel, memory order R,G,B,A. */
+int bt709o_decode_nv12_rgba16f(int gamma, const uint8_t *y, size_t y_stride, const uint8_t *uv, size_t uv_stride,
+                               const uint8_t *alpha, size_t alpha_stride, int width, int height, uint8_t *rgba,
+                               size_t rgba_stride);
+/* Pass 2 alone (MetalScaleRenderContext.m:55-105 + samplingShader, AAPLShaders.metal:73-85):
+ * in_format 0 = BGRA8 sRGB intermediate (taps linearised like the sRGB8 sampler, alpha a plain unorm),
+ * 1 = RGBA16Float (taps already linear); out = BGRA8 sRGB of any size.  Sampling geometry, weights and
+ * summation order as bt709o_decode_nv12_scaled; the sum is saturated before the store as a unorm
+ * render target does. */
+int bt709o_render_scaled(int in_format, const uint8_t *in, size_t in_stride, int width, int height, uint8_t *bgra,
+                         size_t bgra_stride, int out_width, int out_height);
+
 /* unconvertSoftware (BGRAToBT709Converter.m:146-198): packed
  * (Cr<<16)|(Cb<<8)|Y words -> (R<<16)|(G<<8)|B words, alpha byte 0. */
 int bt709o_unconvert_packed(int gamma, const uint32_t *ycbcr, uint32_t *bgra,

@@ -270,3 +270,50 @@ void ref_decode_nv12_scaled(int gamma, const uint8_t *y, size_t y_stride, const 
     }
   }
 }
+
+/* ---- RGBA16Float intermediate (Renderer/AAPLRenderer.m:143-170) ---------------------------------
+ * Pass 1 writes the shader's linear-light float4 into an RGBA16Float texture.  Composition: the
+ * reference's CPU matrix step (BT709_convertYCbCrToNonLinearRGB) and its own curve functions, then
+ * the store's float -> half conversion (round to nearest even; C has no portable binary16 type, so
+ * the conversion is spelled with exact double arithmetic). */
+static uint16_t ref_float_to_half(float v) {
+  const double a = fabs((double)v);
+  const uint16_t sign = signbit(v) ? 0x8000u : 0u;
+  if (a >= 65520.0) return (uint16_t)(sign | 0x7c00u);
+  int e;
+  (void)frexp(a, &e);
+  int ue = e - 11;
+  if (ue < -24) ue = -24;
+  const double r = ldexp(nearbyint(ldexp(a, -ue)), ue);
+  if (r == 0.0) return sign;
+  int re;
+  const double rm = frexp(r, &re);
+  if (re - 1 < -14) return (uint16_t)(sign | (uint16_t)ldexp(r, 24));
+  return (uint16_t)(sign | ((uint16_t)(re + 14) << 10) | ((uint16_t)ldexp(rm, 11) & 0x3ffu));
+}
+
+static float ref_curve_to_linear(int gamma, float v) {
+  if (gamma == 0) return Apple196_nonLinearNormToLinear(v);
+  if (gamma == 1) return sRGB_nonLinearNormToLinear(v);
+  if (gamma == 3) return BT709_nonLinearNormToLinear(v);
+  return v;
+}
+
+/* index (Y<<16)+(Cb<<8)+Cr, three halves R,G,B per entry; rows [y0,y1) of Y */
+void ref_rgba16f_table(int gamma, uint16_t *table, int y0, int y1) {
+  for (int Y = y0; Y < y1; Y++)
+    for (int Cb = 0; Cb < 256; Cb++)
+      for (int Cr = 0; Cr < 256; Cr++) {
+        float n[3];
+        BT709_convertYCbCrToNonLinearRGB(Y, Cb, Cr, &n[0], &n[1], &n[2]);
+        const size_t i = ((size_t)Y << 16) + ((size_t)Cb << 8) + (size_t)Cr;
+        for (int k = 0; k < 3; k++) table[3 * i + k] = ref_float_to_half(ref_curve_to_linear(gamma, n[k]));
+      }
+}
+
+/* linear alpha sample as a half: BT709_decodeAlpha's CPU analogue (R of (A,128,128)), stored unquantised */
+int ref_alpha_half(int A) {
+  float Rn, Gn, Bn;
+  BT709_convertYCbCrToNonLinearRGB(A, 128, 128, &Rn, &Gn, &Bn);
+  return ref_float_to_half(Rn);
+}

@@ -275,6 +275,13 @@ def collect_pass2(ref, pattern_arrays):
                     ref.decode_nv12_scaled(gamma, y, c, ow, oh).tobytes()).hexdigest()
         out["patterns"][tag] = rec
         print("pass2", tag, flush=True)
+    # pass 1 into an RGBA16Float target: every (Y,Cb,Cr) -> three half codes, from the reference's matrix
+    # step and curve functions (ref_rgba16f_table), index (Y<<16)+(Cb<<8)+Cr, little-endian uint16 R,G,B
+    out["rgba16f_table_sha256"] = {}
+    for g, n in ((0, "apple"), (1, "srgb"), (2, "linear"), (3, "itu709")):
+        out["rgba16f_table_sha256"][n] = hashlib.sha256(ref.half_table(g).tobytes()).hexdigest()
+        print("rgba16f table", n, out["rgba16f_table_sha256"][n], flush=True)
+    out["alpha_half_map"] = [ref.alpha_half(a) for a in range(256)]
     return out, stored
 
 

@@ -165,6 +165,54 @@ class Oracle:
                 _ptr(out, _u8p), out.shape[1], out_width, out_height, alpha_fill)
         return out if rc == 0 else None
 
+    def decode_nv12_rgba16f(self, gamma, y, uv, alpha=None):
+        """-> (H, W, 4) float16 R,G,B,A: pass 1 into an RGBA16Float target."""
+        y, width = _plane(y)
+        uv, _ = _plane(uv)
+        a = _plane(alpha)[0] if alpha is not None else None
+        height = y.shape[0]
+        out = np.zeros((height, width * 8), dtype=np.uint8)
+        fn = self.lib.bt709o_decode_nv12_rgba16f
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_int, _u8p, C.c_size_t, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t]
+        rc = fn(gamma, _ptr(y, _u8p), y.shape[1], _ptr(uv, _u8p), uv.shape[1],
+                _ptr(a, _u8p) if a is not None else None, a.shape[1] if a is not None else 0, width, height,
+                _ptr(out, _u8p), out.shape[1])
+        return out.view(np.float16).reshape(height, width, 4) if rc == 0 else None
+
+    def render_scaled(self, src, out_width, out_height):
+        """Pass 2 alone.  src: (H, W*4) uint8 BGRA8 sRGB rows, or (H, W, 4) float16 RGBA linear."""
+        rgba16f = src.dtype == np.float16
+        src = np.ascontiguousarray(src)
+        height = src.shape[0]
+        width = src.shape[1] if rgba16f else src.shape[1] // 4
+        raw = src.view(np.uint8).reshape(height, -1)
+        out = np.zeros((out_height, out_width * 4), dtype=np.uint8)
+        fn = self.lib.bt709o_render_scaled
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_int, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t, C.c_int, C.c_int]
+        rc = fn(int(rgba16f), _ptr(raw, _u8p), raw.shape[1], width, height, _ptr(out, _u8p), out.shape[1], out_width, out_height)
+        return out if rc == 0 else None
+
+    def half_table(self, gamma, nthreads=8):
+        """(2^24, 3) uint16: R,G,B half codes of every (Y,Cb,Cr), index (Y<<16)+(Cb<<8)+Cr."""
+        cb, cr = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+        c = np.empty((256, 512), np.uint8)
+        c[:, 0::2], c[:, 1::2] = cb, cr  # one chroma row per Cb, Cr running along it
+        out = np.empty((256, 65536, 3), np.uint16)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(Y):
+            # a 512 x 512 frame: block (Cb, Cr), all four luma samples = Y
+            y = np.full((512, 512), Y, np.uint8)
+            cc = np.repeat(c.reshape(256, 256, 2), 1, axis=0).reshape(256, 512)
+            px = self.decode_nv12_rgba16f(gamma, y, cc).view(np.uint16)[::2, ::2, :3]
+            out[Y] = px.reshape(65536, 3)
+
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(one, range(256)))
+        return out.reshape(-1, 3)
+
     def unconvert_packed(self, gamma, ycbcr, width, height):
         ycbcr = np.ascontiguousarray(ycbcr, dtype=np.uint32)
         out = np.zeros(width * height, dtype=np.uint32)
@@ -310,6 +358,21 @@ class Reference:
            _ptr(a, _u8p) if a is not None else None, a.shape[1] if a is not None else 0, width, height,
            _ptr(out, _u8p), out.shape[1], out_width, out_height, alpha_fill)
         return out
+
+    def half_table(self, gamma, y0=0, y1=256):
+        """(2^24, 3) uint16 half codes from the reference's own matrix and curve functions."""
+        t = np.zeros(((1 << 24), 3), dtype=np.uint16)
+        fn = self.lib.ref_rgba16f_table
+        fn.restype = None
+        fn.argtypes = [C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(8) as ex:
+            list(ex.map(lambda r: fn(gamma, t.ctypes.data_as(C.POINTER(C.c_uint16)), r, min(r + 16, y1)), range(y0, y1, 16)))
+        return t
+
+    def alpha_half(self, A):
+        self.lib.ref_alpha_half.restype = C.c_int
+        return self.lib.ref_alpha_half(int(A))
 
     def decode_pixel(self, gamma, Y, Cb, Cr):
         out = (C.c_int * 3)()

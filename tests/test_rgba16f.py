@@ -1,0 +1,211 @@
+"""RGBA16Float render targets and the stand-alone pass 2.
+
+The reference renders pass 1 into RGBA16Float where sRGB texture writes are unavailable
+(Renderer/AAPLRenderer.m:143-170) and always runs pass 2 as its own render pass
+(Renderer/MetalScaleRenderContext.m:55-105).  Neither has a CPU twin or a test in the reference;
+the pin is tests/golden/pass2.json: half codes of all 2^24 (Y,Cb,Cr) computed from the reference's own
+matrix step and curve functions (oracle/ref_harness.c), and the fused-rescale goldens the two-pass
+route must reproduce."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import metalbt709decoder_amd as mb
+from metalbt709decoder_amd import _capi
+from oracle_lib import GAMMA_NAMES
+
+GAMMAS = [0, 1, 2, 3]
+
+
+def _frame(w, h, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (h // 2, w), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ CPU: oracle vs the reference-composed pin
+
+@pytest.mark.parametrize("gamma", GAMMAS)
+def test_oracle_half_table_equals_reference_composed_hash(oracle, pass2, gamma):
+    table = oracle.half_table(gamma)
+    assert hashlib.sha256(table.tobytes()).hexdigest() == pass2["rgba16f_table_sha256"][GAMMA_NAMES[gamma]]
+
+
+def test_oracle_alpha_half_and_layout(oracle, pass2):
+    y, c = _frame(64, 8, 1)
+    a = np.arange(256, dtype=np.uint8).repeat(2).reshape(8, 64)
+    out = oracle.decode_nv12_rgba16f(1, y, c, alpha=a)
+    assert out.shape == (8, 64, 4) and out.dtype == np.float16
+    assert [int(v) for v in out.view(np.uint16)[..., 3].reshape(-1)[::2]] == pass2["alpha_half_map"]
+    opaque = oracle.decode_nv12_rgba16f(1, y, c)
+    assert (opaque[..., 3] == np.float16(1.0)).all() and np.array_equal(opaque[..., :3], out[..., :3])
+    # no curve: the half of the saturated non-linear value itself
+    lin = oracle.decode_nv12_rgba16f(2, y, c)
+    n = oracle.ycbcr_to_rgbn(int(y[3, 5]), int(c[1, 4]), int(c[1, 5]))
+    assert np.array_equal(lin[3, 5, :3], n.astype(np.float16))
+
+
+def test_oracle_two_passes_equal_the_fused_definition(oracle):
+    """decode to 8-bit sRGB, then pass 2 alone == the fused decode+rescale the goldens pin."""
+    for gamma, (w, h), (ow, oh) in [(0, (64, 32), (40, 20)), (1, (30, 18), (64, 40)), (3, (48, 24), (24, 12)), (2, (50, 22), (1, 1))]:
+        y, c = _frame(w, h, w + ow)
+        a = np.random.default_rng(h).integers(0, 256, (h, w), dtype=np.uint8) if gamma == 1 else None
+        inter = oracle.decode_nv12(gamma, y, c, alpha=a)
+        assert np.array_equal(oracle.render_scaled(inter, ow, oh), oracle.decode_nv12_scaled(gamma, y, c, ow, oh, alpha=a))
+
+
+def test_oracle_render_scaled_from_rgba16f(oracle):
+    """A float intermediate skips the 8-bit quantisation between the passes: flat fields survive
+    exactly, and the result stays within one code of the 8-bit route on random content."""
+    flat = np.zeros((6, 10, 4), np.float16)
+    flat[...] = [0.25, 0.5, 1.0, 0.5]
+    out = oracle.render_scaled(flat, 7, 4).reshape(-1, 4)
+    assert (out == [255, 188, 137, 128]).all()  # B, G, R = sRGB(1.0, 0.5, 0.25), A = round(127.5)
+    y, c = _frame(64, 32, 5)
+    via16 = oracle.render_scaled(oracle.decode_nv12_rgba16f(0, y, c), 40, 20)
+    via8 = oracle.decode_nv12_scaled(0, y, c, 40, 20)
+    assert np.abs(via16.astype(int) - via8.astype(int)).max() <= 1
+
+
+def test_half_lookup_correction_step(pass2):
+    """The kernel's exactness argument, replayed on the host from the product's own table: whatever
+    neighbour of H(x) the fast candidate lands on, the two thresholds around it give H(x) back --
+    checked next to every threshold, for candidates H-1, H and H+1."""
+    import ctypes as C
+    lib = mb.load_library()
+    fn = lib.bt709hip_half_lookup
+    for gamma in GAMMAS:
+        n = C.c_int()
+        assert fn(gamma, 0.5, 0, C.byref(n)) >= 0
+        if gamma == 2:
+            assert n.value == 0  # no curve, no table
+            assert fn(gamma, 0.5, 0, None) == 0x3800
+            continue
+        assert 5000 < n.value < 9000
+        thr = (C.c_float * n.value)()
+        assert lib.bt709hip_half_thresholds(gamma, thr, n.value) == n.value
+        bits = np.array(list(thr), np.float32)
+        bits = bits[np.isfinite(bits) & (bits > 0)].view(np.uint32)
+        for b in bits[:: max(1, len(bits) // 400)]:
+            for d in (-1, 0, 1):
+                x = float(np.array([int(b) + d], np.uint32).view(np.float32)[0])
+                want = fn(gamma, x, 0, None)
+                assert fn(gamma, x, -1, None) == want and fn(gamma, x, 1, None) == want, (gamma, x)
+
+
+# ------------------------------------------------------------------ GPU
+
+@pytest.fixture(scope="module")
+def gh():
+    import gpu_helpers
+    gpu_helpers.context()
+    return gpu_helpers
+
+
+def gpu_decode_rgba16f(gh, y, c, gamma, alpha=None, stride=None, y_stride=None, cbcr_stride=None):
+    ctx = gh.context()
+    h, w = y.shape
+    dec = gh.make_decoder(gamma, has_alpha=alpha is not None)
+    buf = gh.make_buffer(y, c, dec.gamma, y_stride, cbcr_stride)
+    abuf = gh.make_alpha_buffer(alpha) if alpha is not None else None
+    tex = ctx.makeBGRATexture((w, h), stride=stride, pixelFormat=mb.MTLPixelFormatRGBA16Float)
+    assert dec.decodeBT709(buf, abuf, tex, ctx.commandQueue.commandBuffer(), None, w, h, True), dec.lastStatus
+    assert b"rgba16f" in ctx.lib.bt709hip_last_kernel_name()
+    return ctx.getBGRATexturePixels(tex)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma", GAMMAS)
+def test_gpu_rgba16f_exhaustive_sweep(gh, pass2, gamma):
+    """Every (Y,Cb,Cr) once into an RGBA16Float target: the three half codes must hash to what the
+    REFERENCE's matrix step and curve functions produce (tests/golden/pass2.json)."""
+    y, c = gh.exhaustive_frame()
+    out = gpu_decode_rgba16f(gh, y, c, gamma).view(np.uint16)  # (4096, 4096, 4)
+    assert (out[..., 3] == 0x3C00).all()
+    cb = np.repeat(np.repeat(c[:, 0::2], 2, axis=0), 2, axis=1).astype(np.uint32)
+    cr = np.repeat(np.repeat(c[:, 1::2], 2, axis=0), 2, axis=1).astype(np.uint32)
+    idx = ((y.astype(np.uint32) << 16) | (cb << 8) | cr).reshape(-1)
+    table = np.zeros((1 << 24, 3), np.uint16)
+    table[idx] = out.reshape(-1, 4)[:, :3]
+    assert hashlib.sha256(table.tobytes()).hexdigest() == pass2["rgba16f_table_sha256"][GAMMA_NAMES[gamma]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma", GAMMAS)
+@pytest.mark.parametrize("size", [(2, 2), (6, 4), (250, 30), (1028, 6), (1920, 64)])
+def test_gpu_rgba16f_frames(gh, oracle, gamma, size):
+    w, h = size
+    y, c = _frame(w, h, w + h + gamma)
+    got = gpu_decode_rgba16f(gh, y, c, gamma)
+    assert np.array_equal(got.view(np.uint16), oracle.decode_nv12_rgba16f(gamma, y, c).view(np.uint16))
+
+
+@pytest.mark.gpu
+def test_gpu_rgba16f_alpha_strides_and_padding(gh, oracle):
+    """Linear alpha stored unquantised; odd plane pitches (byte loads), an 8-byte-aligned target pitch
+    (8-byte stores), nothing written outside the rows."""
+    ctx = gh.context()
+    w, h = 70, 12
+    y, c = _frame(w, h, 9)
+    a = np.random.default_rng(3).integers(0, 256, (h, w), dtype=np.uint8)
+    got = gpu_decode_rgba16f(gh, y, c, mb.MetalBT709GammaSRGB, alpha=a)
+    assert np.array_equal(got.view(np.uint16), oracle.decode_nv12_rgba16f(1, y, c, alpha=a).view(np.uint16))
+    for ys, cs, os_ in ((71, 73, w * 8 + 8), (72, 70, w * 8 + 24), (70, 70, w * 8)):
+        dec = gh.make_decoder(mb.MetalBT709GammaApple)
+        buf = gh.make_buffer(y, c, dec.gamma, ys, cs)
+        tex = ctx.makeBGRATexture((w, h), stride=os_, pixelFormat=mb.MTLPixelFormatRGBA16Float)
+        _capi.check(ctx.lib.bt709hip_memset(ctx.handle, tex.ptr, 0x5A, os_ * h, None))
+        assert dec.decodeBT709(buf, None, tex, None, None, w, h, True), dec.lastStatus
+        raw = np.empty((h, os_), np.uint8)
+        _capi.check(ctx.lib.bt709hip_download(ctx.handle, raw.ctypes.data, os_, tex.ptr, os_, os_, h, None))
+        ctx._sync(None)
+        want = oracle.decode_nv12_rgba16f(0, y, c).view(np.uint8).reshape(h, w * 8)
+        assert np.array_equal(raw[:, :w * 8], want) and (raw[:, w * 8:] == 0x5A).all(), (ys, cs, os_)
+
+
+@pytest.mark.gpu
+def test_gpu_rgba16f_batch_4k(gh, oracle):
+    """The reference's fallback intermediate at BASELINE config 3's geometry: 4 x 4K frames, one launch."""
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    n, w, h = 4, 3840, 2160
+    frames = [_frame(w, h, 60 + i) for i in range(n)]
+    bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
+    texs = [ctx.makeBGRATexture((w, h), pixelFormat=mb.MTLPixelFormatRGBA16Float) for _ in range(n)]
+    assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True), dec.lastStatus
+    for (y, c), t in zip(frames, texs):
+        got = ctx.getBGRATexturePixels(t).view(np.uint16)
+        for r0 in (0, 1000, h - 8):
+            want = oracle.decode_nv12_rgba16f(0, y[r0:r0 + 8], c[r0 // 2:r0 // 2 + 4]).view(np.uint16)
+            assert np.array_equal(got[r0:r0 + 8], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(0, (64, 32), (40, 20)), (1, (30, 18), (64, 40)), (3, (1920, 64), (1280, 43)),
+                                  (2, (50, 22), (1, 1)), (0, (48, 24), (24, 12))])
+def test_gpu_two_passes_equal_fused(gh, oracle, case):
+    """The reference's literal pipeline -- -decodeBT709 into an intermediate, then -renderScaled: --
+    through both intermediate formats; the BGRA8 route must equal the fused kernel bit for bit."""
+    gamma, (w, h), (ow, oh) = case
+    ctx = gh.context()
+    y, c = _frame(w, h, w + ow + gamma)
+    a = np.random.default_rng(ow).integers(0, 256, (h, w), dtype=np.uint8) if gamma == 1 else None
+    dec = gh.make_decoder(gamma, has_alpha=a is not None)
+    buf = gh.make_buffer(y, c, dec.gamma)
+    abuf = gh.make_alpha_buffer(a) if a is not None else None
+    scale = mb.MetalScaleRenderContext()
+    assert scale.setupRenderPipelines(ctx)
+    view = ctx.makeBGRATexture((ow, oh))
+    fused = gh.gpu_decode_scaled(y, c, (ow, oh), gamma, dec, alpha=a)
+    for fmt in (mb.MTLPixelFormatBGRA8Unorm_sRGB, mb.MTLPixelFormatRGBA16Float):
+        inter = ctx.makeBGRATexture((w, h), pixelFormat=fmt)
+        cb = ctx.commandQueue.commandBuffer()
+        assert dec.decodeBT709(buf, abuf, inter, cb, None, w, h, False), dec.lastStatus
+        assert scale.renderScaled(ctx, view, ow, oh, cb, None, inter, True), scale.lastStatus
+        got = ctx.getBGRATexturePixels(view).view(np.uint8).reshape(oh, ow * 4)
+        if fmt == mb.MTLPixelFormatBGRA8Unorm_sRGB:
+            assert np.array_equal(got, fused)
+            assert np.array_equal(got, oracle.render_scaled(oracle.decode_nv12(gamma, y, c, alpha=a), ow, oh))
+        else:
+            assert np.array_equal(got, oracle.render_scaled(oracle.decode_nv12_rgba16f(gamma, y, c, alpha=a), ow, oh))
+    assert not scale.renderScaled(ctx, view, ow + 1, oh, None, None, inter, True) and scale.lastStatus == _capi.ERR_SIZE_MISMATCH
