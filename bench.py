@@ -76,6 +76,9 @@ def parse_args(argv=None):
                     help="4k-batch8 only: frames per step of THIS rank (default 8 / world size); lets one GPU "
                          "play a rank of a larger job")
     ap.add_argument("--graph", action="store_true", help="record the K steps into one HIP graph and replay it")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="4k-batch8 only: issue consecutive steps round-robin on this many HIP streams (one stream "
+                         "per in-flight frame); 0 = auto (2: measured best for every share, profiles/r02_batch8_streams*.txt)")
     ap.add_argument("--no-smooth-leg", action="store_true", help="skip the extra smooth-content measurement (N=1, 4k)")
     ap.add_argument("--decoder-option", action="append", default=[], metavar="ID=VALUE",
                     help="bt709hip_decoder_set_option(ID, VALUE) on the bench decoder (tuning sweeps)")
@@ -166,10 +169,24 @@ class GpuRunner:
         self.pos = 0          # 4k-batch8: ring position of the next step
         self.stream = None    # launch stream: the context's default, or a created one when recording a graph
         self.graph = None
+        self.extra_streams, self.join_events, self.turn = [], [], 0
         if args.graph:
             s = C.c_void_p()
             _capi.check(lib.bt709hip_stream_create(h, C.byref(s)), "stream create")
             self.stream = s.value
+        # One HIP stream per in-flight frame (north-star): a step of 1-8 frames is a 8-63 us kernel, and on ONE
+        # stream every launch boundary costs ~3.5 us of idle GPU; consecutive steps touch different frames, so
+        # they may overlap on two streams (measured: 1 frame per step 717 -> 935 Gpixel/s, 8 per step 1041 ->
+        # 1064; four or eight streams are no better).  The 32-frame launches of the other workloads want ONE
+        # stream (two interleave two DRAM address streams: -4 %).
+        nstreams = args.streams or (2 if g["batch8"] and not args.graph else 1)
+        self.nstreams = nstreams if g["batch8"] and not args.graph else 1
+        for _ in range(self.nstreams - 1):
+            s, e = C.c_void_p(), C.c_void_p()
+            _capi.check(lib.bt709hip_stream_create(h, C.byref(s)), "stream create")
+            _capi.check(lib.bt709hip_event_create(h, C.byref(e)), "event create")
+            self.extra_streams.append(s.value)
+            self.join_events.append(e)
         # Untimed pre-warm: the device sits in a low-power state between jobs and needs
         # ~20-50 launches (tens of ms) before its clocks settle (measured: 308 -> 248 us per
         # launch, tools/launchprobe.py).  Done here, before the W warmup steps, so that a
@@ -200,20 +217,23 @@ class GpuRunner:
             if i == 0:
                 self.host_frames[0] = buf.reshape(-1)
 
-    def launch(self, first, n):
+    def launch(self, first, n, stream=None):
+        stream = stream if stream is not None else self.stream
         fp = C.cast(C.byref(self.frames, first * C.sizeof(self.Frame)), C.POINTER(self.Frame))
         sp = C.cast(C.byref(self.surfs, first * C.sizeof(self.Surface)), C.POINTER(self.Surface))
         if self.g["half"]:
-            rc = self.lib.bt709hip_decode_half_batch(self.dec._handle, n, fp, None, sp, self.stream, 0)
+            rc = self.lib.bt709hip_decode_half_batch(self.dec._handle, n, fp, None, sp, stream, 0)
         else:
-            rc = self.lib.bt709hip_decode_batch(self.dec._handle, n, fp, None, sp, self.stream, 0)
+            rc = self.lib.bt709hip_decode_batch(self.dec._handle, n, fp, None, sp, stream, 0)
         if rc != 0:
             raise self._capi.Bt709Error(rc, "decode")
 
     def step(self):
         g, n = self.g, self.g["per_launch"]
-        if g["batch8"]:  # one launch of this rank's share, walking the ring
-            self.launch(self.pos, n)
+        if g["batch8"]:  # one launch of this rank's share, walking the ring (and the streams)
+            lane = self.turn % self.nstreams
+            self.launch(self.pos, n, self.extra_streams[lane - 1] if lane else None)
+            self.turn += 1
             self.pos = (self.pos + n) % g["ring"]
             return
         for j in range(g["launches"]):
@@ -237,9 +257,17 @@ class GpuRunner:
         self._capi.check(self.lib.bt709hip_graph_launch(self.h, self.graph[1], self.stream), "graph launch")
 
     def sync(self):
+        for s in self.extra_streams:
+            self._capi.check(self.lib.bt709hip_stream_synchronize(self.h, s), "sync")
         self._capi.check(self.lib.bt709hip_stream_synchronize(self.h, self.stream), "sync")
 
     def mark(self, which):
+        """Event on the launch stream; with several streams the closing event first joins the others
+        (and the opening one is recorded with every stream idle: timed_region syncs before it)."""
+        if which:
+            for s, e in zip(self.extra_streams, self.join_events):
+                self._capi.check(self.lib.bt709hip_event_record(self.h, e, s))
+                self._capi.check(self.lib.bt709hip_stream_wait_event(self.h, self.stream, e))
         self._capi.check(self.lib.bt709hip_event_record(self.h, self.ev1 if which else self.ev0, self.stream))
 
     def event_ms(self):
@@ -433,6 +461,7 @@ def main(argv=None):
                            g["ring"], "uniform random bytes" if args.content == "random" else "smooth video-like planes",
                            step_text),
             "frames_per_step_per_gpu": g["frames_per_step"],
+            "streams": getattr(runner, "nstreams", 1),
             "sharding": "independent frames per GPU, no collective",
             "device": runner.device,
             "arch": runner.arch,

@@ -173,6 +173,9 @@ int bt709hip_event_create(bt709hip_context *ctx, void **event);
 int bt709hip_event_destroy(bt709hip_context *ctx, void *event);
 int bt709hip_event_record(bt709hip_context *ctx, void *event, void *stream);
 int bt709hip_event_synchronize(bt709hip_context *ctx, void *event);
+/* Makes `stream` wait for `event` (recorded on another stream): joins the per-frame streams of a
+ * pipeline without blocking the host -- MTLCommandBuffer ordering across queues / encodeWaitForEvent:. */
+int bt709hip_stream_wait_event(bt709hip_context *ctx, void *stream, void *event);
 int bt709hip_event_elapsed_ms(bt709hip_context *ctx, void *start, void *stop, float *ms);
 
 /* Recorded command buffers.  The reference encodes a frame's passes into an MTLCommandBuffer

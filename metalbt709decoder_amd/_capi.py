@@ -82,6 +82,7 @@ SYMBOLS = {
     "bt709hip_event_destroy": (_I, [_P, _P]),
     "bt709hip_event_record": (_I, [_P, _P, _P]),
     "bt709hip_event_synchronize": (_I, [_P, _P]),
+    "bt709hip_stream_wait_event": (_I, [_P, _P, _P]),
     "bt709hip_event_elapsed_ms": (_I, [_P, _P, _P, C.POINTER(C.c_float)]),
     "bt709hip_pool_create": (_I, [_P, _I, _I, _I, C.POINTER(C.c_void_p)]),
     "bt709hip_pool_destroy": (_I, [_P]),

@@ -14,9 +14,10 @@
 //
 // Adding the +-0 products of the zero matrix entries never changes a sum's value (only possibly
 // the sign of an exact zero, which saturates to the same bucket), so they are not computed.
-// Every multiply and add is a separate IEEE binary32 operation: the files are compiled with
-// -ffp-contract=off and the arithmetic goes through __fmul_rn/__fadd_rn so no FMA can form (a
-// CPU test greps the ISA).
+// Every multiply and add of the matrix step is a separate IEEE binary32 operation: the files are
+// compiled with -ffp-contract=off and the arithmetic goes through __fmul_rn/__fadd_rn so no FMA can
+// form there (a CPU test greps the ISA); the one deliberate fma is centre_norm below, where it is
+// provably the same rounding.
 //
 // VALU BUDGET (tools/valu_ops.hip, waves of 64): v_add_f32, v_mul_f32 and v_mov_b32 occupy a
 // SIMD for 2 cycles; every other VALU instruction these kernels use -- converts, compares,
@@ -64,10 +65,18 @@ __device__ __forceinline__ float byte_value(uint8_t b) {
   return f;
 }
 
-// (v - off) * (1/255f): integer-valued floats subtract exactly, so this equals the
-// reference's int subtract followed by int->float conversion.
+// (v - off) * (1/255f), v an integer-valued float (a byte), off 16 or 128.  The reference subtracts
+// in int (exact), converts and multiplies: ONE rounding, of the real number (v - off) / 255f.  An
+// fma computes v * (1/255f) + (-off * (1/255f)) with one rounding too, and -off * (1/255f) is exact
+// (off is a power of two), so the real number rounded is the same one: bit-identical, one
+// instruction instead of two.  This is the only fused multiply-add in the decode kernels (a CPU
+// test counts them: one per converted byte, none anywhere else).
 __device__ __forceinline__ float centre_norm(float v, float off) {
+#if defined(BT709_NO_FMA_CENTRE)  // the two-instruction form, for A/B runs
   return __fmul_rn(__fadd_rn(v, -off), kInv255);
+#else
+  return __builtin_fmaf(v, kInv255, -off * kInv255);
+#endif
 }
 
 // a + b saturated to [0, 1] (BT709.h:444-446 `saturatef`) by the add's own clamp bit

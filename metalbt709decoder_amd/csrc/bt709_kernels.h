@@ -43,6 +43,11 @@ struct DecodeParams {
   // sRGB-encode table (transfer_tables.h SplitTable): q = min(qf, (qf >> encode_shift) + encode_offset)
   const void *table_linear;
   const void *table_encode;
+  // persistent 2:1 kernel, encode side: the same composite as a uniform table with a non-power-of-two
+  // bucket count (transfer_tables.h UniformTable): index by two multiplies and an add
+  const void *table_encode_u;
+  uint32_t table_encode_u_bytes;
+  float encode_u_n;
   // alpha decoders, rescale kernels: TransferBucketLinear[N + 1] whose values are byteNorm(byte)
   // (transfer_tables.h buckets_bytenorm): pass 2 filters the alpha channel as a plain unorm
   const void *table_alpha;

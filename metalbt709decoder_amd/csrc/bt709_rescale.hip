@@ -39,10 +39,16 @@ struct RescaleLookup {
   uint32_t split_offset, split_shift;  // SplitTable: q = min(qf, (qf >> shift) + offset)
   float quarter_scale;  // 0.25 * scale
   float scale;          // n_fine of the encode table * 2^40 (the linear values come scaled by 2^-40)
+  // uniform encode table (persistent kernel): v = sum * quarter_unscale is the mean itself, xs = v * enc_n
+  float quarter_unscale;  // 0.25 * 2^40
+  float enc_n;
+  float sum_to_xs;        // quarter_unscale * enc_n
+  uint32_t enc_u_off;     // LDS address of the table + lane's copy offset - (bits(2^23) << enc_shift)
 };
 
 // Stages both tables in 2^r1 / 2^r2 interleaved copies (0 / 0: plain) and returns the lookup
 // constants of this lane.  The caller synchronises.
+template <bool UNIFORM_ENCODE = false>
 __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds_raw, const DecodeParams &p, uint32_t r1,
                                                               uint32_t r2) {
   const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
@@ -52,9 +58,19 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   for (uint32_t i = tid; i < n; i += nthreads) d[i] = src[i >> r1];
   const uint32_t dec_bytes = p.table_linear_bytes << r1;
   u32x2 *d2 = reinterpret_cast<u32x2 *>(lds_raw + dec_bytes);
-  const u32x2 *src2 = reinterpret_cast<const u32x2 *>(p.table_encode);
-  const uint32_t n2 = (p.table_encode_bytes / 8) << r2;
-  for (uint32_t i = tid; i < n2; i += nthreads) d2[i] = src2[i >> r2];
+  const u32x2 *src2 = reinterpret_cast<const u32x2 *>(UNIFORM_ENCODE ? p.table_encode_u : p.table_encode);
+  const uint32_t n2 = ((UNIFORM_ENCODE ? p.table_encode_u_bytes : p.table_encode_bytes) / 8) << r2;
+  if (UNIFORM_ENCODE) {
+    // edges move into the domain of the taps' sum: edge * 4 * 2^-40 (a power of two: exact; +inf stays +inf)
+    const float to_sum = __uint_as_float(static_cast<uint32_t>(127 + 2 + kLinearScaleLog2) << 23);
+    for (uint32_t i = tid; i < n2; i += nthreads) {
+      u32x2 e = src2[i >> r2];
+      e.x = __float_as_uint(__fmul_rn(__uint_as_float(e.x), to_sum));
+      d2[i] = e;
+    }
+  } else {
+    for (uint32_t i = tid; i < n2; i += nthreads) d2[i] = src2[i >> r2];
+  }
 
   const uint32_t base = lds_address(lds_raw);
   RescaleLookup r;
@@ -68,7 +84,22 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   const float unscale = __uint_as_float(static_cast<uint32_t>(127 - kLinearScaleLog2) << 23);  // 2^40
   r.scale = __fmul_rn(p.encode_scale, unscale);
   r.quarter_scale = __fmul_rn(0.25f, r.scale);
+  r.quarter_unscale = __fmul_rn(0.25f, unscale);
+  r.enc_n = p.encode_u_n;
+  r.enc_u_off = r.enc_off - (0x4b000000u << r.enc_shift);
+  asm volatile("" : "+v"(r.enc_u_off));  // keep it ONE addend of the v_lshl_add (hipcc otherwise subtracts bits(2^23) per lookup)
+  r.sum_to_xs = __fmul_rn(r.quarter_unscale, r.enc_n);  // exact: quarter_unscale is a power of two
   return r;
+}
+
+// sRGB byte of the linear-light SUM s of the four taps (times 2^-40) through the uniform table
+// (transfer_tables.h UniformTable).  The mean v = s * quarter_unscale is never formed: the index comes from
+// s * (quarter_unscale * n) -- the same float as v * n, the factor being a power of two times n -- and the
+// bucket's edge is compared in the sum's own domain (edges pre-divided by quarter_unscale at staging).
+__device__ __forceinline__ uint32_t encode_byte_uniform(const RescaleLookup &r, float s) {
+  const uint32_t t = __float_as_uint(__fadd_rn(__fmul_rn(s, r.sum_to_xs), 8388608.0f));  // bits(2^23) + round(v n)
+  const u32x2 e = *reinterpret_cast<LdsPairPtr>((t << r.enc_shift) + r.enc_u_off);
+  return e.y + (s >= __uint_as_float(e.x) ? 1u : 0u);
 }
 
 // sRGB byte of a linear value scaled into the encode table's domain (xs = v * n_fine)
@@ -81,20 +112,28 @@ __device__ __forceinline__ uint32_t encode_byte(const RescaleLookup &r, float xs
   return e.y + (xs >= __uint_as_float(e.x) ? 1u : 0u);
 }
 
-// linear-light values (times 2^-40) of 12 saturated channel values: 6 buckets in flight per wait
+// linear-light values (times 2^-40) of 12 saturated channel values: kLinBatch buckets in flight per wait
+#ifndef BT709_LIN_BATCH
+#define BT709_LIN_BATCH 6
+#endif
+constexpr int kLinBatch = BT709_LIN_BATCH;  // 6 or 12 (12: one wait per pixel, 48 VGPRs of buckets in flight)
 __device__ __forceinline__ void linearise12(const RescaleLookup &r, const float *x, float *lin) {
   uint32_t t[12];
   magic_index12(x, t, r.magic);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    u32x4 e[6];  // {edge, lin(base), lin(base + 1), base}: whole vectors keep the read a ds_read_b128
+  for (int h = 0; h < 12 / kLinBatch; ++h) {
+    u32x4 e[kLinBatch];  // {edge, lin(base), lin(base + 1), base}: whole vectors keep the read a ds_read_b128
 #pragma unroll
-    for (int i = 0; i < 6; ++i) e[i] = *reinterpret_cast<LdsQuadPtr>((t[6 * h + i] << r.dec_shift) + r.dec_off);
-    asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait per batch
+    for (int i = 0; i < kLinBatch; ++i) e[i] = *reinterpret_cast<LdsQuadPtr>((t[kLinBatch * h + i] << r.dec_shift) + r.dec_off);
+    if (kLinBatch == 6) asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait per batch
+    else {
+      asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6 % kLinBatch]), "+v"(e[7 % kLinBatch]),
+                        "+v"(e[8 % kLinBatch]), "+v"(e[9 % kLinBatch]), "+v"(e[10 % kLinBatch]), "+v"(e[11 % kLinBatch]));
+    }
 #pragma unroll
-    for (int i = 0; i < 6; ++i)  // transfer_tables.h TransferBucketLinear: below / above by sub + med3
-      lin[6 * h + i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z),
-                                               __fadd_rn(x[6 * h + i], -__uint_as_float(e[i].x)));
+    for (int i = 0; i < kLinBatch; ++i)  // transfer_tables.h TransferBucketLinear: below / above by sub + med3
+      lin[kLinBatch * h + i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z),
+                                                       __fadd_rn(x[kLinBatch * h + i], -__uint_as_float(e[i].x)));
   }
 }
 
@@ -159,6 +198,7 @@ __device__ __forceinline__ uint32_t half_alpha(const AlphaLookup &a, float magic
 
 // One output pixel of the exact 2:1 rescale: the four source pixels of a 2x2 block share one
 // CbCr sample; (((a+b)+c)+d) * 0.25f per channel.
+template <bool UNIFORM_ENCODE = false>
 __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, float y01, float y10, float y11,
                                             const Chroma &c, uint32_t alpha_word) {
   float x[12];  // r0..r3, g0..g3, b0..b3
@@ -170,20 +210,23 @@ __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, f
   linearise12(r, x, lin);
   const float *lr = lin, *lg = lin + 4, *lb = lin + 8;
   // the average and the scaling into the encode table's domain are both exact powers of two
-  const float mr = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]), r.quarter_scale);
-  const float mg = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]), r.quarter_scale);
-  const float mb = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]), r.quarter_scale);
-  return pack_bgra(encode_byte(r, mr), encode_byte(r, mg), encode_byte(r, mb), alpha_word);
+  const float sr = __fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]);
+  const float sg = __fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]);
+  const float sb = __fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]);
+  if (UNIFORM_ENCODE) return pack_bgra(encode_byte_uniform(r, sr), encode_byte_uniform(r, sg), encode_byte_uniform(r, sb), alpha_word);
+  return pack_bgra(encode_byte(r, __fmul_rn(sr, r.quarter_scale)), encode_byte(r, __fmul_rn(sg, r.quarter_scale)),
+                   encode_byte(r, __fmul_rn(sb, r.quarter_scale)), alpha_word);
 }
 
 // the two output pixels of a quad (4x2 source pixels); aw0 / aw1 = their alpha words
+template <bool UNIFORM_ENCODE = false>
 __device__ __forceinline__ u32x2 half_quad(const RescaleLookup &r, uint32_t ya, uint32_t yb, uint32_t cw,
                                            uint32_t aw0, uint32_t aw1) {
   const Chroma c0 = chroma_terms(byte_of(cw, 0), byte_of(cw, 1));
   const Chroma c1 = chroma_terms(byte_of(cw, 2), byte_of(cw, 3));
   u32x2 v;
-  v.x = half_px(r, byte_of(ya, 0), byte_of(ya, 1), byte_of(yb, 0), byte_of(yb, 1), c0, aw0);
-  v.y = half_px(r, byte_of(ya, 2), byte_of(ya, 3), byte_of(yb, 2), byte_of(yb, 3), c1, aw1);
+  v.x = half_px<UNIFORM_ENCODE>(r, byte_of(ya, 0), byte_of(ya, 1), byte_of(yb, 0), byte_of(yb, 1), c0, aw0);
+  v.y = half_px<UNIFORM_ENCODE>(r, byte_of(ya, 2), byte_of(ya, 3), byte_of(yb, 2), byte_of(yb, 3), c1, aw1);
   return v;
 }
 
@@ -283,6 +326,14 @@ decode_nv12_half(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 namespace {
 
+// encode side of the persistent kernel: the uniform non-power-of-two table (index = mul, mul, add) unless
+// built with -DBT709_REP_SPLIT_ENCODE (round 1's two-resolution table: convert, shift, add, min; A/B runs)
+#if defined(BT709_REP_SPLIT_ENCODE)
+constexpr bool kRepUniformEncode = false;
+#else
+constexpr bool kRepUniformEncode = true;
+#endif
+
 struct TileCursor {
   uint32_t tx, rp, f;
 };
@@ -350,7 +401,7 @@ decode_nv12_half_rep(const DecodeParams p) {
     }
   }
 
-  const RescaleLookup r = stage_rescale_tables(lds_raw, p, p.rep_dec_log2, p.rep_enc_log2);
+  const RescaleLookup r = stage_rescale_tables<kRepUniformEncode>(lds_raw, p, p.rep_dec_log2, p.rep_enc_log2);
   __syncthreads();
 
   for (; t < p.tile_rows; t += U * G) {
@@ -373,7 +424,7 @@ decode_nv12_half_rep(const DecodeParams p) {
     for (int u = 0; u < U; ++u) {
       const bool have = t + u * G < p.tile_rows;
       const TileCursor c = {have ? cur.tx : first.tx, have ? cur.rp : first.rp, have ? cur.f : first.f};
-      const u32x2 v = half_quad(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word, p.alpha_word);
+      const u32x2 v = half_quad<kRepUniformEncode>(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word, p.alpha_word);
       const FramePlanes f = frame_planes(p, c.f);
       uint8_t *o = f.out + static_cast<size_t>(c.rp) * p.out_stride;
       // lanes past the row's end loaded the last quad (clamp), hold its result and store it again
@@ -676,13 +727,11 @@ const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool no
   DecodeParams p = p_in;
   const uint64_t kRepLdsBytes = lds_budget < 16384u ? 16384u : (lds_budget > bt709::kRepLdsBytes ? bt709::kRepLdsBytes : lds_budget);
   // copies: as many as fit the CU's LDS, decode side first (12 of the 15 lookups per output pixel)
+  const uint64_t enc_bytes = kRepUniformEncode ? p.table_encode_u_bytes : p.table_encode_bytes;
   uint32_t r1 = 4, r2 = 0;
-  while (r1 > 0 && (static_cast<uint64_t>(p.table_linear_bytes) << r1) + p.table_encode_bytes > kRepLdsBytes) --r1;
-  if ((static_cast<uint64_t>(p.table_linear_bytes) << r1) + p.table_encode_bytes > kRepLdsBytes) return nullptr;
-  while (r2 < 5 && (static_cast<uint64_t>(p.table_linear_bytes) << r1) +
-                           (static_cast<uint64_t>(p.table_encode_bytes) << (r2 + 1)) <=
-                       kRepLdsBytes)
-    ++r2;
+  while (r1 > 0 && (static_cast<uint64_t>(p.table_linear_bytes) << r1) + enc_bytes > kRepLdsBytes) --r1;
+  if ((static_cast<uint64_t>(p.table_linear_bytes) << r1) + enc_bytes > kRepLdsBytes) return nullptr;
+  while (r2 < 5 && (static_cast<uint64_t>(p.table_linear_bytes) << r1) + (enc_bytes << (r2 + 1)) <= kRepLdsBytes) ++r2;
   p.rep_dec_log2 = r1;
   p.rep_enc_log2 = r2;
   const uint32_t quads = p.width / 4, row_pairs = p.height / 2;
@@ -696,7 +745,7 @@ const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool no
   p.cursor_tx = workgroups % p.tiles_x;
   p.cursor_rp = (workgroups / p.tiles_x) % row_pairs;
   p.cursor_f = (workgroups / p.tiles_x) / row_pairs;
-  const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << r1) + (static_cast<size_t>(p.table_encode_bytes) << r2);
+  const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << r1) + (static_cast<size_t>(enc_bytes) << r2);
   if (nontemporal)
     hipLaunchKernelGGL((decode_nv12_half_rep<true, BT709_REP_STEP>), dim3(workgroups), dim3(threads), lds, stream, p);
   else

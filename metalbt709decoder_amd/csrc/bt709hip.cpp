@@ -69,6 +69,8 @@ struct bt709hip_decoder {
   uint32_t encode_bytes = 0;
   uint32_t encode_n = 0;
   uint32_t encode_offset = 0, encode_shift = 0;
+  void *d_encode_u = nullptr;      // the same composite as a UniformTable (persistent 2:1 kernel)
+  uint32_t encode_u_bytes = 0, encode_u_n = 0;
   // RGBA16F targets: threshold table of the half-float composite (transfer_tables.h HalfTable), built on
   // first use under setup_mutex; half.table_bytes == 0 with half_ready: the gamma has no curve
   bool half_ready = false;
@@ -228,6 +230,9 @@ void set_tables(DecodeParams *p, const bt709hip_decoder *dec) {
   p->table_linear_bytes = dec->table_linear_bytes;
   p->table_alpha = dec->d_table_alpha;
   p->table_alpha_bytes = dec->d_table_alpha ? dec->table_linear_bytes : 0;
+  p->table_encode_u = dec->d_encode_u;
+  p->table_encode_u_bytes = dec->encode_u_bytes;
+  p->encode_u_n = static_cast<float>(dec->encode_u_n);
   p->table_encode = dec->d_encode;
   p->table_encode_bytes = dec->encode_bytes;
   p->encode_scale = static_cast<float>(dec->encode_n);
@@ -447,6 +452,13 @@ int bt709hip_event_synchronize(bt709hip_context *ctx, void *event) {
   return BT709HIP_OK;
 }
 
+int bt709hip_stream_wait_event(bt709hip_context *ctx, void *stream, void *event) {
+  if (event == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipStreamWaitEvent(pick(ctx, stream), static_cast<hipEvent_t>(event), 0));
+  return BT709HIP_OK;
+}
+
 int bt709hip_event_elapsed_ms(bt709hip_context *ctx, void *start, void *stop, float *ms) {
   if (start == nullptr || stop == nullptr || ms == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (int rc = bind(ctx)) return rc;
@@ -574,6 +586,7 @@ int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
     if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
     if (dec->d_table_alpha) (void)hipFree(dec->d_table_alpha);
     if (dec->d_encode) (void)hipFree(dec->d_encode);
+    if (dec->d_encode_u) (void)hipFree(dec->d_encode_u);
     if (dec->half.table) (void)hipFree(const_cast<void *>(dec->half.table));
   }
   delete dec;
@@ -629,7 +642,9 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
 
   TransferTable t;
   SplitTable enc;  // sRGB encoder of the rescale kernel: two-resolution form (6 KiB instead of 33)
-  if (!build_transfer_table(dec->gamma, &t) || !build_split_table(kGammaLinear, &enc))
+  UniformTable enc_u;
+  if (!build_transfer_table(dec->gamma, &t) || !build_split_table(kGammaLinear, &enc) ||
+      !build_uniform_table(kGammaLinear, 256, &enc_u))
     return BT709HIP_ERR_UNSUPPORTED;
   dec->table_n = t.n;
   dec->table_unit_bytes = static_cast<uint32_t>(t.buckets_unit.size() * sizeof(TransferBucket));
@@ -639,17 +654,23 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   dec->encode_shift = 0;
   for (float r = enc.coarse_scale; r < 1.0f; r *= 2.0f) ++dec->encode_shift;  // log2(fine buckets per coarse bucket)
   dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
-  void *d_unit = nullptr, *d_linear = nullptr, *d_alpha = nullptr, *d_enc = nullptr;
+  void *d_unit = nullptr, *d_linear = nullptr, *d_alpha = nullptr, *d_enc = nullptr, *d_enc_u = nullptr;
+  const uint32_t enc_u_bytes = static_cast<uint32_t>(enc_u.buckets.size() * sizeof(TransferBucket));
   int rc = upload_table(t.buckets_unit.data(), dec->table_unit_bytes, &d_unit);
   if (rc == BT709HIP_OK) rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &d_linear);
   if (rc == BT709HIP_OK && dec->has_alpha) rc = upload_table(t.buckets_bytenorm.data(), dec->table_linear_bytes, &d_alpha);
   if (rc == BT709HIP_OK) rc = upload_table(enc.buckets.data(), dec->encode_bytes, &d_enc);
+  if (rc == BT709HIP_OK) rc = upload_table(enc_u.buckets.data(), enc_u_bytes, &d_enc_u);
   if (rc != BT709HIP_OK) {  // a retry starts from scratch: nothing is published, nothing leaks
     if (d_unit) (void)hipFree(d_unit);
     if (d_linear) (void)hipFree(d_linear);
     if (d_alpha) (void)hipFree(d_alpha);
+    if (d_enc) (void)hipFree(d_enc);
     return rc;
   }
+  dec->d_encode_u = d_enc_u;
+  dec->encode_u_bytes = enc_u_bytes;
+  dec->encode_u_n = enc_u.n;
   dec->d_table_unit = d_unit;
   dec->d_table_linear = d_linear;
   dec->d_table_alpha = d_alpha;

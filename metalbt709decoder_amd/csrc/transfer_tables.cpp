@@ -257,6 +257,42 @@ bool build_half_table(int gamma, HalfTable *out) {
   return true;
 }
 
+uint32_t uniform_index(float v, float n) {
+  volatile float xs = v * n;            // binary32 product, round to nearest even
+  volatile float t = xs + 8388608.0f;   // floats in [2^23, 2^24) have ulp 1: round(xs)
+  return to_bits(t) - 0x4b000000u;
+}
+
+bool build_uniform_table(int kind, uint32_t n_min, UniformTable *out) {
+  if (kind < 0 || kind >= kTableKinds || out == nullptr) return false;
+  float thr[255];
+  for (int k = 1; k <= 255; ++k) thr[k - 1] = find_threshold(kind, k);
+  const float inf = std::numeric_limits<float>::infinity();
+  for (uint32_t n = (n_min + 31) / 32 * 32; n <= 65536; n += 32) {
+    const float nf = static_cast<float>(n);
+    std::vector<TransferBucket> b(n + 2, TransferBucket{inf, 0u});
+    std::vector<uint32_t> held(n + 2, 0u);
+    bool ok = true;
+    for (int k = 0; k < 255 && ok; ++k) {
+      if (thr[k] == inf) continue;
+      const uint32_t q = uniform_index(thr[k], nf);
+      if (q > n + 1 || held[q] != 0) ok = false;
+      else held[q] = 1, b[q].edge = thr[k];
+    }
+    if (!ok || uniform_index(1.0f, nf) > n + 1) continue;
+    uint32_t before = 0;
+    for (uint32_t q = 0; q < n + 2; ++q) {
+      b[q].base = before;
+      before += held[q];
+    }
+    while ((b.size() * sizeof(TransferBucket)) % 16 != 0) b.push_back(TransferBucket{inf, 255u});
+    out->n = n;
+    out->buckets = b;
+    return true;
+  }
+  return false;
+}
+
 bool build_split_table(int kind, SplitTable *out) {
   if (kind < 0 || kind >= kTableKinds || out == nullptr) return false;
   float thr[255];

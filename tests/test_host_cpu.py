@@ -248,17 +248,23 @@ def _kernel_body(asm, mangled_fragment):
     return _kernel_bodies(asm, mangled_fragment)[0]
 
 
-def test_isa_has_no_fused_multiply_add(asm):
-    """Every multiply and add must round separately (BT709.h:424-426 is evaluated without
-    contraction on the CPU); an FMA anywhere in these kernels would break bit-exactness."""
-    n = 0
+def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
+    """Every multiply and add of the matrix step must round separately (BT709.h:424-426 is evaluated
+    without contraction on the CPU).  The ONE fused multiply-add the decode kernels contain is
+    centre_norm's byte * (1/255f) - off * (1/255f) (bt709_device.h): the same single rounding of
+    (byte - off) / 255f as the reference's exact integer subtract + one multiply.  So: every fma-class
+    instruction has 1/255f (0x3b808081) as its multiplier, and a multiply fused with the float -> half
+    conversion (v_fma_mix*: one rounding instead of two) appears nowhere."""
+    n = fused = 0
     for kernel in ("17decode_nv12_quads", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
                    "18decode_nv12_scaled", "19decode_nv12_rgba16f", "13render_scaled"):
         for body in _kernel_bodies(asm, kernel):
-            # v_fma_mix* included: a multiply fused with the float -> half conversion rounds once instead of twice
-            assert not re.search(r"\bv_(pk_)?(fma|fmac|mad|mac)_(f32|legacy_f32|f16|mix)", body), kernel
+            for line in re.findall(r"^\s*(v_(?:pk_)?(?:fma|fmac|fmamk|fmaak|mad|mac|madmk|madak)_(?:f32|f16|legacy|mix)\w*\s[^\n]*)", body, flags=re.M):
+                assert re.match(r"v_fmamk_f32 v\d+, v\d+, 0x3b808081, v\d+|v_fmac_f32_e32 v\d+, 0x3b808081, v\d+", line), (kernel, line)
+                fused += 1
             n += 1
     assert n == 28  # every instantiation the launchers can pick
+    assert fused > 300
 
 
 def test_isa_memory_shape(asm):
