@@ -30,8 +30,7 @@ namespace {
 
 struct HalfLookup {
   float split, low_scale, pre_add, pre_scale, exponent;
-  uint32_t h_min, h_max;
-  uint32_t table_off;  // LDS address of T - 4 * h_min
+  uint32_t table_off;  // LDS address of T[h_min] - 4 * h_min
 };
 
 __device__ __forceinline__ uint32_t half_bits(float v) {
@@ -40,7 +39,8 @@ __device__ __forceinline__ uint32_t half_bits(float v) {
 }
 
 // H(x) for a saturated x in [0, 1]
-template <bool HAS_TABLE>
+// HAS_PRE: the curve's base is (x + a) / (1 + a) (sRGB, ITU); without it the base is x itself (Apple)
+template <bool HAS_TABLE, bool HAS_PRE>
 __device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
   // The product is rounded to binary32 first, THEN to binary16, as on the CPU: the empty asm keeps hipcc
   // from fusing multiply and conversion into v_fma_mixlo_f16 (one rounding instead of two).
@@ -50,9 +50,12 @@ __device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
   if (!HAS_TABLE) return low;
   float xb;  // max(x, split): keeps the candidate inside the table whatever x is
   asm("v_max_f32 %0, %1, %2" : "=v"(xb) : "v"(x), "s"(t.split));
-  const float base = __fmul_rn(__fadd_rn(xb, t.pre_add), t.pre_scale);
+  const float base = HAS_PRE ? __fmul_rn(__fadd_rn(xb, t.pre_add), t.pre_scale) : xb;
   const float p = __builtin_amdgcn_exp2f(__fmul_rn(t.exponent, __builtin_amdgcn_logf(base)));  // v_log_f32 is log2
-  const uint32_t h0 = min(max(half_bits(p), t.h_min), t.h_max);
+  // xb >= split, so the candidate is H(xb) or a neighbour: within [h_min - 1, h_max + 1].  The staged table
+  // carries one guard entry on each side (T[h_min - 1] = 0: never "below"; T[h_max + 2] = +inf: never
+  // "reached"), so no clamp is needed and a candidate one off either end is still settled correctly.
+  const uint32_t h0 = half_bits(p);
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
   const LdsFloatPtr e = reinterpret_cast<LdsFloatPtr>((h0 << 2) + t.table_off);
   const uint32_t h = h0 + (xb >= e[1] ? 1u : 0u) - (xb < e[0] ? 1u : 0u);
@@ -62,11 +65,13 @@ __device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
 }  // namespace
 
 // grid = (tiles of blockDim 2x2 blocks, groups of row_pairs_per_block row pairs, frames)
-template <bool HAS_TABLE, bool HAS_ALPHA, bool PAIRS>
+// CURVE: 0 = no curve (LINEAR), 1 = power curve on x itself (Apple), 2 = power curve on (x + a) / (1 + a) (sRGB, ITU)
+template <int CURVE, bool HAS_ALPHA, bool PAIRS>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
+  constexpr bool HAS_TABLE = CURVE != 0, HAS_PRE = CURVE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  if (HAS_TABLE) stage_table(lds_raw, hp.table, hp.table_bytes);
+  if (HAS_TABLE) stage_table(lds_raw, hp.table, hp.table_bytes);  // the device copy starts with the guard entry T[h_min - 1]
   __syncthreads();
   HalfLookup t;
   t.split = hp.split;
@@ -74,9 +79,7 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
   t.pre_add = hp.pre_add;
   t.pre_scale = hp.pre_scale;
   t.exponent = hp.exponent;
-  t.h_min = hp.h_min;
-  t.h_max = hp.h_max;
-  t.table_off = lds_address(lds_raw) - (hp.h_min << 2);
+  t.table_off = lds_address(lds_raw) + 4u - (hp.h_min << 2);
 
   const FramePlanes f = frame_planes(p, blockIdx.z);
   const uint32_t blocks = p.width >> 1, row_pairs = p.height >> 1;
@@ -110,7 +113,8 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
     for (int px = 0; px < 4; ++px) {
       float r, g, b;
       pixel_rgb(yv[px], c, r, g, b);
-      const uint32_t hr = half_code<HAS_TABLE>(t, r), hg = half_code<HAS_TABLE>(t, g), hb = half_code<HAS_TABLE>(t, b);
+      const uint32_t hr = half_code<HAS_TABLE, HAS_PRE>(t, r), hg = half_code<HAS_TABLE, HAS_PRE>(t, g),
+                     hb = half_code<HAS_TABLE, HAS_PRE>(t, b);
       const uint32_t ha = HAS_ALPHA ? (half_bits(alpha_value(av[px])) << 16) : opaque;  // linear alpha, unquantised
       w[2 * px] = hr | (hg << 16);
       w[2 * px + 1] = hb | ha;
@@ -144,16 +148,19 @@ const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp_in
   hp.wide_store = out_align >= 16 ? 1 : 0;
   const dim3 grid(tiles, (row_pairs + rpb - 1) / rpb, static_cast<uint32_t>(frames));
   const dim3 block(threads);
-  const bool table = hp.table_bytes != 0, pairs = in_align >= 2;
-  const size_t lds = table ? hp.table_bytes : 16;
-#define BT709_LAUNCH_RGBA16F(T, A, P) hipLaunchKernelGGL((decode_nv12_rgba16f<T, A, P>), grid, block, lds, stream, p, hp)
-  if (table) {
-    if (has_alpha) { if (pairs) BT709_LAUNCH_RGBA16F(true, true, true); else BT709_LAUNCH_RGBA16F(true, true, false); }
-    else { if (pairs) BT709_LAUNCH_RGBA16F(true, false, true); else BT709_LAUNCH_RGBA16F(true, false, false); }
-  } else {
-    if (has_alpha) { if (pairs) BT709_LAUNCH_RGBA16F(false, true, true); else BT709_LAUNCH_RGBA16F(false, true, false); }
-    else { if (pairs) BT709_LAUNCH_RGBA16F(false, false, true); else BT709_LAUNCH_RGBA16F(false, false, false); }
-  }
+  const bool pairs = in_align >= 2;
+  const int curve = hp.table_bytes == 0 ? 0 : ((hp.pre_add == 0.0f && hp.pre_scale == 1.0f) ? 1 : 2);
+  const size_t lds = curve ? hp.table_bytes : 16;
+#define BT709_LAUNCH_RGBA16F(C, A, P) hipLaunchKernelGGL((decode_nv12_rgba16f<C, A, P>), grid, block, lds, stream, p, hp)
+#define BT709_LAUNCH_RGBA16F_AP(C)                                                            \
+  do {                                                                                        \
+    if (has_alpha) { if (pairs) BT709_LAUNCH_RGBA16F(C, true, true); else BT709_LAUNCH_RGBA16F(C, true, false); } \
+    else { if (pairs) BT709_LAUNCH_RGBA16F(C, false, true); else BT709_LAUNCH_RGBA16F(C, false, false); }         \
+  } while (0)
+  if (curve == 0) BT709_LAUNCH_RGBA16F_AP(0);
+  else if (curve == 1) BT709_LAUNCH_RGBA16F_AP(1);
+  else BT709_LAUNCH_RGBA16F_AP(2);
+#undef BT709_LAUNCH_RGBA16F_AP
 #undef BT709_LAUNCH_RGBA16F
   return has_alpha ? "decode_nv12_rgba16f<alpha>" : "decode_nv12_rgba16f";
 }
@@ -161,14 +168,12 @@ const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp_in
 hipError_t prepare_rgba16f_kernels() {
   const int cap = 160 * 1024;
   const void *fns[] = {
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<true, true, true>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<true, true, false>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<true, false, true>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<true, false, false>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<false, true, true>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<false, true, false>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<false, false, true>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<false, false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<0, true, true>),  reinterpret_cast<const void *>(&decode_nv12_rgba16f<0, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<0, false, true>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<0, false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, true, true>),  reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, false, true>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<2, true, true>),  reinterpret_cast<const void *>(&decode_nv12_rgba16f<2, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_rgba16f<2, false, true>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<2, false, false>),
   };
   for (const void *fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

@@ -212,9 +212,17 @@ int ensure_half_table(bt709hip_decoder *dec, void *stream) {
     size_t real = t.thresholds.size();
     while (real > 0 && t.thresholds[real - 1] == std::numeric_limits<float>::infinity()) --real;
     hp.h_max = t.h_min + static_cast<uint32_t>(real) - 1;
-    hp.table_bytes = static_cast<uint32_t>(t.thresholds.size() * sizeof(float));
+    // device image: a guard entry below (T[h_min - 1] = 0: no x is "below" it) and two +inf above
+    // (T[h_max + 1], T[h_max + 2]), so a candidate one code off either end needs no clamp; 16-byte multiple
+    std::vector<float> image;
+    image.push_back(0.0f);
+    image.insert(image.end(), t.thresholds.begin(), t.thresholds.begin() + static_cast<std::ptrdiff_t>(real));
+    image.push_back(std::numeric_limits<float>::infinity());
+    image.push_back(std::numeric_limits<float>::infinity());
+    while (image.size() % 4 != 0) image.push_back(std::numeric_limits<float>::infinity());
+    hp.table_bytes = static_cast<uint32_t>(image.size() * sizeof(float));
     void *d = nullptr;
-    if (int rc = upload_table(t.thresholds.data(), hp.table_bytes, &d)) return rc;
+    if (int rc = upload_table(image.data(), hp.table_bytes, &d)) return rc;
     hp.table = d;
   }
   dec->half = hp;

@@ -1,8 +1,9 @@
 // Decode lab: times the PRODUCTION kernels (csrc/bt709_kernels.hip included verbatim) over a
 // ring of 64 distinct 4K frames, several launch shapes, interleaved rounds (median / min).
-// Build variants: -DBT709_LAB_NO_LDS prices the LDS lookups, -DBT709_LAB_LDS_CHROMA the LDS-staged chroma
-// tile, -DBT709_LAB_LDS_PAD (+ env BT709_LAB_LDS_PAD=KiB) caps the workgroups resident per CU,
-// -DBT709_MAX_BLOCK_THREADS / -DBT709_QUADS_PER_LANE change the tile shape.
+// Build variants of the shipping kernels: -DBT709_INDEX_RTZ (round 1's floor index between two s_setreg),
+// -DBT709_NO_FMA_CENTRE, -DBT709_MAX_BLOCK_THREADS / -DBT709_QUADS_PER_LANE (tile shape).  With
+// -DBT709_LAB_VARIANTS the lab copy tools/lab_quads_variants.hip is timed instead, whose own macros
+// (-DBT709_LAB_NO_LDS, _LDS_CHROMA, _ADJACENT, _LDS_PAD) select round 1's rejected variants.
 //
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 tools/decode_lab.hip \
 //         metalbt709decoder_amd/csrc/transfer_tables.cpp -o tools/bin/decode_lab
@@ -17,7 +18,11 @@
 #include <string>
 #include <vector>
 
+#if defined(BT709_LAB_VARIANTS)  // round 1's kernel file with the rejected variants (see its header)
+#include "lab_quads_variants.hip"
+#else
 #include "../metalbt709decoder_amd/csrc/bt709_kernels.hip"
+#endif
 #if defined(BT709_LAB_LDS_CHROMA)
 #define LAB_EXTRA_LDS 4096
 #else

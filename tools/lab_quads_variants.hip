@@ -1,3 +1,11 @@
+// LAB COPY of round 1's csrc/bt709_kernels.hip with its rejected variants still in place (tools/decode_lab.hip
+// includes this file instead of the shipping kernels when built with -DBT709_LAB_VARIANTS):
+//   -DBT709_LAB_NO_LDS      LDS lookups stubbed out (wrong output): their price, ~3 %
+//   -DBT709_LAB_LDS_CHROMA  the north-star's LDS-staged CbCr tile: -5 %
+//   -DBT709_LAB_ADJACENT    a lane owns adjacent quads (8-byte loads, 32-byte store runs): 3x slower
+//   -DBT709_LAB_LDS_PAD     (+ env BT709_LAB_LDS_PAD=KiB) caps the workgroups resident per CU
+// The shipping file carries none of these branches.
+//
 // CDNA4 (gfx950) kernels of the BT.709 NV12 -> sRGB BGRA decode path.
 //
 // What the reference does in its first Metal pass -- BT709ToLinearSRGBKernel & friends
@@ -26,32 +34,17 @@
 #include <cstdint>
 #include <cstdlib>
 
-#include "bt709_device.h"
+#include "../metalbt709decoder_amd/csrc/bt709_device.h"
 
 namespace bt709 {
 namespace {
 
-struct UnitLookup {
-  float magic;      // M = 2^23 / N
-  uint32_t offset;  // LDS address of the table - (bits(M) << 3)
-};
-
-__device__ __forceinline__ UnitLookup unit_lookup(const DecodeParams &p, const void *lds_table) {
-  UnitLookup u;
-  u.magic = p.unit_magic;
-  u.offset = lds_address(lds_table) - (__float_as_uint(u.magic) << 3);
-  return u;
-}
-
-// byte of the decoder's gamma for saturated x, t = bits(x + M) from magic_floor*
-__device__ __forceinline__ uint32_t bucket_byte(const UnitLookup &u, float x, uint32_t t) {
-#if defined(BT709_LAB_NO_LDS)  // tools/decode_lab only: price of the LDS lookups (wrong output)
+#if defined(BT709_LAB_NO_LDS)  // price of the LDS lookups (wrong output): shadows bt709_device.h's bucket_byte
+__device__ __forceinline__ uint32_t lab_bucket_byte(const UnitLookup &, float x, uint32_t t) {
   return (t & 0xffu) + (x >= 0.3f ? 1u : 0u);
-#else
-  const u32x2 e = *reinterpret_cast<LdsPairPtr>((t << 3) + u.offset);  // {edge bits, base}
-  return e.y + (x >= __uint_as_float(e.x) ? 1u : 0u);
-#endif
 }
+#define bucket_byte lab_bucket_byte
+#endif
 
 // One 4x2 quad: 8 pixels x (R, G, B) = 24 lookups.  Pixel p = 0..3 top row, 4..7 bottom row.
 template <bool HAS_ALPHA>
@@ -64,8 +57,8 @@ __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, ui
   for (int px = 0; px < 8; ++px)
     pixel_rgb(byte_of(px < 4 ? ya : yb, px & 3), (px & 2) ? c1 : c0, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
   uint32_t t[24];
-  magic_floor12(x, t, u.magic);
-  magic_floor12(x + 12, t + 12, u.magic);
+  magic_index12(x, t, u.magic);
+  magic_index12(x + 12, t + 12, u.magic);
   uint32_t byte[24];
 #pragma unroll
   for (int i = 0; i < 24; ++i) byte[i] = bucket_byte(u, x[i], t[i]);
@@ -80,7 +73,7 @@ __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, ui
     for (int px = 0; px < 8; ++px) a[px] = alpha_value(byte_of(px < 4 ? aa : ab, px & 3));
 #pragma unroll
     for (int i = 8; i < 12; ++i) a[i] = 0.0f;
-    magic_floor12(a, ta, u.magic);
+    magic_index12(a, ta, u.magic);
 #pragma unroll
     for (int px = 0; px < 8; ++px) al[px] = bucket_byte(u, a[px], ta[px]) << 24;
   }
@@ -103,14 +96,14 @@ __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[
 #pragma unroll
   for (int px = 0; px < 4; ++px) pixel_rgb(y[px], c, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
   uint32_t t[12];
-  magic_floor12(x, t, u.magic);
+  magic_index12(x, t, u.magic);
   uint32_t al[4] = {alpha_word, alpha_word, alpha_word, alpha_word};
   if (HAS_ALPHA) {
     float av[4];
     uint32_t ta[4];
 #pragma unroll
     for (int px = 0; px < 4; ++px) av[px] = alpha_value(a[px]);
-    magic_floor4(av, ta, u.magic);
+    magic_index4(av, ta, u.magic);
 #pragma unroll
     for (int px = 0; px < 4; ++px) al[px] = bucket_byte(u, av[px], ta[px]) << 24;
   }
@@ -207,7 +200,7 @@ decode_nv12_quads(const DecodeParams p) {
     if (HAS_ALPHA) asm volatile("" : "+v"(aa[u]), "+v"(ab[u]));
   }
 
-  const UnitLookup ul = unit_lookup(p, lds_raw);
+  const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = BT709_QUAD_OF(u);
@@ -233,7 +226,7 @@ decode_nv12_blocks(const DecodeParams p) {
   stage_table(lds_raw, p.table_unit, p.table_unit_bytes);
   __syncthreads();
 
-  const UnitLookup ul = unit_lookup(p, lds_raw);
+  const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
   const FramePlanes f = frame_planes(p, blockIdx.y);
   const uint32_t bw = p.width >> 1;
   const uint32_t row_pairs = p.height >> 1;
