@@ -689,6 +689,64 @@ def test_error_behaviour(gh):
     assert orphan.decodeBT709(good, None, tex, None, None, 8, 4, True) is False
 
 
+def test_launch_limits_are_reported_not_launched(gh):
+    """The row-pair dimension of every kernel lives in gridDim.y (<= 65535): taller surfaces are refused
+    with ERR_UNSUPPORTED instead of failing as an opaque HIP launch error."""
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    w, h = 4, 2 * 65536 + 4
+    buf = mb.CVPixelBuffer(ctx, w, h)
+    mb.BGRAToBT709Converter.setBT709Attributes(buf)
+    assert not dec.decodeBT709(buf, None, ctx.makeBGRATexture((w, h)), None, None, w, h, True)
+    assert dec.lastStatus == _capi.ERR_UNSUPPORTED
+    ok = mb.CVPixelBuffer(ctx, w, 2 * 65535)  # the tallest frame one launch takes
+    mb.BGRAToBT709Converter.setBT709Attributes(ok)
+    assert dec.decodeBT709(ok, None, ctx.makeBGRATexture((w, 2 * 65535)), None, None, w, 2 * 65535, True), dec.lastStatus
+    small = gh.make_buffer(*gh.random_nv12(8, 4, seed=2), dec.gamma)
+    assert not dec.decodeBT709Scaled(small, ctx.makeBGRATexture((2, 65536)), None, True)  # view-fit: one output row per gridDim.y
+    assert dec.lastStatus == _capi.ERR_UNSUPPORTED
+    tex = ctx.makeBGRATexture((4, 2 * 65536 + 4))
+    assert not mb.BGRAToBT709Converter.convertIntoCoreVideoBuffer(tex, buf, mb.MetalBT709GammaSRGB, mb.MetalBT709GammaApple)
+
+
+def test_lazily_built_tables_are_refused_inside_a_capture(gh, oracle):
+    """hipMalloc and blocking copies are illegal while a stream records a graph: an entry point that
+    would have to build its tables there returns ERR_NOT_SETUP; after the matching *_prepare call the
+    same recording works and replays correctly."""
+    ctx = gh.context()
+    lib, h = ctx.lib, ctx.handle
+    w, hgt = 64, 16
+    y, c = gh.random_nv12(w, hgt, seed=11)
+    dec = gh.make_decoder(mb.MetalBT709GammaITU709)  # a decoder of its own: its RGBA16F table is not built yet
+    buf = gh.make_buffer(y, c, dec.gamma)
+    half = ctx.makeBGRATexture((w, hgt), pixelFormat=mb.MTLPixelFormatRGBA16Float)
+    cb = ctx.commandQueue.commandBuffer(new_stream=True)
+    cb.beginRecording()
+    assert not dec.decodeBT709(buf, None, half, cb, None, w, hgt, False) and dec.lastStatus == _capi.ERR_NOT_SETUP
+    cb.endRecording().release()
+    assert lib.bt709hip_decoder_prepare_format(dec._handle, _capi.FORMAT_RGBA16F) == _capi.OK
+    cb.beginRecording()
+    assert dec.decodeBT709(buf, None, half, cb, None, w, hgt, False), dec.lastStatus
+    rec = cb.endRecording()
+    rec.replay(cb)
+    cb.waitUntilCompleted()
+    got = ctx.getBGRATexturePixels(half)
+    assert np.array_equal(got.view(np.uint16), oracle.decode_nv12_rgba16f(mb.MetalBT709GammaITU709, y, c).view(np.uint16))
+    rec.release()
+    # a fresh decoder inside a capture: -setupMetal has not run yet
+    fresh = mb.MetalBT709Decoder()
+    fresh.metalRenderContext = ctx
+    hnd = C.c_void_p()
+    assert lib.bt709hip_decoder_create(h, 0, 0, C.byref(hnd)) == _capi.OK
+    f8, s8 = gh.make_buffer(y, c, 0).frame(), ctx.makeBGRATexture((w, hgt)).surface()
+    cb.beginRecording()
+    assert lib.bt709hip_decode(hnd, C.byref(f8), None, C.byref(s8), w, hgt, cb.stream, 0) == _capi.ERR_NOT_SETUP
+    cb.endRecording().release()
+    assert lib.bt709hip_decode(hnd, C.byref(f8), None, C.byref(s8), w, hgt, cb.stream, 1) == _capi.OK
+    lib.bt709hip_decoder_destroy(hnd)
+    cb.release()
+
+
 def test_empty_frame_is_a_noop(gh):
     ctx = gh.context()
     dec = gh.make_decoder(mb.MetalBT709GammaApple)

@@ -1,0 +1,39 @@
+#!/bin/bash
+# One-call evidence run on the GPU box: tests, every bench line, rocprof + PMC summaries.
+# usage (through gpurun, from the repo root): tools/evidence.sh r02
+R=${1:-r02}
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/$R; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log
+python bench.py --steps 20 --warmup 5 > $O/bench_4k_driver_args.json 2> $O/bench_4k.err
+python bench.py --no-cpu-baseline > $O/bench_4k.json 2>/dev/null
+python bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>/dev/null
+python bench.py --workload 8k-half > $O/bench_8k-half.json 2>/dev/null
+for sh in 8 4 2 1; do python bench.py --workload 4k-batch8 --share $sh --no-cpu-baseline --steps 400 > $O/bench_batch8_share$sh.json 2>/dev/null; done
+python bench.py --workload 4k-batch8 --share 1 --streams 1 --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_1stream.json 2>/dev/null
+python bench.py --workload 4k-batch8 --share 1 --graph --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_graph.json 2>/dev/null
+python tools/bench_encode.py --frames-per-launch 32 > $O/bench_encode.json 2>/dev/null
+python tools/bench_encode.py --frames-per-launch 1 > $O/bench_encode_single.json 2>/dev/null
+tools/bench_paths.sh > $O/bench_paths.txt 2>&1
+python tools/stream_bench.py > $O/stream_bench.txt 2>&1
+tools/profile_gpu.sh 4k > /dev/null 2>&1
+tools/profile_gpu.sh 8k-half --workload 8k-half > /dev/null 2>&1
+PROFILE_PROG=tools/bench_encode.py tools/profile_gpu.sh encode --frames-per-launch 32 > /dev/null 2>&1
+PROFILE_PROG=tools/bench_scaled.py tools/profile_gpu.sh scaled --path scaled --frames-per-launch 8 > /dev/null 2>&1
+PROFILE_PROG=tools/bench_scaled.py tools/profile_gpu.sh rgba16f --path rgba16f --frames-per-launch 16 > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/prof_4k $R 4k > /dev/null
+python tools/pmc_summary.py gpurun_out/prof_8k-half $R 8k-half > /dev/null
+python tools/pmc_summary.py gpurun_out/prof_encode $R encode encode_bgra > /dev/null
+python tools/pmc_summary.py gpurun_out/prof_scaled $R scaled decode_nv12_scaled > /dev/null
+python tools/pmc_summary.py gpurun_out/prof_rgba16f $R rgba16f decode_nv12_rgba16f > /dev/null
+mkdir -p $O/profiles; cp profiles/${R}_*_kernel_stats.csv profiles/${R}_*_pmc.json profiles/pmc_traffic.json $O/profiles/
+python - <<PY
+import json,glob
+for f in sorted(glob.glob("$O/bench_*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1])
+        r=d.get("roofline",{})
+        print(f.split("/")[-1], d.get("value", d.get("gpixel_per_s")), r.get("frac", d.get("frac_of_8TBps")), r.get("avg_launch_us"), r.get("same_run_copy_GBps"), d.get("parity_spot_check"))
+    except Exception as e: print(f, "ERR", e)
+PY
+cat $O/bench_paths.txt; tail -5 $O/stream_bench.txt
