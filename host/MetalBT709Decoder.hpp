@@ -130,23 +130,27 @@ class CVPixelBuffer {
   void *base_ = nullptr;
 };
 
-// BGRA8Unorm_sRGB render target (-makeBGRATexture / -getBGRATexturePixels, MetalRenderContext.h:62-105)
+// Render target (-makeBGRATexture / -getBGRATexturePixels, MetalRenderContext.h:62-105): BGRA8Unorm_sRGB by
+// default, or the RGBA16Float intermediate of AAPLRenderer.m:143-170 (pixelFormat = BT709HIP_FORMAT_RGBA16F)
 class BGRATexture {
  public:
-  BGRATexture(MetalRenderContext &ctx, int width, int height) : ctx_(ctx) {
+  BGRATexture(MetalRenderContext &ctx, int width, int height, int pixelFormat = BT709HIP_FORMAT_BGRA8_SRGB) : ctx_(ctx) {
     s_.width = width;
     s_.height = height;
-    s_.stride = (static_cast<size_t>(width) * 4 + 15) / 16 * 16;
+    s_.format = pixelFormat;
+    s_.stride = (static_cast<size_t>(width) * (pixelFormat == BT709HIP_FORMAT_RGBA16F ? 8 : 4) + 15) / 16 * 16;
     bt709hip_malloc(ctx.handle(), s_.stride * height + 16, &s_.bgra);
   }
   ~BGRATexture() { bt709hip_free(ctx_.handle(), s_.bgra); }
   BGRATexture(const BGRATexture &) = delete;
   BGRATexture &operator=(const BGRATexture &) = delete;
 
+  // (A<<24)|(R<<16)|(G<<8)|B words; an RGBA16Float texture reads back as two words per pixel (four halves R,G,B,A)
   std::vector<uint32_t> getBGRATexturePixels() const {
-    std::vector<uint32_t> px(static_cast<size_t>(s_.width) * s_.height);
+    const size_t words = s_.format == BT709HIP_FORMAT_RGBA16F ? 2 : 1;
+    std::vector<uint32_t> px(static_cast<size_t>(s_.width) * s_.height * words);
     if (px.empty()) return px;
-    const size_t row = static_cast<size_t>(s_.width) * 4;
+    const size_t row = static_cast<size_t>(s_.width) * 4 * words;
     bt709hip_download(ctx_.handle(), px.data(), row, s_.bgra, s_.stride, row, s_.height, nullptr);
     bt709hip_stream_synchronize(ctx_.handle(), nullptr);
     return px;
@@ -176,6 +180,31 @@ struct HostTexture {  // BGRA8Unorm_sRGB pixels in host memory
   uint8_t *bgra = nullptr;
   size_t stride = 0;
   int width = 0, height = 0;
+};
+
+// Pass 2 on its own (Renderer/MetalScaleRenderContext.h:17-40); the view's drawable is a BGRATexture.
+class MetalScaleRenderContext {
+ public:
+  // -setupRenderPipelines:mtkView: (MetalScaleRenderContext.m:31-51)
+  bool setupRenderPipelines(MetalRenderContext &mrc) {
+    return (lastStatus_ = bt709hip_render_scaled_prepare(mrc.handle())) == BT709HIP_OK;
+  }
+  // -renderScaled:mtkView:renderWidth:renderHeight:commandBuffer:renderPassDescriptor:bgraTexture: (.h:34-40)
+  bool renderScaled(MetalRenderContext &mrc, const BGRATexture &mtkView, int renderWidth, int renderHeight,
+                    void *commandBuffer, const void * /*renderPassDescriptor*/, const BGRATexture &bgraTexture,
+                    bool waitUntilCompleted = false) {
+    if (renderWidth != mtkView.width() || renderHeight != mtkView.height()) {
+      lastStatus_ = BT709HIP_ERR_SIZE_MISMATCH;
+      return false;
+    }
+    lastStatus_ = bt709hip_render_scaled(mrc.handle(), bgraTexture.surface(), mtkView.surface(), commandBuffer,
+                                         waitUntilCompleted ? 1 : 0);
+    return lastStatus_ == BT709HIP_OK;
+  }
+  int lastStatus() const { return lastStatus_; }
+
+ private:
+  int lastStatus_ = BT709HIP_OK;
 };
 
 class MetalBT709Decoder {
@@ -390,6 +419,12 @@ class InFlightFramePool {
     *y = static_cast<uint8_t *>(py);
     *cbcr = static_cast<uint8_t *>(pc);
     return lastStatus_ == BT709HIP_OK ? slot : -1;
+  }
+  // pinned alpha plane of an acquired slot (decoders with hasAlphaChannel); fill it before submit
+  uint8_t *alphaPlane(int slot, size_t *stride) {
+    void *p = nullptr;
+    lastStatus_ = bt709hip_pool_alpha_plane(pool_, slot, &p, stride);
+    return static_cast<uint8_t *>(p);
   }
   bool submit(int slot) { return (lastStatus_ = bt709hip_pool_submit(pool_, slot)) == BT709HIP_OK; }
   // pinned BGRA rows of a submitted slot, valid until the slot is acquired again

@@ -75,7 +75,41 @@ static int run_host_vectors(MetalBT709Decoder &metalDecoder, int argc, char **ar
   return failures ? 1 : 0;
 }
 
+// The reference's literal two passes (-decodeBT709 into an intermediate, then -renderScaled:) against the
+// fused call: through a BGRA8 intermediate the pixels must be identical; through RGBA16Float they must run.
+static int run_two_pass(MetalRenderContext &ctx, MetalBT709Decoder &dec) {
+  const int w = 32, h = 16, ow = 20, oh = 10;
+  std::vector<uint32_t> packed(static_cast<size_t>(w) * h);
+  uint32_t st = 709;
+  for (uint32_t &p : packed) p = (st = st * 1664525u + 1013904223u) >> 8;  // Y | Cb << 8 | Cr << 16, full range
+  CVPixelBuffer buf(ctx, w, h);
+  buf.setBT709Attributes();
+  buf.copyBT709ToCoreVideo(packed.data());
+  BGRATexture fused(ctx, ow, oh), view(ctx, ow, oh), inter8(ctx, w, h), inter16(ctx, w, h, BT709HIP_FORMAT_RGBA16F);
+  MetalScaleRenderContext scale;
+  int failures = 0;
+  if (!scale.setupRenderPipelines(ctx)) ++failures;
+  if (!dec.decodeBT709Scaled(&buf, &fused, nullptr, true)) ++failures;
+  if (!dec.decodeBT709(&buf, nullptr, &inter8, nullptr, nullptr, w, h, false)) ++failures;
+  if (!scale.renderScaled(ctx, view, ow, oh, nullptr, nullptr, inter8, true)) ++failures;
+  if (fused.getBGRATexturePixels() != view.getBGRATexturePixels()) ++failures;
+  if (!dec.decodeBT709(&buf, nullptr, &inter16, nullptr, nullptr, w, h, false)) ++failures;
+  if (!scale.renderScaled(ctx, view, ow, oh, nullptr, nullptr, inter16, true)) ++failures;
+  if (scale.renderScaled(ctx, view, ow + 2, oh, nullptr, nullptr, inter16, true) ||
+      scale.lastStatus() != BT709HIP_ERR_SIZE_MISMATCH)
+    ++failures;
+  std::printf("%s: two-pass pipeline, %d failures\n", failures ? "FAIL" : "ok", failures);
+  return failures ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::strcmp(argv[1], "--two-pass") == 0) {
+    MetalRenderContext ctx;
+    MetalBT709Decoder dec;
+    dec.metalRenderContext = &ctx;
+    if (!dec.setupMetal()) return 3;
+    return run_two_pass(ctx, dec);
+  }
   const bool host = argc > 1 && std::strcmp(argv[1], "--host") == 0;
   if (host) {
     --argc;

@@ -785,6 +785,15 @@ def test_cpp_host_mirror_host_memory_overload(gh, vectors, tmp_path):
     assert "28 host vectors, 0 failures" in res.stdout
 
 
+def test_cpp_host_mirror_two_pass_pipeline(gh, tmp_path):
+    """C++ mirror of MetalScaleRenderContext: pass 1 into a BGRA8 / RGBA16Float intermediate, pass 2 on its
+    own; the BGRA8 route must equal the fused decodeBT709Scaled."""
+    import subprocess
+    from test_host_cpu import build_cpp_selftest
+    res = subprocess.run([build_cpp_selftest(tmp_path), "--two-pass"], capture_output=True, text=True)
+    assert res.returncode == 0 and "two-pass pipeline, 0 failures" in res.stdout, res.stdout + res.stderr
+
+
 def test_cpp_host_mirror_reference_vectors(gh, vectors, tmp_path):
     """The C++ twin of the reference's Metal decode test (host/decoder_selftest.cpp over
     host/MetalBT709Decoder.hpp) on the 28 reference vectors."""

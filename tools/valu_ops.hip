@@ -49,6 +49,36 @@
 #define CMP(i) "v_cmp_ge_f32 vcc, %" #i ", %8\n"
 #define CNDS(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 
+// packed f32: operands are VGPR pairs (float2), two results per instruction
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define KERNEL2(NAME, ASMSTR)                                                                      \
+  __global__ void __launch_bounds__(256) NAME(float *out, int iters, long long *cyc) {             \
+    f2 a0 = {threadIdx.x * 0.001f, 1.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f; \
+    f2 b = {1.0001f + blockIdx.x * 1e-7f, 0.9999f};                                              \
+    long long t0 = clock64();                                                                     \
+    for (int it = 0; it < iters; ++it) {                                                          \
+      asm volatile(ASMSTR : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)); \
+    }                                                                                             \
+    long long t1 = clock64();                                                                     \
+    const f2 r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                           \
+    out[blockIdx.x * 256 + threadIdx.x] = r.x + r.y;                                              \
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;                                      \
+  }
+#define PKADD(i) "v_pk_add_f32 %" #i ", %" #i ", %8\n"
+#define PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
+#define PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %8\n"
+#define PKADDC(i) "v_pk_add_f32 %" #i ", %" #i ", %8 clamp\n"
+#define MED3(i) "v_med3_f32 %" #i ", %" #i ", %8, %8\n"
+#define SUBF(i) "v_sub_f32 %" #i ", %" #i ", %8\n"
+#define ADDCL(i) "v_add_f32_e64 %" #i ", %" #i ", %8 clamp\n"
+KERNEL2(k_pkadd, S8(X8(PKADD)))
+KERNEL2(k_pkmul, S8(X8(PKMUL)))
+KERNEL2(k_pkfma, S8(X8(PKFMA)))
+KERNEL2(k_pkaddc, S8(X8(PKADDC)))
+KERNEL(k_med3, S8(X8(MED3)))
+KERNEL(k_sub, S8(X8(SUBF)))
+KERNEL(k_addcl, S8(X8(ADDCL)))
+
 KERNEL(k_add, S8(X8(ADD)))
 KERNEL(k_mul, S8(X8(MUL)))
 KERNEL(k_fma, S8(X8(FMA)))
@@ -94,8 +124,10 @@ int main() {
       {"v_and_or_b32", k_andor, 64}, {"v_cmp+v_cndmask", k_cmpsel, 128}, {"v_cmp+v_addc", k_cmpaddc, 128},
       {"v_cmp_ge_f32", k_cmp, 64}, {"v_cndmask_b32", k_cnd, 64}, {"v_perm_b32", k_perm, 64},
       {"v_or3_b32", k_or3, 64}, {"v_lshl_add_u32", k_lshladd, 64}, {"v_add_u32_sdwa", k_sdwa, 64},
-      {"v_mov_b32", k_mov, 64}};
-  for (int w : {1, 4, 8})
+      {"v_mov_b32", k_mov, 64}, {"v_med3_f32", k_med3, 64}, {"v_sub_f32", k_sub, 64}, {"v_add_f32 clamp (e64)", k_addcl, 64},
+      {"v_pk_add_f32 (2 results)", k_pkadd, 64}, {"v_pk_mul_f32 (2 results)", k_pkmul, 64},
+      {"v_pk_fma_f32 (2 results)", k_pkfma, 64}, {"v_pk_add_f32 clamp", k_pkaddc, 64}};
+  for (int w : {1, 2, 4, 8})
     for (auto &k : ks) run(k.n, k.k, k.per, d, dc, w);
   return 0;
 }
