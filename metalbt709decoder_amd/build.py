@@ -90,7 +90,10 @@ def build_variant(out_path, defines):
     """A second build of the library with extra -D flags (e.g. BT709_INDEX_RTZ), for same-call A/B
     runs: bench.py --library <out_path>.  Never replaces the in-tree library."""
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, *FLAGS, *["-D" + d for d in defines], "-shared",
+    # items starting with "-" are raw compiler flags (e.g. -fslp-vectorize), the rest -D macros
+    extra = [d if d.startswith("-") else "-D" + d for d in defines]
+    flags = [f for f in FLAGS if not ("-fslp-vectorize" in extra and f == "-fno-slp-vectorize")]
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, *flags, *extra, "-shared",
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", out_path]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # 1:1 kernel: does the placement of rows / frames in memory matter? (runs on the GPU box)
-run() { echo "== $*"; env "$@" timeout 120 tools/bin/decode_lab 0 5 | head -1; }
+run() { echo "== $*"; env "$@" timeout 120 tools/bin/decode_lab_fma 0 5 | head -1; }
 run LAB_ROW_PAD=0
 run LAB_ROW_PAD=256
 run LAB_ROW_PAD=1024

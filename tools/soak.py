@@ -1,5 +1,7 @@
-"""Random soak of the decode / 2:1 / any-ratio paths against the oracle (runs on the GPU box):
+"""Random soak of every GPU path against the oracle (runs on the GPU box):
     python tools/soak.py [seed] [cases]
+decode (opaque / alpha, 8-bit and RGBA16Float targets), exact 2:1 (both kernels, with alpha), any-ratio
+(with alpha), the reference's two passes through both intermediate formats, the encoder.
 Fresh seeds every time it is used; the committed tests hold the fixed-seed fuzz."""
 import os
 import sys
@@ -12,25 +14,47 @@ from metalbt709decoder_amd import _capi
 oracle = Oracle()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ctx = gh.context()
-bad = 0
+scale = mb.MetalScaleRenderContext(); assert scale.setupRenderPipelines(ctx)
+bad, counts = 0, {}
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
-    kind = int(rng.integers(0, 3))
+    kind = int(rng.integers(0, 6))
+    counts[kind] = counts.get(kind, 0) + 1
     gamma = int(rng.integers(0, 4))
     w = 4 * int(rng.integers(1, 600)); h = 4 * int(rng.integers(1, 40))
-    y, c = gh.random_nv12(w, h, seed=int(rng.integers(0, 1 << 30)))
+    y, c = gh.random_nv12(w, h, seed=int(rng.integers(0, 1 << 30)), legal=bool(rng.integers(0, 4) == 0))
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8) if rng.integers(0, 3) == 0 else None
+    g = gamma if a is None else mb.MetalBT709GammaSRGB
     if kind == 0:
-        a = rng.integers(0, 256, (h, w), dtype=np.uint8) if rng.integers(0, 3) == 0 else None
-        got = gh.gpu_decode(y, c, gamma if a is None else mb.MetalBT709GammaSRGB, alpha=a)
-        want = oracle.decode_nv12(gamma if a is None else mb.MetalBT709GammaSRGB, y, c, alpha=a)
+        got = gh.gpu_decode(y, c, g, alpha=a); want = oracle.decode_nv12(g, y, c, alpha=a)
     elif kind == 1:
-        dec = gh.make_decoder(gamma, options={_capi.OPT_HALF_KERNEL: int(rng.integers(0, 2)),
-                                              _capi.OPT_HALF_WORKGROUPS: int(rng.integers(1, 400))})
-        got = gh.gpu_decode_half(y, c, gamma, decoder=dec); want = oracle.decode_nv12_half(gamma, y, c)
-    else:
+        dec = gh.make_decoder(g, has_alpha=a is not None, options={_capi.OPT_HALF_KERNEL: int(rng.integers(-1, 2)),
+                                                                    _capi.OPT_HALF_WORKGROUPS: int(rng.integers(1, 400))})
+        got = gh.gpu_decode_half(y, c, g, decoder=dec, alpha=a); want = oracle.decode_nv12_half(g, y, c, alpha=a)
+    elif kind == 2:
         ow, oh = int(rng.integers(1, 2 * w)), int(rng.integers(1, 2 * h))
-        dec = gh.make_decoder(gamma); buf = gh.make_buffer(y, c, dec.gamma); tex = ctx.makeBGRATexture((ow, oh))
-        assert dec.decodeBT709Scaled(buf, tex, None, True)
-        got = ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(oh, ow * 4); want = oracle.decode_nv12_scaled(gamma, y, c, ow, oh)
-    if not np.array_equal(got, want):
-        bad += 1; print("MISMATCH", case, kind, gamma, w, h)
-print("soak done, mismatches:", bad)
+        got = gh.gpu_decode_scaled(y, c, (ow, oh), g, alpha=a); want = oracle.decode_nv12_scaled(g, y, c, ow, oh, alpha=a)
+    elif kind == 3:  # RGBA16Float target
+        dec = gh.make_decoder(g, has_alpha=a is not None)
+        tex = ctx.makeBGRATexture((w, h), pixelFormat=mb.MTLPixelFormatRGBA16Float)
+        assert dec.decodeBT709(gh.make_buffer(y, c, dec.gamma), gh.make_alpha_buffer(a) if a is not None else None, tex, None, None, w, h, True)
+        got = ctx.getBGRATexturePixels(tex).view(np.uint16); want = oracle.decode_nv12_rgba16f(g, y, c, alpha=a).view(np.uint16)
+    elif kind == 4:  # two passes, either intermediate
+        fmt = mb.MTLPixelFormatRGBA16Float if rng.integers(0, 2) else mb.MTLPixelFormatBGRA8Unorm_sRGB
+        ow, oh = int(rng.integers(1, 2 * w)), int(rng.integers(1, 2 * h))
+        dec = gh.make_decoder(g, has_alpha=a is not None)
+        inter, view = ctx.makeBGRATexture((w, h), pixelFormat=fmt), ctx.makeBGRATexture((ow, oh))
+        assert dec.decodeBT709(gh.make_buffer(y, c, dec.gamma), gh.make_alpha_buffer(a) if a is not None else None, inter, None, None, w, h, False)
+        assert scale.renderScaled(ctx, view, ow, oh, None, None, inter, True)
+        got = ctx.getBGRATexturePixels(view).view(np.uint8).reshape(oh, ow * 4)
+        src = oracle.decode_nv12_rgba16f(g, y, c, alpha=a) if fmt == mb.MTLPixelFormatRGBA16Float else oracle.decode_nv12(g, y, c, alpha=a)
+        want = oracle.render_scaled(src, ow, oh)
+    else:  # encoder: BGRA -> NV12, then compare planes
+        ig, og = [(1, 0), (1, 1), (2, 2), (0, 0), (1, 2)][int(rng.integers(0, 5))]
+        bgra = rng.integers(0, 1 << 32, w * h, dtype=np.uint32)
+        tex = ctx.makeBGRATexture((w, h), pixels=bgra); buf = mb.CVPixelBuffer(ctx, w, h)
+        assert mb.BGRAToBT709Converter.convertIntoCoreVideoBuffer(tex, buf, ig, og)
+        gy, gc = buf.download_planes(); wy, wc = oracle.encode_nv12(bgra, w, h, ig, og)
+        got, want = np.concatenate([gy.reshape(-1), gc.reshape(-1)]), np.concatenate([wy.reshape(-1), wc.reshape(-1)])
+    if got is None or not np.array_equal(got, want):
+        bad += 1; print("MISMATCH", case, kind, g, w, h, a is not None)
+print("soak done:", sum(counts.values()), "cases by kind", dict(sorted(counts.items())), "mismatches:", bad)
