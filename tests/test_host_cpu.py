@@ -259,12 +259,20 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
     for kernel in ("17decode_nv12_quads", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
                    "18decode_nv12_scaled", "19decode_nv12_rgba16f", "13render_scaled"):
         for body in _kernel_bodies(asm, kernel):
+            packed = 0
             for line in re.findall(r"^\s*(v_(?:pk_)?(?:fma|fmac|fmamk|fmaak|mad|mac|madmk|madak)_(?:f32|f16|legacy|mix)\w*\s[^\n]*)", body, flags=re.M):
+                if line.startswith("v_pk_fma_f32"):  # the persistent 2:1 kernel's centre_norm2: constants ride in VGPR pairs
+                    packed += 1
+                    continue
                 assert re.match(r"v_fmamk_f32 v\d+, v\d+, 0x3b808081, v\d+|v_fmac_f32_e32 v\d+, 0x3b808081, v\d+", line), (kernel, line)
                 fused += 1
+            # one packed fma per PAIR of converted bytes, only in the kernel that pairs its two output pixels
+            assert packed == (len(re.findall(r"\bv_cvt_f32_ubyte[0-3]", body)) // 2 if kernel == "20decode_nv12_half_rep" else 0), kernel
             n += 1
     assert n == 32  # every instantiation the launchers can pick
     assert fused > 300
+    rep = _kernel_body(asm, "20decode_nv12_half_repILb1E")  # and the pair's other packed ops are plain IEEE adds / multiplies
+    assert set(re.findall(r"\bv_pk_\w+", rep)) <= {"v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_pk_mov_b32"}
 
 
 def test_isa_memory_shape(asm):
@@ -315,6 +323,22 @@ def test_isa_valu_budget_contract(asm):
     assert "ds_read_b128" in rep and not re.search(r"\bv_cvt_u32_f32\b.*\n.*v_and_or", rep)
     enc = _kernel_body(asm, "16encode_bgra_nv12E")
     assert enc.count("v_cvt_pk_u8_f32") == 12 and enc.count("v_lshlrev_b32_sdwa") == 24
+
+
+def test_integration_doc_shows_the_shipped_objc_binding():
+    """INTEGRATION.md section 2 embeds objc/MetalBT709Decoder+HIP.m verbatim (from its first #import), and
+    that file implements the reference's selector unchanged (Renderer/MetalBT709Decoder.h:65-72)."""
+    src = open(os.path.join(ROOT, "objc", "MetalBT709Decoder+HIP.m")).read()
+    body = src[src.index('#import "MetalBT709Decoder.h"'):]
+    assert body in open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    flat = re.sub(r"\s+", "", body)
+    for part in ("-(BOOL)decodeBT709:(CVPixelBufferRef)yCbCrPixelBuffer", "alphaPixelBuffer:(CVPixelBufferRef)alphaPixelBuffer",
+                 "bgraSRGBTexture:(id<MTLTexture>)bgraSRGBTexture", "commandBuffer:(id<MTLCommandBuffer>)commandBuffer",
+                 "renderPassDescriptor:(MTLRenderPassDescriptor*)renderPassDescriptor", "renderWidth:(int)renderWidth",
+                 "renderHeight:(int)renderHeight", "waitUntilCompleted:(BOOL)waitUntilCompleted", "-(BOOL)setupMetal"):
+        assert part in flat, part
+    for call in ("bt709hip_pool_acquire", "bt709hip_pool_submit", "bt709hip_pool_wait", "bt709hip_pool_alpha_plane"):
+        assert call in body
 
 
 def test_product_never_touches_the_oracle():
