@@ -230,110 +230,6 @@ __device__ __forceinline__ u32x2 half_quad(const RescaleLookup &r, uint32_t ya, 
   return v;
 }
 
-// ---- the same quad with PACKED f32 arithmetic (persistent kernel only) -----------------------------
-// The two output pixels of a quad run the same instruction sequence on different bytes, so every
-// add / multiply / fma that is not tied to a table lookup is done for both at once on a VGPR pair
-// (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32 [clamp]): one issue slot, two IEEE binary32 results,
-// each rounded exactly as its scalar twin.  At this kernel's occupancy (4 waves per SIMD, some of them
-// always waiting on LDS) a wave cannot issue more than one VALU instruction every ~4 cycles, so the
-// instruction COUNT is what costs; the lookups themselves (address, read, subtract,
-// median, compare) stay scalar.  Pair component .x = output pixel 0 (source columns 0,1), .y = pixel 1.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x2 pk_add_sat(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-  f32x2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
-// bytes LO and HI of a word as floats, one per pixel of the pair
-template <int LO, int HI>
-__device__ __forceinline__ f32x2 byte_pair(uint32_t w) {
-  f32x2 r;
-  r.x = byte_of(w, LO);
-  r.y = byte_of(w, HI);
-  return r;
-}
-// (byte - off) / 255f for both pixels: the one provably exact fma (bt709_device.h centre_norm), packed
-__device__ __forceinline__ f32x2 centre_norm2(f32x2 v, float off) { return pk_fma(v, splat(kInv255), splat(-off * kInv255)); }
-
-// linear-light values (times 2^-40) of four saturated channel values of BOTH pixels: 8 lookups
-__device__ __forceinline__ void linearise4x2(const RescaleLookup &r, const f32x2 *x, f32x2 *lin) {
-  f32x2 t[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) t[i] = pk_add(x[i], splat(r.magic));  // bits(magic) + bucket index, both pixels
-  u32x4 e[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    e[2 * i] = *reinterpret_cast<LdsQuadPtr>((__float_as_uint(t[i].x) << r.dec_shift) + r.dec_off);
-    e[2 * i + 1] = *reinterpret_cast<LdsQuadPtr>((__float_as_uint(t[i].y) << r.dec_shift) + r.dec_off);
-  }
-  asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]));  // one wait
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lin[i].x = __builtin_amdgcn_fmed3f(__uint_as_float(e[2 * i].y), __uint_as_float(e[2 * i].z),
-                                       __fadd_rn(x[i].x, -__uint_as_float(e[2 * i].x)));
-    lin[i].y = __builtin_amdgcn_fmed3f(__uint_as_float(e[2 * i + 1].y), __uint_as_float(e[2 * i + 1].z),
-                                       __fadd_rn(x[i].y, -__uint_as_float(e[2 * i + 1].x)));
-  }
-}
-
-// sum of the four taps of one channel for both pixels, then its two sRGB bytes (uniform encode table)
-__device__ __forceinline__ void encode_pair(const RescaleLookup &r, const f32x2 *lin, uint32_t &byte0, uint32_t &byte1) {
-  const f32x2 s = pk_add(pk_add(pk_add(lin[0], lin[1]), lin[2]), lin[3]);  // (((a+b)+c)+d), per pixel
-  const f32x2 tt = pk_add(pk_mul(s, splat(r.sum_to_xs)), splat(8388608.0f));
-  const u32x2 e0 = *reinterpret_cast<LdsPairPtr>((__float_as_uint(tt.x) << r.enc_shift) + r.enc_u_off);
-  const u32x2 e1 = *reinterpret_cast<LdsPairPtr>((__float_as_uint(tt.y) << r.enc_shift) + r.enc_u_off);
-  byte0 = e0.y + (s.x >= __uint_as_float(e0.x) ? 1u : 0u);
-  byte1 = e1.y + (s.y >= __uint_as_float(e1.x) ? 1u : 0u);
-}
-
-__device__ __forceinline__ u32x2 half_quad_packed(const RescaleLookup &r, uint32_t ya, uint32_t yb, uint32_t cw,
-                                                  uint32_t alpha_word) {
-  // chroma products of both blocks: pixel 0 uses (Cb, Cr) = bytes 0,1 of cw, pixel 1 bytes 2,3
-  const f32x2 cbn = centre_norm2(byte_pair<0, 2>(cw), 128.0f), crn = centre_norm2(byte_pair<1, 3>(cw), 128.0f);
-  const f32x2 cr_r = pk_mul(crn, splat(kMCrR)), cb_g = pk_mul(cbn, splat(kMCbG)), cr_g = pk_mul(crn, splat(kMCrG)),
-              cb_b = pk_mul(cbn, splat(kMCbB));
-  // luma terms of the four source pixels of each output pixel: top-left, top-right, bottom-left, bottom-right
-  const f32x2 yv[4] = {pk_mul(centre_norm2(byte_pair<0, 2>(ya), 16.0f), splat(kMY)),
-                       pk_mul(centre_norm2(byte_pair<1, 3>(ya), 16.0f), splat(kMY)),
-                       pk_mul(centre_norm2(byte_pair<0, 2>(yb), 16.0f), splat(kMY)),
-                       pk_mul(centre_norm2(byte_pair<1, 3>(yb), 16.0f), splat(kMY))};
-  f32x2 x[4], lin[4];
-  uint32_t R0, R1, G0, G1, B0, B1;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = pk_add_sat(yv[i], cr_r);  // R = ((Yn*My) + 0) + (Crn*McrR), saturated
-  linearise4x2(r, x, lin);
-  encode_pair(r, lin, R0, R1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = pk_add_sat(pk_add(yv[i], cb_g), cr_g);  // G: reference order (BT709.h:425)
-  linearise4x2(r, x, lin);
-  encode_pair(r, lin, G0, G1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = pk_add_sat(yv[i], cb_b);
-  linearise4x2(r, x, lin);
-  encode_pair(r, lin, B0, B1);
-  u32x2 v;
-  v.x = pack_bgra(R0, G0, B0, alpha_word);
-  v.y = pack_bgra(R1, G1, B1, alpha_word);
-  return v;
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -437,13 +333,9 @@ constexpr bool kRepUniformEncode = false;
 #else
 constexpr bool kRepUniformEncode = true;
 #endif
-// packed f32 arithmetic for the two output pixels of a quad (half_quad_packed; needs the uniform encode table);
-// -DBT709_REP_SCALAR builds the scalar form for A/B runs
-#if defined(BT709_REP_SCALAR) || defined(BT709_REP_SPLIT_ENCODE)
-constexpr bool kRepPacked = false;
-#else
-constexpr bool kRepPacked = true;
-#endif
+// (A form that runs the quad's two output pixels on VGPR pairs -- v_pk_fma/mul/add_f32, 25 % fewer
+// instructions -- measured 4.7 % SLOWER in the same call, profiles/r02_ab_half_packed_f32.txt: packed f32 ops
+// run at half rate, so the VALU cycles do not change, and the pairing costs scheduling freedom.  Commit e0a028e.)
 
 struct TileCursor {
   uint32_t tx, rp, f;
@@ -535,8 +427,7 @@ decode_nv12_half_rep(const DecodeParams p) {
     for (int u = 0; u < U; ++u) {
       const bool have = t + u * G < p.tile_rows;
       const TileCursor c = {have ? cur.tx : first.tx, have ? cur.rp : first.rp, have ? cur.f : first.f};
-      const u32x2 v = kRepPacked ? half_quad_packed(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word)
-                                 : half_quad<kRepUniformEncode>(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word, p.alpha_word);
+      const u32x2 v = half_quad<kRepUniformEncode>(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word, p.alpha_word);
       const FramePlanes f = frame_planes(p, c.f);
       uint8_t *o = f.out + static_cast<size_t>(c.rp) * p.out_stride;
       // lanes past the row's end loaded the last quad (clamp), hold its result and store it again
