@@ -747,6 +747,50 @@ def test_lazily_built_tables_are_refused_inside_a_capture(gh, oracle):
     cb.release()
 
 
+def test_copy_probe_and_stream_join(gh):
+    """The benchmark's copy ceiling really copies (every byte, odd multiples of 16 included, nothing
+    beyond), and bt709hip_stream_wait_event orders two streams without blocking the host."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    lib, h = ctx.lib, ctx.handle
+    rng = np.random.default_rng(5)
+    for nbytes in (16, 16 * 1023, 16 * 1025, 16 * 70001):
+        src = rng.integers(0, 256, (1, nbytes), dtype=np.uint8)
+        a, b = DeviceBuffer(ctx, nbytes), DeviceBuffer(ctx, nbytes + 64)
+        ctx._upload(a.ptr, nbytes, src, None)
+        _capi.check(lib.bt709hip_memset(h, b.ptr, 0x5A, nbytes + 64, None))
+        _capi.check(lib.bt709hip_copy_probe(h, b.ptr, a.ptr, nbytes, None))
+        out = np.empty((1, nbytes + 64), np.uint8)
+        _capi.check(lib.bt709hip_download(h, out.ctypes.data, nbytes + 64, b.ptr, nbytes + 64, nbytes + 64, 1, None))
+        ctx._sync(None)
+        assert np.array_equal(out[0, :nbytes], src[0]) and (out[0, nbytes:] == 0x5A).all()
+    assert lib.bt709hip_copy_probe(h, b.ptr, a.ptr, 24, None) == _capi.ERR_INVALID_ARG      # not a multiple of 16
+    assert lib.bt709hip_copy_probe(h, b.ptr + 4, a.ptr, 16, None) == _capi.ERR_INVALID_ARG  # misaligned
+    # producer on stream 1, consumer on stream 2 joined by an event: decode A -> copy A's pixels elsewhere
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    w, hgt = 256, 64
+    y, c = gh.random_nv12(w, hgt, seed=91)
+    buf, tex = gh.make_buffer(y, c, dec.gamma), ctx.makeBGRATexture((w, hgt))
+    dst = DeviceBuffer(ctx, w * hgt * 4)
+    cb1, cb2 = ctx.commandQueue.commandBuffer(new_stream=True), ctx.commandQueue.commandBuffer(new_stream=True)
+    ev = C.c_void_p()
+    _capi.check(lib.bt709hip_event_create(h, C.byref(ev)))
+    for _ in range(20):
+        assert dec.decodeBT709(buf, None, tex, cb1, None, w, hgt, False)
+    _capi.check(lib.bt709hip_event_record(h, ev, cb1.stream))
+    _capi.check(lib.bt709hip_stream_wait_event(h, cb2.stream, ev))
+    _capi.check(lib.bt709hip_copy_probe(h, dst.ptr, tex.ptr, w * hgt * 4, cb2.stream))
+    cb2.waitUntilCompleted()
+    got = np.empty((hgt, w * 4), np.uint8)
+    _capi.check(lib.bt709hip_download(h, got.ctypes.data, w * 4, dst.ptr, w * 4, w * 4, hgt, cb2.stream))
+    cb2.waitUntilCompleted()
+    assert np.array_equal(got, gh.gpu_decode(y, c, decoder=dec))
+    assert lib.bt709hip_stream_wait_event(h, cb2.stream, None) == _capi.ERR_INVALID_ARG
+    lib.bt709hip_event_destroy(h, ev)
+    cb1.release()
+    cb2.release()
+
+
 def test_empty_frame_is_a_noop(gh):
     ctx = gh.context()
     dec = gh.make_decoder(mb.MetalBT709GammaApple)
