@@ -132,7 +132,8 @@ struct Variant {
 int main(int argc, char **argv) {
   const int gamma = argc > 1 ? std::atoi(argv[1]) : 0;
   const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
-  Ring r(3840, 2160, 64, 32, gamma);
+  const int batch = argc > 3 ? std::atoi(argv[3]) : 32;  // frames per launch (1: the config-5 unit at 8 GPUs)
+  Ring r(3840, 2160, 64, batch, gamma);
   hipStream_t s = r.s;
   std::vector<Variant> vs;
   auto add = [&](const std::string &n, std::function<void(int)> f) { vs.push_back({n, f, {}}); };
