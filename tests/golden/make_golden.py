@@ -130,6 +130,23 @@ def collect_vectors():
                 "test": name, "src": "EmptyiOSTests/CoreImageMetalFilterTests.m:%d" % line,
                 "rgb_in": [env["Rin"], env["Gin"], env["Bin"]], "ycbcr": ycc, "rgb_out": rgb,
                 "calls": calls, "applyGammaMap": flag})
+    # 4. 2x2 averaging tests: BT709_average_pixel_values(R1..B4, inputGamma, outputGamma) -> Y1..Y4, Cb, Cr
+    #    (the encoder's per-block function, CoreImageMetalFilterTests.m:1683-2096)
+    out["average_blocks"] = []
+    gam = {"BT709GammaApple": 0, "BT709GammaSrgb": 1, "BT709GammaLinear": 2}
+    for name, line, body in methods(f):
+        if "BT709_average_pixel_values" not in body:
+            continue
+        vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"\bint\s+([RGB][1-4])\s*=\s*(\d+)\s*;", body)}
+        gi = re.search(r"inputGamma\s*=\s*(BT709Gamma\w+)", body)
+        go = re.search(r"outputGamma\s*=\s*(BT709Gamma\w+)", body)
+        _, expects, _, _, _ = parse_method(body)
+        want = triple(expects, ["Y1", "Y2", "Y3", "Y4", "Cb", "Cr"])
+        if len(vals) == 12 and gi and go and want:
+            out["average_blocks"].append({
+                "test": name, "src": "EmptyiOSTests/CoreImageMetalFilterTests.m:%d" % line,
+                "rgb": [vals[c + str(i)] for i in range(1, 5) for c in "RGB"],
+                "in": gam[gi.group(1)], "out": gam[go.group(1)], "y4cbcr": want})
     return out
 
 

@@ -102,6 +102,16 @@ def test_gpu_encoder_reference_blocks(gh, refdata):
 
 
 @pytest.mark.gpu
+def test_gpu_encoder_xctest_average_of_4_vectors(gh, vectors):
+    """The reference's own asserted 2x2-averaging numbers (CoreImageMetalFilterTests.m:1683-2096), through the GPU encoder."""
+    for b in vectors["average_blocks"]:
+        rgb = b["rgb"]
+        words = np.array([(rgb[3 * i] << 16) | (rgb[3 * i + 1] << 8) | rgb[3 * i + 2] for i in range(4)], np.uint32)
+        y, c = gpu_encode(gh, words, 2, 2, b["in"], b["out"])
+        assert [int(y[0, 0]), int(y[0, 1]), int(y[1, 0]), int(y[1, 1]), int(c[0, 0]), int(c[0, 1])] == b["y4cbcr"], b["test"]
+
+
+@pytest.mark.gpu
 def test_gpu_encoder_all_grey_levels_and_primaries(gh, oracle):
     cols = [(v, v, v) for v in range(256)] + [(255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 0), (0, 255, 255),
                                               (255, 0, 255)]

@@ -139,6 +139,15 @@ def test_subsample_blocks(oracle, refdata):
         assert list(oracle.subsample_block(b["rgb"], b["in"], b["out"])) == b["y4cbcr"]
 
 
+def test_xctest_average_of_4_vectors(oracle, vectors):
+    """The five 2x2-averaging expectations the reference's own XCTest file asserts
+    (CoreImageMetalFilterTests.m:1683-2096: BT709_average_pixel_values with sRGB input and sRGB /
+    Apple / linear output): Y1..Y4 and the averaged Cb, Cr."""
+    assert len(vectors["average_blocks"]) == 5
+    for b in vectors["average_blocks"]:
+        assert list(oracle.subsample_block(b["rgb"], b["in"], b["out"])) == b["y4cbcr"], b["test"]
+
+
 def test_bundled_pattern_crops(oracle, refdata, patterns):
     """Crops of the reference's bundled test images, NV12-encoded and decoded by the
     reference headers; the oracle must reproduce every output byte in every gamma."""
