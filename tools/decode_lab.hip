@@ -62,8 +62,25 @@ struct Ring {
     ob = os * H;
     in_stride = (yb + cb + 255) / 256 * 256 + frame_pad;
     out_stride = ob + frame_pad;
-    CK(hipMalloc(&d_in, in_stride * ring));
-    CK(hipMalloc(&d_out, out_stride * ring));
+    // LAB_ALLOC: 0 hipMalloc (default) | 1 output slab uncached | 2 both slabs uncached | 3 output fine-grained
+    const int alloc = std::getenv("LAB_ALLOC") ? std::atoi(std::getenv("LAB_ALLOC")) : 0;
+    //            4 one allocation for both slabs (in, then out at a 2 MiB boundary) | 5 out slab allocated before the in slab
+    if (alloc == 4) {
+      const size_t gap = std::getenv("LAB_GAP_KB") ? size_t(std::atoll(std::getenv("LAB_GAP_KB"))) << 10 : 0;
+      const size_t in_bytes = (in_stride * ring + (2u << 20) - 1) / (2u << 20) * (2u << 20) + gap;
+      CK(hipMalloc(&d_in, in_bytes + out_stride * ring));
+      d_out = d_in + in_bytes;
+    } else if (alloc == 5) {
+      CK(hipMalloc(&d_out, out_stride * ring));
+      CK(hipMalloc(&d_in, in_stride * ring));
+    } else
+    if (alloc == 2) CK(hipExtMallocWithFlags(reinterpret_cast<void **>(&d_in), in_stride * ring, hipDeviceMallocUncached));
+    else CK(hipMalloc(&d_in, in_stride * ring));
+    if (alloc == 4 || alloc == 5) {
+    } else
+    if (alloc == 1 || alloc == 2) CK(hipExtMallocWithFlags(reinterpret_cast<void **>(&d_out), out_stride * ring, hipDeviceMallocUncached));
+    else if (alloc == 3) CK(hipExtMallocWithFlags(reinterpret_cast<void **>(&d_out), out_stride * ring, hipDeviceMallocFinegrained));
+    else CK(hipMalloc(&d_out, out_stride * ring));
     std::vector<uint8_t> h8(in_stride);
     uint64_t st = 0x709;
     for (int i = 0; i < ring; ++i) {
@@ -77,6 +94,9 @@ struct Ring {
       }
       CK(hipMemcpy(d_in + i * in_stride, h8.data(), h8.size(), hipMemcpyHostToDevice));
     }
+    std::printf("slabs: in %p  out %p  (out - in) = %lld KiB, in %% 1GiB = %llu KiB, out %% 1GiB = %llu KiB\n", (void *)d_in, (void *)d_out,
+                (long long)((intptr_t)d_out - (intptr_t)d_in) / 1024, (unsigned long long)((uintptr_t)d_in % (1ull << 30)) / 1024,
+                (unsigned long long)((uintptr_t)d_out % (1ull << 30)) / 1024);
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
