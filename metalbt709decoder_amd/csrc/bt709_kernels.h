@@ -68,7 +68,7 @@ struct DecodeParams {
   // decode_nv12_scaled only: output size and source-per-output-pixel ratios W/OW, H/OH (float)
   uint32_t out_width, out_height;
   float scale_x, scale_y;
-  uint32_t scaled_rows;  // output rows a workgroup walks (filled by launch_decode_scaled)
+  uint32_t scaled_rows;  // output rows of a strip (filled by launch_decode_scaled)
   // uniform != 0: frame i = frames[0] + i * step_* (bytes); lets one launch cover any number of frames
   uint32_t uniform;
   int64_t step_y, step_cbcr, step_alpha, step_out;
@@ -190,6 +190,7 @@ constexpr uint32_t kRepLdsBytes = 160 * 1024;
 
 // scaled: grid = (ceil(OW / kBlockThreads), ceil(OH / rows), frames) x kBlockThreads, rows chosen from the CU count.
 // in_align: largest power of two dividing every input plane pointer, pitch and frame spacing (picks the tap fetch width).
+// nullptr: a plane of 2 GiB or more (row offsets are formed in 32 bits)
 const char *launch_decode_scaled(const DecodeParams &p, int frames, bool has_alpha, uint32_t in_align,
                                  uint32_t compute_units, hipStream_t stream);
 

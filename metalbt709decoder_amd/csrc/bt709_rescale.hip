@@ -48,9 +48,11 @@ struct RescaleLookup {
 
 // Stages both tables in 2^r1 / 2^r2 interleaved copies (0 / 0: plain) and returns the lookup
 // constants of this lane.  The caller synchronises.
+// sum_log2 (uniform encode table only): the value handed to encode_byte_uniform is 2^sum_log2 times the
+// mean -- 2 for the four-tap sum of the exact 2:1 kernel, 0 for the weighted sum of the any-ratio one.
 template <bool UNIFORM_ENCODE = false>
 __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds_raw, const DecodeParams &p, uint32_t r1,
-                                                              uint32_t r2) {
+                                                              uint32_t r2, uint32_t sum_log2 = 2) {
   const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
   u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
   const u32x4 *src = reinterpret_cast<const u32x4 *>(p.table_linear);
@@ -62,7 +64,7 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   const uint32_t n2 = ((UNIFORM_ENCODE ? p.table_encode_u_bytes : p.table_encode_bytes) / 8) << r2;
   if (UNIFORM_ENCODE) {
     // edges move into the domain of the taps' sum: edge * 4 * 2^-40 (a power of two: exact; +inf stays +inf)
-    const float to_sum = __uint_as_float(static_cast<uint32_t>(127 + 2 + kLinearScaleLog2) << 23);
+    const float to_sum = __uint_as_float(static_cast<uint32_t>(127 + sum_log2 + kLinearScaleLog2) << 23);
     for (uint32_t i = tid; i < n2; i += nthreads) {
       u32x2 e = src2[i >> r2];
       e.x = __float_as_uint(__fmul_rn(__uint_as_float(e.x), to_sum));
@@ -84,7 +86,7 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   const float unscale = __uint_as_float(static_cast<uint32_t>(127 - kLinearScaleLog2) << 23);  // 2^40
   r.scale = __fmul_rn(p.encode_scale, unscale);
   r.quarter_scale = __fmul_rn(0.25f, r.scale);
-  r.quarter_unscale = __fmul_rn(0.25f, unscale);
+  r.quarter_unscale = __fmul_rn(__uint_as_float((127u - sum_log2) << 23), unscale);  // 2^-sum_log2 * 2^40
   r.enc_n = p.encode_u_n;
   r.enc_u_off = r.enc_off - (0x4b000000u << r.enc_shift);
   asm volatile("" : "+v"(r.enc_u_off));  // keep it ONE addend of the v_lshl_add (hipcc otherwise subtracts bits(2^23) per lookup)
@@ -135,6 +137,21 @@ __device__ __forceinline__ void linearise12(const RescaleLookup &r, const float 
       lin[kLinBatch * h + i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z),
                                                        __fadd_rn(x[kLinBatch * h + i], -__uint_as_float(e[i].x)));
   }
+}
+
+// one batch of six (the two horizontal taps of a source row in decode_nv12_scaled)
+__device__ __forceinline__ void linearise6(const RescaleLookup &r, const float *x, float *lin) {
+  const float xp[8] = {x[0], x[1], x[2], x[3], x[4], x[5], 0.0f, 0.0f};
+  uint32_t t[8];
+  u32x4 e[6];
+  magic_index4(xp, t, r.magic);
+  magic_index4(xp + 4, t + 4, r.magic);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) e[i] = *reinterpret_cast<LdsQuadPtr>((t[i] << r.dec_shift) + r.dec_off);
+  asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));  // one wait
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    lin[i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z), __fadd_rn(x[i], -__uint_as_float(e[i].x)));
 }
 
 // Alpha decoders only.  Pass 2 reads the alpha channel of the 8-bit intermediate as a plain unorm
@@ -449,37 +466,44 @@ decode_nv12_half_rep(const DecodeParams p) {
 //   does; v = (((w00*l00 + w01*l01) + w10*l10) + w11*l11) with w00 = (1-fx)(1-fy), ...;
 //   sRGB-encode, quantise.  For an exact 2:1 ratio every weight is 0.25 and this is bit for bit
 //   the decode_nv12_half result.
-// One lane per output column, walking `rows` consecutive output rows (grid = (ceil(OW /
-// blockDim), ceil(OH / rows), frames)): the horizontal tap positions and weights are computed
-// once per lane, the vertical ones are uniform per row (scalar), and the 14 KiB of tables are
-// staged once per workgroup instead of once per 256 output pixels (the first version did that and
-// spent its time staging: 86 Gpixel/s whatever the size).  The next row's taps are fetched
-// before the current row's arithmetic, as widely as the layout allows (12 -> 8 loads per pixel was
-// worth +25 %; 8 -> 4 and the prefetch are neutral: what is left is VALU time -- chroma products
-// per tap, weights and twelve weighted terms, ~600 cycles per output pixel; a replicated-table
-// one-workgroup-per-CU form was measured and is no faster.  140-160 Gpixel/s, one frame per launch):
+// One lane per output column, walking a strip of `rows` consecutive output rows (grid = (ceil(OW /
+// blockDim), strips, frames)): the horizontal tap positions and weights are computed once per lane, the
+// vertical ones once per strip (lane i does row i; rows read them with v_readlane_b32), the 14 KiB of
+// tables are staged once per workgroup.  What round 2 changed (204 -> 240 Gpixel/s on 4K -> 1440p, 439 ->
+// 373 ... see DESIGN 6.5 for every shape):
+//   * the ROW CACHE: which source rows an output row needs is the same for every lane, and consecutive
+//     output rows share source rows whenever the vertical ratio is below 2 (always when enlarging), so
+//     the two linearised rows of the previous output row stay in registers and only rows not seen yet are
+//     decoded (scalar branches); the chroma products are kept the same way (two luma rows share a CbCr
+//     row).  12 lookups per output pixel become 6 * scale_y;
+//   * fetches are unconditional, one output row ahead, in two explicit register sets (see the loop);
+//   * planes are raw buffer resources (scalar row offset, 32-bit lane offset: no VALU address arithmetic).
+// Tap fetch, as wide as the layout allows:
 //   TAPS_WIDE  (planes and strides 4-byte aligned, width % 4 == 0, width >= 8): per source row ONE
-//              aligned 8-byte load that contains both horizontal taps, and one v_perm_b32 with a
-//              per-lane selector (computed once) picks them out: 4 loads per output pixel;
-//   TAPS_PAIRS (CbCr plane 2-byte aligned): a tap's Cb,Cr with one 2-byte load: 8 loads;
-//   TAPS_BYTES any layout: 12 loads.
+//              aligned 8-byte load per plane that contains both horizontal taps, and one v_perm_b32 with
+//              a per-lane selector (computed once) picks them out;
+//   TAPS_PAIRS (CbCr plane 2-byte aligned): a tap's Cb,Cr with one 2-byte load;
+//   TAPS_BYTES any layout: byte loads.
 // 4-byte coalesced stores.
 // ---------------------------------------------------------------------------
-enum : int { TAPS_BYTES = 0, TAPS_PAIRS = 1, TAPS_WIDE = 2 };
+enum : int { TAPS_BYTES = 0, TAPS_PAIRS = 1, TAPS_WIDE = 2, TAPS_SHARED = 3 };
 
-template <int TAPS, bool HAS_ALPHA>
-__global__ void __launch_bounds__(kBlockThreads)
-decode_nv12_scaled(const DecodeParams p) {
-  typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);
-  AlphaLookup al = {};
-  if (HAS_ALPHA) al = stage_alpha_tables(lds_raw + p.table_linear_bytes + p.table_encode_bytes, p);
-  __syncthreads();
-
-  const FramePlanes f = frame_planes(p, blockIdx.z);
-  const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ox >= p.out_width) return;
+// Output column `ox_raw` of frame `f`, output rows [oy0, oy1) (at most 64).
+//   TAPS_BYTES / TAPS_PAIRS / TAPS_WIDE: the lane fetches its own taps (see above); lanes past the
+//     row's end must not call.
+//   TAPS_SHARED (layout as TAPS_WIDE, 64 * scale_x + 12 <= 252): the WAVE fetches a source row -- lane l
+//     loads the l-th dword of the 256-byte span that starts at lane 0's window, one fully coalesced
+//     access per plane (4 cache accesses per wave instruction against ~17 for per-lane 8-byte windows at
+//     4-byte granularity) -- and a lane picks its windows out of its neighbours' registers with four
+//     ds_bpermute_b32 when (and only when) the row is decoded.  Pays when most fetched rows are not
+//     decoded, i.e. when enlarging; the launcher picks it for scale_y < 1.  All 64 lanes must call; `live`
+//     masks the store.
+//   UNIFORM_ENCODE: the encode side goes through the uniform table (staged with sum_log2 = 0).
+template <int TAPS, bool HAS_ALPHA, bool UNIFORM_ENCODE>
+__device__ __forceinline__ void scaled_strip(const DecodeParams &p, const RescaleLookup &r, const AlphaLookup &al,
+                                             const FramePlanes &f, uint32_t ox_raw, uint32_t oy0, uint32_t oy1) {
+  const bool live = ox_raw < p.out_width;
+  const uint32_t ox = TAPS == TAPS_SHARED ? min(ox_raw, p.out_width - 1u) : ox_raw;
 
   const float sx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ox), 0.5f), p.scale_x), -0.5f);
   const float x0f = __builtin_floorf(sx);
@@ -488,109 +512,259 @@ decode_nv12_scaled(const DecodeParams p) {
   const int xi = static_cast<int>(x0f);
   const uint32_t xs[2] = {static_cast<uint32_t>(min(max(xi, 0), wmax)), static_cast<uint32_t>(min(max(xi + 1, 0), wmax))};
   const uint32_t cx[2] = {2u * (xs[0] >> 1), 2u * (xs[1] >> 1)};
-  // TAPS_WIDE: 8-byte windows [ybase, ybase + 8) and [cbase, cbase + 8) hold both taps of a row
+  // TAPS_WIDE / TAPS_SHARED: 8-byte windows [ybase, ybase + 8) and [cbase, cbase + 8) hold both taps of a row
   const uint32_t ybase = min(xs[0] & ~3u, p.width - 8u), cbase = min(cx[0] & ~3u, p.width - 8u);
   const uint32_t ysel = ((xs[1] - ybase) << 8) | (xs[0] - ybase);  // v_perm_b32 selector: {Y0, Y1, -, -}
   const uint32_t k0 = cx[0] - cbase, k1 = cx[1] - cbase;
   const uint32_t csel = ((k1 + 1u) << 24) | (k1 << 16) | ((k0 + 1u) << 8) | k0;  // {Cb0, Cr0, Cb1, Cr1}
+  // TAPS_SHARED: the wave's spans start at lane 0's windows (the windows move right with the lane);
+  // ysrc / csrc = 4 * (lane that holds the first dword of this lane's window): the ds_bpermute address
+  const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const uint32_t wybase = __builtin_amdgcn_readfirstlane(ybase), wcbase = __builtin_amdgcn_readfirstlane(cbase);
+  const uint32_t yoff = min(wybase + 4u * lane, p.width - 4u), coff = min(wcbase + 4u * lane, p.width - 4u);
+  const uint32_t ysrc = ybase - wybase, csrc = cbase - wcbase;
 
-  // vertical taps of an output row: uniform, hence scalar
+  // Vertical taps: the same for every lane.  gfx950 has no scalar float unit, so one evaluation costs 8
+  // VALU instructions per row whichever way it is written; instead lane i works out row oy0 + i of the strip
+  // once (a strip has at most 64 rows) and each row then takes its two numbers with v_readlane_b32 -- which
+  // also puts them in SGPRs, so row offsets and the row-cache tests are scalar work.
   struct RowTaps {
     int ys[2];
     float fy;
   };
+  const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const float sy_l = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy0 + lane_id), 0.5f), p.scale_y), -0.5f);
+  const float y0f_l = __builtin_floorf(sy_l);
+  const float fy_l = __fadd_rn(sy_l, -y0f_l);
+  const int yi_l = static_cast<int>(y0f_l);
   auto row_taps = [&](uint32_t oy) {
     RowTaps rt;
-    const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy), 0.5f), p.scale_y), -0.5f);
-    const float y0f = __builtin_floorf(sy);
-    rt.fy = __fadd_rn(sy, -y0f);
-    const int yi = static_cast<int>(y0f);
+    const int k = static_cast<int>(oy - oy0);
+    rt.fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy_l), k));
+    const int yi = __builtin_amdgcn_readlane(yi_l, k);
     rt.ys[0] = min(max(yi, 0), hmax);
     rt.ys[1] = min(max(yi + 1, 0), hmax);
     return rt;
   };
-  // the source bytes of one output pixel: [row] = {Y0 | Y1 << 8, Cb0 | Cr0 << 8 | Cb1 << 16 | Cr1 << 24, A0 | A1 << 8}
-  struct Fetched {
-    uint32_t yy[2], cc[2], aa[2];
+  // What the loads of one source row return, untouched: nothing consumes a load inside the block that
+  // issues it, so the wait sits in front of the next row's decode, a whole iteration later.
+  struct Fetched1 {
+    uint32_t y[2], c[4], a[2];
   };
-  auto fetch = [&](const RowTaps &rt) {
-    Fetched v;
-#pragma unroll
-    for (int row = 0; row < 2; ++row) {
-      const uint8_t *yrow = f.y + static_cast<size_t>(rt.ys[row]) * p.y_stride;
-      const uint8_t *crow = f.cbcr + static_cast<size_t>(rt.ys[row] >> 1) * p.cbcr_stride;
-      const uint8_t *arow = HAS_ALPHA ? f.alpha + static_cast<size_t>(rt.ys[row]) * p.alpha_stride : nullptr;
-      v.aa[row] = 0;
-      if (TAPS == TAPS_WIDE) {
-        const u32x2a4 yw = *reinterpret_cast<const u32x2a4 *>(yrow + ybase);
-        const u32x2a4 cw = *reinterpret_cast<const u32x2a4 *>(crow + cbase);
-        v.yy[row] = __builtin_amdgcn_perm(yw.y, yw.x, ysel);
-        v.cc[row] = __builtin_amdgcn_perm(cw.y, cw.x, csel);
-        if (HAS_ALPHA) {
-          const u32x2a4 aw = *reinterpret_cast<const u32x2a4 *>(arow + ybase);
-          v.aa[row] = __builtin_amdgcn_perm(aw.y, aw.x, ysel);
-        }
+  // Planes as raw buffer resources: a row's offset rides in the instruction's SCALAR offset operand and the
+  // lane's position in its 32-bit vector offset, so no address is formed in the VALU (with 64-bit global
+  // pointers hipcc kept plane + lane offset in a VGPR pair and added the row offset per load).  The launcher
+  // refuses planes of 2 GiB and more.
+  auto plane = [](const uint8_t *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ry = plane(f.y), rc = plane(f.cbcr), ra = plane(HAS_ALPHA ? f.alpha : f.y), ro = plane(f.out);
+  auto fetch_row = [&](int srow) {
+    Fetched1 v = {};
+    const int yo = srow * static_cast<int>(p.y_stride), co = (srow >> 1) * static_cast<int>(p.cbcr_stride);
+    const int ao = HAS_ALPHA ? srow * static_cast<int>(p.alpha_stride) : 0;
+    if (TAPS == TAPS_SHARED) {
+      v.y[0] = __builtin_amdgcn_raw_buffer_load_b32(ry, yoff, yo, 0);
+      v.c[0] = __builtin_amdgcn_raw_buffer_load_b32(rc, coff, co, 0);
+      if (HAS_ALPHA) v.a[0] = __builtin_amdgcn_raw_buffer_load_b32(ra, yoff, ao, 0);
+    } else if (TAPS == TAPS_WIDE) {
+      const u32x2 yw = __builtin_amdgcn_raw_buffer_load_b64(ry, ybase, yo, 0);
+      const u32x2 cw = __builtin_amdgcn_raw_buffer_load_b64(rc, cbase, co, 0);
+      v.y[0] = yw.x, v.y[1] = yw.y, v.c[0] = cw.x, v.c[1] = cw.y;
+      if (HAS_ALPHA) {
+        const u32x2 aw = __builtin_amdgcn_raw_buffer_load_b64(ra, ybase, ao, 0);
+        v.a[0] = aw.x, v.a[1] = aw.y;
+      }
+    } else {
+      v.y[0] = __builtin_amdgcn_raw_buffer_load_b8(ry, xs[0], yo, 0);
+      v.y[1] = __builtin_amdgcn_raw_buffer_load_b8(ry, xs[1], yo, 0);
+      if (HAS_ALPHA) {
+        v.a[0] = __builtin_amdgcn_raw_buffer_load_b8(ra, xs[0], ao, 0);
+        v.a[1] = __builtin_amdgcn_raw_buffer_load_b8(ra, xs[1], ao, 0);
+      }
+      if (TAPS == TAPS_PAIRS) {
+        v.c[0] = __builtin_amdgcn_raw_buffer_load_b16(rc, cx[0], co, 0);
+        v.c[1] = __builtin_amdgcn_raw_buffer_load_b16(rc, cx[1], co, 0);
       } else {
-        v.yy[row] = yrow[xs[0]] | (static_cast<uint32_t>(yrow[xs[1]]) << 8);
-        if (HAS_ALPHA) v.aa[row] = arow[xs[0]] | (static_cast<uint32_t>(arow[xs[1]]) << 8);
-        if (TAPS == TAPS_PAIRS) {
-          v.cc[row] = *reinterpret_cast<const uint16_t *>(crow + cx[0]) |
-                      (static_cast<uint32_t>(*reinterpret_cast<const uint16_t *>(crow + cx[1])) << 16);
-        } else {
-          v.cc[row] = crow[cx[0]] | (static_cast<uint32_t>(crow[cx[0] + 1]) << 8) |
-                      (static_cast<uint32_t>(crow[cx[1]]) << 16) | (static_cast<uint32_t>(crow[cx[1] + 1]) << 24);
-        }
+        v.c[0] = __builtin_amdgcn_raw_buffer_load_b8(rc, cx[0], co, 0);
+        v.c[1] = __builtin_amdgcn_raw_buffer_load_b8(rc, cx[0] + 1, co, 0);
+        v.c[2] = __builtin_amdgcn_raw_buffer_load_b8(rc, cx[1], co, 0);
+        v.c[3] = __builtin_amdgcn_raw_buffer_load_b8(rc, cx[1] + 1, co, 0);
       }
     }
     return v;
   };
-
-  const uint32_t oy0 = blockIdx.y * p.scaled_rows, oy1 = min(oy0 + p.scaled_rows, p.out_height);
-  RowTaps rt = row_taps(oy0);
-  Fetched cur = fetch(rt);
-  for (uint32_t oy = oy0; oy < oy1; ++oy) {
-    // the next row's taps go out before this row's arithmetic (uniform branch: not on the last row)
-    RowTaps nrt = rt;
-    Fetched nxt = cur;
-    if (oy + 1 < oy1) {
-      nrt = row_taps(oy + 1);
-      nxt = fetch(nrt);
+  // this lane's two taps of that row: Y0 | Y1 << 8, Cb0 | Cr0 << 8 | Cb1 << 16 | Cr1 << 24, A0 | A1 << 8
+  struct TapBytes {
+    uint32_t yy, cc, aa;
+  };
+  auto tap_bytes = [&](const Fetched1 &v) {
+    TapBytes t;
+    t.aa = 0;
+    if (TAPS == TAPS_SHARED) {
+      const int ylo = __builtin_amdgcn_ds_bpermute(static_cast<int>(ysrc), static_cast<int>(v.y[0]));
+      const int yhi = __builtin_amdgcn_ds_bpermute(static_cast<int>(ysrc + 4u), static_cast<int>(v.y[0]));
+      const int clo = __builtin_amdgcn_ds_bpermute(static_cast<int>(csrc), static_cast<int>(v.c[0]));
+      const int chi = __builtin_amdgcn_ds_bpermute(static_cast<int>(csrc + 4u), static_cast<int>(v.c[0]));
+      t.yy = __builtin_amdgcn_perm(static_cast<uint32_t>(yhi), static_cast<uint32_t>(ylo), ysel);
+      t.cc = __builtin_amdgcn_perm(static_cast<uint32_t>(chi), static_cast<uint32_t>(clo), csel);
+      if (HAS_ALPHA) {
+        const int alo = __builtin_amdgcn_ds_bpermute(static_cast<int>(ysrc), static_cast<int>(v.a[0]));
+        const int ahi = __builtin_amdgcn_ds_bpermute(static_cast<int>(ysrc + 4u), static_cast<int>(v.a[0]));
+        t.aa = __builtin_amdgcn_perm(static_cast<uint32_t>(ahi), static_cast<uint32_t>(alo), ysel);
+      }
+    } else if (TAPS == TAPS_WIDE) {
+      t.yy = __builtin_amdgcn_perm(v.y[1], v.y[0], ysel);
+      t.cc = __builtin_amdgcn_perm(v.c[1], v.c[0], csel);
+      if (HAS_ALPHA) t.aa = __builtin_amdgcn_perm(v.a[1], v.a[0], ysel);
+    } else {
+      t.yy = v.y[0] | (v.y[1] << 8);
+      if (HAS_ALPHA) t.aa = v.a[0] | (v.a[1] << 8);
+      t.cc = TAPS == TAPS_PAIRS ? (v.c[0] | (v.c[1] << 16)) : (v.c[0] | (v.c[1] << 8) | (v.c[2] << 16) | (v.c[3] << 24));
     }
+    return t;
+  };
+
+  // One source row of this lane: its two horizontal taps, linearised (times 2^-40).  Consecutive
+  // output rows share source rows whenever the vertical ratio is below 2 (always when enlarging), and
+  // which rows an output row needs is the same for every lane, so the two rows of the previous output
+  // row stay in registers and only rows not seen yet are fetched and decoded (scalar branches).  The
+  // chroma products are kept the same way: two luma rows share a CbCr row.
+  struct RowLin {
+    float v[6];  // R, G, B of tap 0; R, G, B of tap 1
+    float a[2];  // byteNorm of the two alpha taps (alpha decoders)
+  };
+  int chroma_row = -1;
+  Chroma ch0 = {}, ch1 = {};
+  auto decode_row = [&](const Fetched1 &raw, int srow) {
+    const TapBytes fr = tap_bytes(raw);
+    if ((srow >> 1) != chroma_row) {
+      ch0 = chroma_terms(byte_of(fr.cc, 0), byte_of(fr.cc, 1));
+      ch1 = chroma_terms(byte_of(fr.cc, 2), byte_of(fr.cc, 3));
+      chroma_row = srow >> 1;
+    }
+    float x[6];
+    pixel_rgb(byte_of(fr.yy, 0), ch0, x[0], x[1], x[2]);
+    pixel_rgb(byte_of(fr.yy, 1), ch1, x[3], x[4], x[5]);
+    RowLin rl;
+    linearise6(r, x, rl.v);
+    rl.a[0] = rl.a[1] = 0.0f;
+    if (HAS_ALPHA) {
+      const float ab[4] = {byte_of(fr.aa, 0), byte_of(fr.aa, 1), 0.0f, 0.0f};
+      float n[4];
+      alpha_norm4(al, r.magic, ab, n);
+      rl.a[0] = n[0];
+      rl.a[1] = n[1];
+    }
+    return rl;
+  };
+
+  int have_top = -1, have_bot = -1;  // source rows held in `top` / `bot`
+  RowLin top = {}, bot = {};
+  // The loads of a fetched row are waited for HERE whether or not the row gets decoded: a load still in
+  // flight at a skipped decode would leave its destination registers pending, and hipcc then drains vmcnt
+  // (stores included) wherever it reuses one of them.  No instruction is emitted, only the s_waitcnt.
+  auto landed = [&](const Fetched1 &v) {
+    if (TAPS == TAPS_SHARED) asm volatile("" ::"v"(v.y[0]), "v"(v.c[0]));
+    else if (TAPS == TAPS_BYTES) asm volatile("" ::"v"(v.y[0]), "v"(v.y[1]), "v"(v.c[0]), "v"(v.c[1]), "v"(v.c[2]), "v"(v.c[3]));
+    else asm volatile("" ::"v"(v.y[0]), "v"(v.y[1]), "v"(v.c[0]), "v"(v.c[1]));
+    if (HAS_ALPHA) {
+      if (TAPS == TAPS_SHARED) asm volatile("" ::"v"(v.a[0]));
+      else asm volatile("" ::"v"(v.a[0]), "v"(v.a[1]));
+    }
+  };
+  // one output row from the fetched bytes of its two source rows
+  auto output_row = [&](uint32_t oy, const RowTaps &rt, const Fetched1 &f0, const Fetched1 &f1) {
+    landed(f0);
+    landed(f1);
+    if (rt.ys[0] == have_bot) top = bot;  // the previous bottom row is this row's top row
+    else if (rt.ys[0] != have_top) top = decode_row(f0, rt.ys[0]);
+    if (rt.ys[1] == rt.ys[0]) bot = top;  // both taps clamped onto one row
+    else if (rt.ys[1] != have_bot) bot = decode_row(f1, rt.ys[1]);
+    have_top = rt.ys[0];
+    have_bot = rt.ys[1];
     const float fy = rt.fy, gy = __fadd_rn(1.0f, -fy);
     const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
-    float x[12];  // tap t = (row t >> 1, column t & 1): x[3t] = R, x[3t + 1] = G, x[3t + 2] = B
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint32_t yy = cur.yy[t >> 1], cc = cur.cc[t >> 1];
-      const Chroma ch = (t & 1) ? chroma_terms(byte_of(cc, 2), byte_of(cc, 3)) : chroma_terms(byte_of(cc, 0), byte_of(cc, 1));
-      pixel_rgb((t & 1) ? byte_of(yy, 1) : byte_of(yy, 0), ch, x[3 * t], x[3 * t + 1], x[3 * t + 2]);
-    }
-    float lin[12];
-    linearise12(r, x, lin);
     float acc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      acc[k] = __fmul_rn(w[0], lin[k]);
-#pragma unroll
-      for (int t = 1; t < 4; ++t) acc[k] = __fadd_rn(acc[k], __fmul_rn(w[t], lin[3 * t + k]));
+      acc[k] = __fmul_rn(w[0], top.v[k]);
+      acc[k] = __fadd_rn(acc[k], __fmul_rn(w[1], top.v[3 + k]));
+      acc[k] = __fadd_rn(acc[k], __fmul_rn(w[2], bot.v[k]));
+      acc[k] = __fadd_rn(acc[k], __fmul_rn(w[3], bot.v[3 + k]));
     }
-    const uint32_t R = encode_byte(r, __fmul_rn(acc[0], r.scale));
-    const uint32_t G = encode_byte(r, __fmul_rn(acc[1], r.scale));
-    const uint32_t B = encode_byte(r, __fmul_rn(acc[2], r.scale));
+    const uint32_t R = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[0]) : encode_byte(r, __fmul_rn(acc[0], r.scale));
+    const uint32_t G = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[1]) : encode_byte(r, __fmul_rn(acc[1], r.scale));
+    const uint32_t B = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[2]) : encode_byte(r, __fmul_rn(acc[2], r.scale));
     uint32_t aw = p.alpha_word;
     if (HAS_ALPHA) {
-      const float ab[4] = {byte_of(cur.aa[0], 0), byte_of(cur.aa[0], 1), byte_of(cur.aa[1], 0), byte_of(cur.aa[1], 1)};
-      float n[4];
-      alpha_norm4(al, r.magic, ab, n);
-      float av = __fmul_rn(w[0], n[0]);
-#pragma unroll
-      for (int t = 1; t < 4; ++t) av = __fadd_rn(av, __fmul_rn(w[t], n[t]));
+      float av = __fmul_rn(w[0], top.a[0]);
+      av = __fadd_rn(av, __fmul_rn(w[1], top.a[1]));
+      av = __fadd_rn(av, __fmul_rn(w[2], bot.a[0]));
+      av = __fadd_rn(av, __fmul_rn(w[3], bot.a[1]));
       aw = alpha_quantise(al, add_sat(__fmul_rn(av, al.unscale), 0.0f));
     }
-    reinterpret_cast<uint32_t *>(f.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, aw);
-    cur = nxt;
-    rt = nrt;
+    if (TAPS != TAPS_SHARED || live)
+      __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, oy * p.out_stride, 0);
+  };
+
+  // The FETCH is unconditional and one output row ahead (a load the row does not need after all is an L2
+  // hit; fetching only the new rows was measured: -22 % instructions, but the waits then covered the loads
+  // just issued); the DECODE is what is skipped.  Two output rows per trip through explicit A / B register
+  // sets: rotating one set through copies made hipcc drain vmcnt -- the row's STORE included -- at the end
+  // of every row.
+  // (Past the strip's end the fetch repeats the last row instead of being branched around: hipcc's vmcnt
+  // accounting takes the path with the fewest loads in flight, so one conditional fetch turns every
+  // wait of the loop into a full drain.)
+  const uint32_t last = oy1 - 1;
+  RowTaps rta = row_taps(oy0), rtb;
+  Fetched1 a0 = fetch_row(rta.ys[0]), a1 = fetch_row(rta.ys[1]), b0, b1;
+  for (uint32_t oy = oy0; oy < oy1; oy += 2) {
+    rtb = row_taps(min(oy + 1, last));
+    b0 = fetch_row(rtb.ys[0]);
+    b1 = fetch_row(rtb.ys[1]);
+    output_row(oy, rta, a0, a1);
+    if (oy + 1 >= oy1) {  // uniform.  Nothing stays in flight past the strip: a dangling load is a pending
+      landed(b0);         // write to registers the next strip reuses, i.e. a drain in every trip of ITS loop
+      landed(b1);
+      break;
+    }
+    rta = row_taps(min(oy + 2, last));
+    a0 = fetch_row(rta.ys[0]);
+    a1 = fetch_row(rta.ys[1]);
+    output_row(oy + 1, rtb, b0, b1);
   }
+  landed(a0);
+  landed(a1);
+}
+
+// A workgroup = 256 output columns x kScaledStrips strips of `scaled_rows` output rows of one frame; its
+// waves share nothing but the single-copy tables.  Measured on 4K -> 1440p, 8 frames per launch, same call
+// (profiles/r02_ab_scaled.txt): one strip + the 6 KiB two-resolution encode table (14 KiB staged per
+// workgroup) 240 Gpixel/s; two strips per workgroup 224; the 24 KiB uniform encode table (9 fewer VALU
+// instructions per pixel, but 32 KiB staged per 4 096 output pixels and 5 workgroups per CU) 194.
+#ifndef BT709_SCALED_STRIPS
+#define BT709_SCALED_STRIPS 1
+#endif
+#ifndef BT709_SCALED_UNIFORM
+#define BT709_SCALED_UNIFORM 0
+#endif
+constexpr uint32_t kScaledStrips = BT709_SCALED_STRIPS;
+constexpr bool kScaledUniform = BT709_SCALED_UNIFORM != 0;
+template <int TAPS, bool HAS_ALPHA>
+__global__ void __launch_bounds__(kBlockThreads *kScaledStrips)
+decode_nv12_scaled(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const RescaleLookup r = stage_rescale_tables<kScaledUniform>(lds_raw, p, 0, 0, 0);
+  AlphaLookup al = {};
+  if (HAS_ALPHA) al = stage_alpha_tables(lds_raw + p.table_linear_bytes + (kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes), p);
+  __syncthreads();
+  const FramePlanes f = frame_planes(p, blockIdx.z);
+  const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t oy0 = (blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y)) * p.scaled_rows;
+  if (oy0 >= p.out_height) return;
+  if (TAPS != TAPS_SHARED && ox >= p.out_width) return;  // TAPS_SHARED: the wave fetches together
+  scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, al, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height));
 }
 
 // ---------------------------------------------------------------------------
@@ -759,31 +933,54 @@ const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool no
 const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_alpha, uint32_t in_align,
                                  uint32_t compute_units, hipStream_t stream) {
   DecodeParams p = p_in;
-  // rows per workgroup: as many as still leave ~8 workgroups per CU (table staging is per workgroup)
-  const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
-  const uint64_t want = 8ull * (compute_units ? compute_units : 256u);
-  uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height * static_cast<uint32_t>(frames) / want);
-  rows = rows < 1 ? 1 : (rows > 32 ? 32 : rows);
-  p.scaled_rows = rows;
-  const dim3 grid(cols, (p.out_height + rows - 1) / rows, static_cast<uint32_t>(frames));
-  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes +
-                     (has_alpha ? static_cast<size_t>(p.table_alpha_bytes) + p.table_unit_bytes : 0);
+  const uint32_t cus = compute_units ? compute_units : 256u;
+  // the kernels form row offsets in 32 bits
+  const uint64_t kPlaneLimit = 1ull << 31;
+  if (static_cast<uint64_t>(p.height) * p.y_stride >= kPlaneLimit || static_cast<uint64_t>(p.height / 2) * p.cbcr_stride >= kPlaneLimit ||
+      (has_alpha && static_cast<uint64_t>(p.height) * p.alpha_stride >= kPlaneLimit) ||
+      static_cast<uint64_t>(p.out_height) * p.out_stride >= kPlaneLimit)
+    return nullptr;
   // widest tap fetch the layout allows (see the kernel); the frame spacing of a uniform batch counts too
   uint32_t align = in_align > 4 ? 4 : in_align;
   auto fold = [&align](uint64_t v) { while (align > 1 && v % align) align /= 2; };
   if (p.uniform) fold(static_cast<uint64_t>(p.step_y)), fold(static_cast<uint64_t>(p.step_cbcr)), fold(static_cast<uint64_t>(p.step_alpha));
-  const int taps = (align == 4 && p.width % 4 == 0 && p.width >= 8) ? TAPS_WIDE : (align >= 2 ? TAPS_PAIRS : TAPS_BYTES);
-  const dim3 block(kBlockThreads);
-  if (has_alpha) {
-    if (taps == TAPS_WIDE) hipLaunchKernelGGL((decode_nv12_scaled<TAPS_WIDE, true>), grid, block, lds, stream, p);
-    else if (taps == TAPS_PAIRS) hipLaunchKernelGGL((decode_nv12_scaled<TAPS_PAIRS, true>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((decode_nv12_scaled<TAPS_BYTES, true>), grid, block, lds, stream, p);
-    return "decode_nv12_scaled<alpha>";
-  }
-  if (taps == TAPS_WIDE) hipLaunchKernelGGL((decode_nv12_scaled<TAPS_WIDE, false>), grid, block, lds, stream, p);
-  else if (taps == TAPS_PAIRS) hipLaunchKernelGGL((decode_nv12_scaled<TAPS_PAIRS, false>), grid, block, lds, stream, p);
-  else hipLaunchKernelGGL((decode_nv12_scaled<TAPS_BYTES, false>), grid, block, lds, stream, p);
-  return "decode_nv12_scaled";
+  int taps = (align == 4 && p.width % 4 == 0 && p.width >= 8) ? TAPS_WIDE : (align >= 2 ? TAPS_PAIRS : TAPS_BYTES);
+  // Fetching by the wave pays when most fetched rows are not decoded (enlarging: the two loads per output
+  // row dominate) and costs when they are (four ds_bpermute per decoded row on an LDS pipe the lookups
+  // keep busy): 1080p -> 4K +6.6 %, 4K -> 1440p -8 % (same call).  A wave's 64 windows must fit one 256-byte span.
+#ifndef BT709_SCALED_SHARED_BELOW
+#define BT709_SCALED_SHARED_BELOW 1.0f
+#endif
+  if (taps == TAPS_WIDE && p.scale_y < BT709_SCALED_SHARED_BELOW && p.scale_x * 64.0f + 12.0f <= 252.0f) taps = TAPS_SHARED;
+
+  // rows per strip: as many as still leave ~8 workgroups per CU (table staging is per workgroup)
+#ifndef BT709_SCALED_WG_PER_CU
+#define BT709_SCALED_WG_PER_CU 8
+#endif
+#ifndef BT709_SCALED_MAX_ROWS
+#define BT709_SCALED_MAX_ROWS 16
+#endif
+  const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
+  const uint64_t want = static_cast<uint64_t>(BT709_SCALED_WG_PER_CU) * cus * kScaledStrips;
+  uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height * static_cast<uint32_t>(frames) / want);
+  rows = rows < 1 ? 1 : (rows > BT709_SCALED_MAX_ROWS ? BT709_SCALED_MAX_ROWS : rows);
+  p.scaled_rows = rows;
+  const uint32_t strips = (p.out_height + rows - 1) / rows;
+  const dim3 grid(cols, (strips + kScaledStrips - 1) / kScaledStrips, static_cast<uint32_t>(frames));
+  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + (kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes) +
+                     (has_alpha ? static_cast<size_t>(p.table_alpha_bytes) + p.table_unit_bytes : 0);
+  const dim3 block(kBlockThreads, kScaledStrips);
+#define BT709_LAUNCH_SCALED(T)                                                                               \
+  do {                                                                                                       \
+    if (has_alpha) hipLaunchKernelGGL((decode_nv12_scaled<T, true>), grid, block, lds, stream, p);          \
+    else hipLaunchKernelGGL((decode_nv12_scaled<T, false>), grid, block, lds, stream, p);                   \
+  } while (0)
+  if (taps == TAPS_SHARED) BT709_LAUNCH_SCALED(TAPS_SHARED);
+  else if (taps == TAPS_WIDE) BT709_LAUNCH_SCALED(TAPS_WIDE);
+  else if (taps == TAPS_PAIRS) BT709_LAUNCH_SCALED(TAPS_PAIRS);
+  else BT709_LAUNCH_SCALED(TAPS_BYTES);
+#undef BT709_LAUNCH_SCALED
+  return has_alpha ? "decode_nv12_scaled<alpha>" : "decode_nv12_scaled";
 }
 
 hipError_t prepare_rescale_kernels() {
@@ -802,6 +999,8 @@ hipError_t prepare_rescale_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_BYTES, true>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_PAIRS, true>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_WIDE, true>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_SHARED, false>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_SHARED, true>),
       reinterpret_cast<const void *>(&render_scaled<true>),
       reinterpret_cast<const void *>(&render_scaled<false>),
   };

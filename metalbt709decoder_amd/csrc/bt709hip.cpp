@@ -862,8 +862,10 @@ int bt709hip_decode_scaled_batch(bt709hip_decoder *dec, int count, const bt709hi
   p.scale_x = static_cast<float>(p.width) / static_cast<float>(p.out_width);
   p.scale_y = static_cast<float>(p.height) / static_cast<float>(p.out_height);
   hipStream_t s = pick(dec->ctx, stream);
-  tl_kernel_name = launch_decode_scaled(p, count, dec->has_alpha != 0, info.in_align,
-                                        static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), s);
+  const char *name = launch_decode_scaled(p, count, dec->has_alpha != 0, info.in_align,
+                                          static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), s);
+  if (name == nullptr) return BT709HIP_ERR_UNSUPPORTED;  // a plane of 2 GiB or more
+  tl_kernel_name = name;
   return finish_launch(s, wait_until_completed);
 }
 

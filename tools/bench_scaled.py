@@ -41,7 +41,10 @@ def main():
     ap.add_argument("--out-width", type=int, default=2560)
     ap.add_argument("--out-height", type=int, default=1440)
     ap.add_argument("--frames-per-launch", type=int, default=1)
+    ap.add_argument("--library", default=None, help="a variant build of libbt709hip.so (python -m metalbt709decoder_amd.build --variant)")
     args = ap.parse_args()
+    if args.library:
+        _capi.load(os.path.abspath(args.library))
     W, H, path = args.width, args.height, args.path
     OW, OH = (W, H) if path == "rgba16f" else (args.out_width, args.out_height)
     fpl = 1 if path.startswith("render") else max(1, min(args.frames_per_launch, args.ring))
