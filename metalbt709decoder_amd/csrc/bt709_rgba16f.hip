@@ -28,9 +28,13 @@
 namespace bt709 {
 namespace {
 
+constexpr float kHalfBias = 2.0e-5f;  // log2 units: the candidate is low by a factor 2^-kHalfBias
+
 struct HalfLookup {
   float split, low_scale, pre_add, pre_scale, exponent;
-  uint32_t table_off;  // LDS address of T[h_min] - 4 * h_min
+  float pre_add_scaled;  // pre_add * pre_scale
+  uint32_t h_below;      // h_min - 1
+  uint32_t table_off;    // LDS address of T[h_min] - 4 * h_min
 };
 
 __device__ __forceinline__ uint32_t half_bits(float v) {
@@ -46,20 +50,35 @@ __device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
   // from fusing multiply and conversion into v_fma_mixlo_f16 (one rounding instead of two).
   float lowv = __fmul_rn(x, t.low_scale);  // exact below the split for 1/16; x itself when there is no curve
   asm("" : "+v"(lowv));
+  if (!HAS_TABLE) return half_bits(lowv);
+#if defined(BT709_RGBA16F_TWO_SIDED)  // round 2's first form: unbiased candidate, both neighbours' thresholds, the low piece apart
   const uint32_t low = half_bits(lowv);
-  if (!HAS_TABLE) return low;
   float xb;  // max(x, split): keeps the candidate inside the table whatever x is
   asm("v_max_f32 %0, %1, %2" : "=v"(xb) : "v"(x), "s"(t.split));
   const float base = HAS_PRE ? __fmul_rn(__fadd_rn(xb, t.pre_add), t.pre_scale) : xb;
   const float p = __builtin_amdgcn_exp2f(__fmul_rn(t.exponent, __builtin_amdgcn_logf(base)));  // v_log_f32 is log2
-  // xb >= split, so the candidate is H(xb) or a neighbour: within [h_min - 1, h_max + 1].  The staged table
-  // carries one guard entry on each side (T[h_min - 1] = 0: never "below"; T[h_max + 2] = +inf: never
-  // "reached"), so no clamp is needed and a candidate one off either end is still settled correctly.
   const uint32_t h0 = half_bits(p);
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
   const LdsFloatPtr e = reinterpret_cast<LdsFloatPtr>((h0 << 2) + t.table_off);
   const uint32_t h = h0 + (xb >= e[1] ? 1u : 0u) - (xb < e[0] ? 1u : 0u);
   return x < t.split ? low : h;
+#else
+  // Above the split the candidate is pushed DOWN by kHalfBias in the exponent (a factor 1 - 1.4e-5: several
+  // times the error of v_log_f32 * g -> v_exp_f32, a thirtieth of a half's spacing), so its half is H or
+  // H - 1, never H + 1, and ONE threshold settles it: H = h0 + (x >= T[h0 + 1]).  The bias rides in the fma
+  // that replaces the multiply, and the (x + a) / (1 + a) step is one fma too: both belong to the CANDIDATE,
+  // not to the reference's arithmetic -- any value within the stated bounds gives the same H.
+  // Below the split the exact product takes the candidate's place before the one conversion; its half IS H,
+  // and it goes through the same settlement: the index is held at h_min - 1 from below, T[h_min] is the
+  // smallest x of the WHOLE curve that reaches h_min, so nothing is added (and a value of the low piece that
+  // already rounds to h_min is compared with T[h_min + 1] > split).  No clamp of x, no second conversion.
+  const float base = HAS_PRE ? __builtin_fmaf(x, t.pre_scale, t.pre_add_scaled) : x;
+  const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(t.exponent, __builtin_amdgcn_logf(base), -kHalfBias));  // v_log_f32 is log2
+  const uint32_t h0 = half_bits(x < t.split ? lowv : p);
+  typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
+  const LdsFloatPtr e = reinterpret_cast<LdsFloatPtr>((max(h0, t.h_below) << 2) + t.table_off);
+  return h0 + (x >= e[1] ? 1u : 0u);
+#endif
 }
 
 }  // namespace
@@ -79,6 +98,8 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
   t.pre_add = hp.pre_add;
   t.pre_scale = hp.pre_scale;
   t.exponent = hp.exponent;
+  t.pre_add_scaled = __fmul_rn(hp.pre_add, hp.pre_scale);
+  t.h_below = hp.h_min - 1u;
   t.table_off = lds_address(lds_raw) + 4u - (hp.h_min << 2);
 
   const FramePlanes f = frame_planes(p, blockIdx.z);

@@ -1323,7 +1323,7 @@ int bt709hip_half_thresholds(int gamma, float *thresholds, int capacity) {
 
 int bt709hip_half_lookup(int gamma, float x, int candidate_offset, int *table_entries) {
   const HalfTable *t = host_half_table(gamma);
-  if (t == nullptr || !(x >= 0.0f && x <= 1.0f) || candidate_offset < -1 || candidate_offset > 1)
+  if (t == nullptr || !(x >= 0.0f && x <= 1.0f) || candidate_offset < -1 || candidate_offset > 0)
     return BT709HIP_ERR_INVALID_ARG;
   if (table_entries) *table_entries = t->split > 1.0f ? 0 : static_cast<int>(t->thresholds.size());
   const int low = float_to_half(x * t->low_scale);
@@ -1332,9 +1332,11 @@ int bt709hip_half_lookup(int gamma, float x, int candidate_offset, int *table_en
   while (real > 0 && t->thresholds[real - 1] == std::numeric_limits<float>::infinity()) --real;
   const int h_min = static_cast<int>(t->h_min), h_max = h_min + static_cast<int>(real) - 1;
   int h0 = static_cast<int>(float_to_half(curve_to_linear(gamma, x))) + candidate_offset;
-  h0 = h0 < h_min ? h_min : (h0 > h_max ? h_max : h0);
-  const float *e = &t->thresholds[static_cast<size_t>(h0 - h_min)];
-  return h0 + (x >= e[1] ? 1 : 0) - (x < e[0] ? 1 : 0);
+  h0 = h0 < h_min - 1 ? h_min - 1 : (h0 > h_max ? h_max : h0);  // x >= split: H(x) >= h_min
+  // T[h0 + 1]; T[h_max + 1] = +inf (the device copy's guard entry): the top code is never exceeded
+  const size_t above = static_cast<size_t>(h0 + 1 - h_min);
+  const float edge = above < real ? t->thresholds[above] : std::numeric_limits<float>::infinity();
+  return h0 + (x >= edge ? 1 : 0);
 }
 
 int bt709hip_matrix_constants(float c[8]) {

@@ -242,7 +242,16 @@ bool build_half_table(int gamma, HalfTable *out) {
   const uint32_t lo_bits = to_bits(out->split), hi_bits = 0x3f800000u;
   out->h_min = H(out->split);
   const uint32_t h_max = H(1.0f);
-  out->thresholds.push_back(0.0f);  // T[h_min]: every x of the segment reaches it
+  {  // T[h_min] over the WHOLE curve (the piece below the split included): the kernel settles values of
+     // that piece against it too, and they must stay where the exact product put them
+    uint32_t lo = 0, hi = lo_bits;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (H(from_bits(mid)) >= out->h_min) hi = mid;
+      else lo = mid + 1;
+    }
+    out->thresholds.push_back(from_bits(lo));
+  }
   for (uint32_t h = out->h_min + 1; h <= h_max; ++h) {
     uint32_t lo = lo_bits, hi = hi_bits;  // H is monotone: bisect on the bit pattern
     while (lo < hi) {

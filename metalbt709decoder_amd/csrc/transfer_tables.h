@@ -158,7 +158,7 @@ struct HalfTable {
   // candidate: base = (x + pre_add) * pre_scale; h0 = half(exp2(exponent * log2(base)))
   float pre_add = 0.0f, pre_scale = 1.0f, exponent = 1.0f;
   uint32_t h_min = 0;      // H(split): first code the table covers
-  // T[i] = smallest x >= split with H(x) >= h_min + i; T[0] = 0; one +inf entry past H(1.0); padded to 16 bytes
+  // T[i] = smallest x with H(x) >= h_min + i (T[0] may lie below the split); one +inf entry past H(1.0); padded to 16 bytes
   std::vector<float> thresholds;
 };
 uint16_t float_to_half(float v);               // IEEE binary32 -> binary16, round to nearest even

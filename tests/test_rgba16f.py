@@ -68,9 +68,9 @@ def test_oracle_render_scaled_from_rgba16f(oracle):
 
 
 def test_half_lookup_correction_step(pass2):
-    """The kernel's exactness argument, replayed on the host from the product's own table: whatever
-    neighbour of H(x) the fast candidate lands on, the two thresholds around it give H(x) back --
-    checked next to every threshold, for candidates H-1, H and H+1."""
+    """The kernel's exactness argument, replayed on the host from the product's own table: the fast
+    candidate is biased downward, so it lands on H(x) or H(x) - 1, and the one threshold above it gives
+    H(x) back -- checked next to every threshold, for both candidates; a candidate above H is refused."""
     import ctypes as C
     lib = mb.load_library()
     fn = lib.bt709hip_half_lookup
@@ -90,7 +90,8 @@ def test_half_lookup_correction_step(pass2):
             for d in (-1, 0, 1):
                 x = float(np.array([int(b) + d], np.uint32).view(np.float32)[0])
                 want = fn(gamma, x, 0, None)
-                assert fn(gamma, x, -1, None) == want and fn(gamma, x, 1, None) == want, (gamma, x)
+                assert fn(gamma, x, -1, None) == want, (gamma, x)
+        assert fn(gamma, 0.5, 1, None) < 0
 
 
 # ------------------------------------------------------------------ GPU
