@@ -267,8 +267,12 @@ bool build_half_table(int gamma, HalfTable *out) {
 }
 
 uint32_t uniform_index(float v, float n) {
+#if defined(BT709_UNIFORM_INDEX_TWO_STEP)
   volatile float xs = v * n;            // binary32 product, round to nearest even
   volatile float t = xs + 8388608.0f;   // floats in [2^23, 2^24) have ulp 1: round(xs)
+#else
+  volatile float t = std::fmaf(v, n, 8388608.0f);  // one rounding of v n + 2^23, as the kernel's v_fma_f32
+#endif
   return to_bits(t) - 0x4b000000u;
 }
 

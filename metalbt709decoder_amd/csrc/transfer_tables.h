@@ -128,11 +128,10 @@ bool build_transfer_table(int gamma, TransferTable *out);
 // Uniform bucket table with ANY bucket count n (not a power of two): the smallest n that still keeps
 // one threshold per bucket.  The sRGB-encode composite needs n >= 3296 only because its thresholds
 // are 1/(255 * 12.92) apart near zero; a power of two would cost 4096 buckets = 33 KiB, n = 33xx costs
-// 26 KiB, and the index is two 2-cycle multiplies and one 2-cycle add instead of the two-resolution
-// table's convert + shift + add + min:
-//     xs = v * n;  q = bits(xs + 2^23) - bits(2^23) = round(xs);  byte = buckets[q].base + (v >= buckets[q].edge)
-// (edge is the threshold itself, in v units: the product's rounding only moves bucket boundaries, which
-// the builder replays exactly, never the comparison).  n + 2 buckets (q <= n, one spare), padded to 16 bytes.
+// 26 KiB, and the index is ONE fma instead of the two-resolution table's convert + shift + add + min:
+//     q = bits(fma(v, n, 2^23)) - bits(2^23) = round(v n);  byte = buckets[q].base + (v >= buckets[q].edge)
+// (edge is the threshold itself, in v units: the rounding only moves bucket boundaries, which the builder
+// replays exactly, never the comparison).  n + 2 buckets (q <= n, one spare), padded to 16 bytes.
 struct UniformTable {
   uint32_t n = 0;
   std::vector<TransferBucket> buckets;
