@@ -109,13 +109,6 @@ __device__ __forceinline__ void pixel_rgb(float ybyte, const Chroma &c, float &r
   b = add_sat(yv, c.cb_b);
 }
 
-// the same from the pixel's luma term yv = Yn * My (kernels that take it from a table)
-__device__ __forceinline__ void luma_rgb(float yv, const Chroma &c, float &r, float &g, float &b) {
-  r = add_sat(yv, c.cr_r);
-  g = add_sat(__fadd_rn(yv, c.cb_g), c.cr_g);
-  b = add_sat(yv, c.cb_b);
-}
-
 // linear alpha sample: the luma term alone (AAPLShaders.metal:249-271; CPU twin BT709.h:466-513)
 __device__ __forceinline__ float alpha_value(float abyte) {
   return add_sat(__fmul_rn(centre_norm(abyte, 16.0f), kMY), 0.0f);

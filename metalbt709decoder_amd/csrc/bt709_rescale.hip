@@ -221,22 +221,14 @@ __device__ __forceinline__ uint32_t half_alpha(const AlphaLookup &a, float magic
 
 // One output pixel of the exact 2:1 rescale: the four source pixels of a 2x2 block share one
 // CbCr sample; (((a+b)+c)+d) * 0.25f per channel.
-// LUMA_TABLE: y00.. are already the luma terms (Yn * My) of the four pixels, else their bytes as floats
-template <bool UNIFORM_ENCODE = false, bool LUMA_TABLE = false>
+template <bool UNIFORM_ENCODE = false>
 __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, float y01, float y10, float y11,
                                             const Chroma &c, uint32_t alpha_word) {
   float x[12];  // r0..r3, g0..g3, b0..b3
-  if (LUMA_TABLE) {
-    luma_rgb(y00, c, x[0], x[4], x[8]);
-    luma_rgb(y01, c, x[1], x[5], x[9]);
-    luma_rgb(y10, c, x[2], x[6], x[10]);
-    luma_rgb(y11, c, x[3], x[7], x[11]);
-  } else {
-    pixel_rgb(y00, c, x[0], x[4], x[8]);
-    pixel_rgb(y01, c, x[1], x[5], x[9]);
-    pixel_rgb(y10, c, x[2], x[6], x[10]);
-    pixel_rgb(y11, c, x[3], x[7], x[11]);
-  }
+  pixel_rgb(y00, c, x[0], x[4], x[8]);
+  pixel_rgb(y01, c, x[1], x[5], x[9]);
+  pixel_rgb(y10, c, x[2], x[6], x[10]);
+  pixel_rgb(y11, c, x[3], x[7], x[11]);
   float lin[12];
   linearise12(r, x, lin);
   const float *lr = lin, *lg = lin + 4, *lb = lin + 8;
@@ -250,38 +242,12 @@ __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, f
 }
 
 // the two output pixels of a quad (4x2 source pixels); aw0 / aw1 = their alpha words
-// The luma term Yn * My of byte LANE of a word, from the 256-entry table the persistent kernel keeps at LDS
-// address 0 (it has no static LDS): v_lshlrev_b32_sdwa selects the byte and scales it to the entry in one
-// instruction, the table's entries were computed by this same device code (centre_norm, multiply) at staging.
-// One VALU instruction + one ds_read_b32 instead of convert, fma, multiply: the kernel is VALU-issue-bound
-// (SQ_ACTIVE_INST_VALU x 4 cycles = the launch) with the LDS 60 % busy.
-template <int LANE>
-__device__ __forceinline__ float luma_term(uint32_t two, uint32_t word) {
-  uint32_t a;
-  if (LANE == 0)
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(two), "v"(word));
-  else if (LANE == 1)
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(two), "v"(word));
-  else if (LANE == 2)
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(two), "v"(word));
-  else
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(two), "v"(word));
-  typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
-  return *reinterpret_cast<LdsFloatPtr>(a);
-}
-
-// `two`: a VGPR holding 2 (SDWA operands cannot be inline constants); only read when LUMA_TABLE
-template <bool UNIFORM_ENCODE = false, bool LUMA_TABLE = false>
+template <bool UNIFORM_ENCODE = false>
 __device__ __forceinline__ u32x2 half_quad(const RescaleLookup &r, uint32_t ya, uint32_t yb, uint32_t cw,
-                                           uint32_t aw0, uint32_t aw1, uint32_t two = 2) {
+                                           uint32_t aw0, uint32_t aw1) {
   const Chroma c0 = chroma_terms(byte_of(cw, 0), byte_of(cw, 1));
   const Chroma c1 = chroma_terms(byte_of(cw, 2), byte_of(cw, 3));
   u32x2 v;
-  if (LUMA_TABLE) {
-    v.x = half_px<UNIFORM_ENCODE, true>(r, luma_term<0>(two, ya), luma_term<1>(two, ya), luma_term<0>(two, yb), luma_term<1>(two, yb), c0, aw0);
-    v.y = half_px<UNIFORM_ENCODE, true>(r, luma_term<2>(two, ya), luma_term<3>(two, ya), luma_term<2>(two, yb), luma_term<3>(two, yb), c1, aw1);
-    return v;
-  }
   v.x = half_px<UNIFORM_ENCODE>(r, byte_of(ya, 0), byte_of(ya, 1), byte_of(yb, 0), byte_of(yb, 1), c0, aw0);
   v.y = half_px<UNIFORM_ENCODE>(r, byte_of(ya, 2), byte_of(ya, 3), byte_of(yb, 2), byte_of(yb, 3), c1, aw1);
   return v;
@@ -390,13 +356,10 @@ constexpr bool kRepUniformEncode = false;
 #else
 constexpr bool kRepUniformEncode = true;
 #endif
-// luma terms through a 256-entry LDS table (luma_term above) unless built with -DBT709_REP_NO_LUMA_TABLE (A/B runs)
-#if defined(BT709_REP_NO_LUMA_TABLE)
-constexpr bool kRepLumaTable = false;
-#else
-constexpr bool kRepLumaTable = true;
-#endif
-constexpr uint32_t kRepLumaBytes = kRepLumaTable ? 1024u : 0u;
+// (The luma terms Yn * My from a 256-entry LDS table -- one SDWA shift + ds_read_b32 instead of convert, fma,
+// multiply, 8 fewer VALU instructions per output pixel in a VALU-issue-bound kernel -- measured 3 % SLOWER in the
+// same call, profiles/r02_ab_half_luma_table.txt: at 60 % busy the LDS pipe has no room for four more conflicted
+// gathers per pixel, and no LDS is left to replicate that table.  The commit before this comment holds the code.)
 // (A form that runs the quad's two output pixels on VGPR pairs -- v_pk_fma/mul/add_f32, 25 % fewer
 // instructions -- measured 4.7 % SLOWER in the same call, profiles/r02_ab_half_packed_f32.txt: packed f32 ops
 // run at half rate, so the VALU cycles do not change, and the pairing costs scheduling freedom.  Commit e0a028e.)
@@ -468,17 +431,7 @@ decode_nv12_half_rep(const DecodeParams p) {
     }
   }
 
-  // LDS: [luma terms of the 256 byte values, 1 KiB, at address 0][decode-side copies][encode table]
-  if (kRepLumaTable) {
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-      float b = static_cast<float>(i);
-      asm("" : "+v"(b));
-      reinterpret_cast<float *>(lds_raw)[i] = __fmul_rn(centre_norm(b, 16.0f), kMY);  // pixel_rgb's first line
-    }
-  }
-  const RescaleLookup r = stage_rescale_tables<kRepUniformEncode>(lds_raw + kRepLumaBytes, p, p.rep_dec_log2, p.rep_enc_log2);
-  uint32_t two = 2;
-  asm volatile("" : "+v"(two));
+  const RescaleLookup r = stage_rescale_tables<kRepUniformEncode>(lds_raw, p, p.rep_dec_log2, p.rep_enc_log2);
   __syncthreads();
 
   for (; t < p.tile_rows; t += U * G) {
@@ -501,7 +454,7 @@ decode_nv12_half_rep(const DecodeParams p) {
     for (int u = 0; u < U; ++u) {
       const bool have = t + u * G < p.tile_rows;
       const TileCursor c = {have ? cur.tx : first.tx, have ? cur.rp : first.rp, have ? cur.f : first.f};
-      const u32x2 v = half_quad<kRepUniformEncode, kRepLumaTable>(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word, p.alpha_word, two);
+      const u32x2 v = half_quad<kRepUniformEncode>(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word, p.alpha_word);
       const FramePlanes f = frame_planes(p, c.f);
       uint8_t *o = f.out + static_cast<size_t>(c.rp) * p.out_stride;
       // lanes past the row's end loaded the last quad (clamp), hold its result and store it again
@@ -959,7 +912,7 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
 const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool nontemporal, uint32_t workgroups,
                                    uint32_t lds_budget, hipStream_t stream) {
   DecodeParams p = p_in;
-  const uint64_t kRepLdsBytes = (lds_budget < 16384u ? 16384u : (lds_budget > bt709::kRepLdsBytes ? bt709::kRepLdsBytes : lds_budget)) - kRepLumaBytes;
+  const uint64_t kRepLdsBytes = (lds_budget < 16384u ? 16384u : (lds_budget > bt709::kRepLdsBytes ? bt709::kRepLdsBytes : lds_budget));
   // copies: as many as fit the CU's LDS, decode side first (12 of the 15 lookups per output pixel)
   const uint64_t enc_bytes = kRepUniformEncode ? p.table_encode_u_bytes : p.table_encode_bytes;
   uint32_t r1 = 4, r2 = 0;
@@ -979,7 +932,7 @@ const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool no
   p.cursor_tx = workgroups % p.tiles_x;
   p.cursor_rp = (workgroups / p.tiles_x) % row_pairs;
   p.cursor_f = (workgroups / p.tiles_x) / row_pairs;
-  const size_t lds = kRepLumaBytes + (static_cast<size_t>(p.table_linear_bytes) << r1) + (static_cast<size_t>(enc_bytes) << r2);
+  const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << r1) + (static_cast<size_t>(enc_bytes) << r2);
   if (nontemporal)
     hipLaunchKernelGGL((decode_nv12_half_rep<true, BT709_REP_STEP>), dim3(workgroups), dim3(threads), lds, stream, p);
   else
