@@ -823,37 +823,95 @@ render_scaled(const RenderParams p) {
   const uint32_t xs[2] = {static_cast<uint32_t>(min(max(xi, 0), wmax)), static_cast<uint32_t>(min(max(xi + 1, 0), wmax))};
   constexpr uint32_t kTexel = IN_RGBA16F ? 8u : 4u;
 
+  // Same walk as decode_nv12_scaled (see scaled_strip): vertical taps once per strip (lane i does row i,
+  // rows read them with v_readlane_b32), the two LINEARISED source rows of the previous output row kept
+  // in registers and only rows not seen yet converted, fetches unconditional and one output row ahead in
+  // two explicit register sets, the intermediate as a raw buffer resource (scalar row offset).
   const uint32_t oy0 = blockIdx.y * p.rows, oy1 = min(oy0 + p.rows, p.out_height);
-  for (uint32_t oy = oy0; oy < oy1; ++oy) {
-    const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy), 0.5f), p.scale_y), -0.5f);
-    const float y0f = __builtin_floorf(sy);
-    const float fy = __fadd_rn(sy, -y0f), gy = __fadd_rn(1.0f, -fy);
-    const int yi = static_cast<int>(y0f);
-    const uint32_t ys[2] = {static_cast<uint32_t>(min(max(yi, 0), hmax)), static_cast<uint32_t>(min(max(yi + 1, 0), hmax))};
-    const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // R, G, B, A
+  const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const float sy_l = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy0 + lane_id), 0.5f), p.scale_y), -0.5f);
+  const float y0f_l = __builtin_floorf(sy_l);
+  const float fy_l = __fadd_rn(sy_l, -y0f_l);
+  const int yi_l = static_cast<int>(y0f_l);
+  struct RowTaps {
+    int ys[2];
+    float fy;
+  };
+  auto row_taps = [&](uint32_t oy) {
+    RowTaps rt;
+    const int k = static_cast<int>(oy - oy0);
+    rt.fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy_l), k));
+    const int yi = __builtin_amdgcn_readlane(yi_l, k);
+    rt.ys[0] = min(max(yi, 0), hmax);
+    rt.ys[1] = min(max(yi + 1, 0), hmax);
+    return rt;
+  };
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.in), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7fffffff, 0x00020000);
+  struct Fetched {  // the two texels of a source row, untouched
+    uint32_t w[IN_RGBA16F ? 4 : 2];
+  };
+  auto fetch_row = [&](int srow) {
+    Fetched v;
+    const int ro = srow * static_cast<int>(p.in_stride);
+    if (IN_RGBA16F) {
+      const u32x2 t0 = __builtin_amdgcn_raw_buffer_load_b64(rin, xs[0] * kTexel, ro, 0);
+      const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(rin, xs[1] * kTexel, ro, 0);
+      v.w[0] = t0.x, v.w[1] = t0.y, v.w[2] = t1.x, v.w[3] = t1.y;
+    } else {
+      v.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rin, xs[0] * kTexel, ro, 0);
+      v.w[1] = __builtin_amdgcn_raw_buffer_load_b32(rin, xs[1] * kTexel, ro, 0);
+    }
+    return v;
+  };
+  auto landed = [&](const Fetched &v) {
+    if (IN_RGBA16F) asm volatile("" ::"v"(v.w[0]), "v"(v.w[1]), "v"(v.w[2]), "v"(v.w[3]));
+    else asm volatile("" ::"v"(v.w[0]), "v"(v.w[1]));
+  };
+  struct RowLin {
+    float s[8];  // R, G, B, A of tap 0; R, G, B, A of tap 1: what the sampler hands the filter
+  };
+  auto convert_row = [&](const Fetched &f) {
+    RowLin rl;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint8_t *px = p.in + static_cast<size_t>(ys[t >> 1]) * p.in_stride + static_cast<size_t>(xs[t & 1]) * kTexel;
-      float s[4];
+    for (int t = 0; t < 2; ++t) {
+      float *s = rl.s + 4 * t;
       if (IN_RGBA16F) {
-        const u32x2 v = *reinterpret_cast<const u32x2 *>(px);
-        s[0] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v.x & 0xffffu)));
-        s[1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v.x >> 16)));
-        s[2] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v.y & 0xffffu)));
-        s[3] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v.y >> 16)));
+        const uint32_t lo = f.w[2 * t], hi = f.w[2 * t + 1];
+        s[0] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(lo & 0xffffu)));
+        s[1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(lo >> 16)));
+        s[2] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(hi & 0xffffu)));
+        s[3] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(hi >> 16)));
       } else {
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(px);
+        const uint32_t v = f.w[t];
         s[0] = *reinterpret_cast<LdsFloatPtr>(((v >> 14) & 0x3fcu) + lin_off);  // R: byte 2
         s[1] = *reinterpret_cast<LdsFloatPtr>(((v >> 6) & 0x3fcu) + lin_off);   // G: byte 1
         s[2] = *reinterpret_cast<LdsFloatPtr>(((v << 2) & 0x3fcu) + lin_off);   // B: byte 0
         s[3] = __fmul_rn(byte_of(v, 3), kInv255);                                // byteNorm
       }
+    }
+    return rl;
+  };
+  int have_top = -1, have_bot = -1;
+  RowLin top = {}, bot = {};
+  auto output_row = [&](uint32_t oy, const RowTaps &rt, const Fetched &f0, const Fetched &f1) {
+    landed(f0);
+    landed(f1);
+    if (rt.ys[0] == have_bot) top = bot;
+    else if (rt.ys[0] != have_top) top = convert_row(f0);
+    if (rt.ys[1] == rt.ys[0]) bot = top;
+    else if (rt.ys[1] != have_bot) bot = convert_row(f1);
+    have_top = rt.ys[0];
+    have_bot = rt.ys[1];
+    const float fy = rt.fy, gy = __fadd_rn(1.0f, -fy);
+    const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+    float acc[4];  // R, G, B, A
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float term = __fmul_rn(w[t], s[k]);
-        acc[k] = t ? __fadd_rn(acc[k], term) : term;
-      }
+    for (int k = 0; k < 4; ++k) {
+      acc[k] = __fmul_rn(w[0], top.s[k]);
+      acc[k] = __fadd_rn(acc[k], __fmul_rn(w[1], top.s[4 + k]));
+      acc[k] = __fadd_rn(acc[k], __fmul_rn(w[2], bot.s[k]));
+      acc[k] = __fadd_rn(acc[k], __fmul_rn(w[3], bot.s[4 + k]));
     }
     const uint32_t R = encode_byte(r, __fmul_rn(add_sat(acc[0], 0.0f), p.encode_scale));
     const uint32_t G = encode_byte(r, __fmul_rn(add_sat(acc[1], 0.0f), p.encode_scale));
@@ -863,8 +921,28 @@ render_scaled(const RenderParams p) {
     uint32_t at[4];
     magic_index4(ax, at, unit.magic);
     const uint32_t A = bucket_byte(unit, av, at[0]) << 24;
-    reinterpret_cast<uint32_t *>(p.out + static_cast<size_t>(oy) * p.out_stride)[ox] = pack_bgra(R, G, B, A);
+    __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, A), rout, ox * 4u, oy * p.out_stride, 0);
+  };
+  const uint32_t last = oy1 - 1;
+  RowTaps rta = row_taps(oy0), rtb;
+  Fetched a0 = fetch_row(rta.ys[0]), a1 = fetch_row(rta.ys[1]), b0, b1;
+  for (uint32_t oy = oy0; oy < oy1; oy += 2) {
+    rtb = row_taps(min(oy + 1, last));
+    b0 = fetch_row(rtb.ys[0]);
+    b1 = fetch_row(rtb.ys[1]);
+    output_row(oy, rta, a0, a1);
+    if (oy + 1 >= oy1) {
+      landed(b0);
+      landed(b1);
+      break;
+    }
+    rta = row_taps(min(oy + 2, last));
+    a0 = fetch_row(rta.ys[0]);
+    a1 = fetch_row(rta.ys[1]);
+    output_row(oy + 1, rtb, b0, b1);
   }
+  landed(a0);
+  landed(a1);
 }
 
 const char *launch_render_scaled(const RenderParams &p_in, bool in_rgba16f, uint32_t compute_units, hipStream_t stream) {
@@ -872,8 +950,10 @@ const char *launch_render_scaled(const RenderParams &p_in, bool in_rgba16f, uint
   const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
   const uint64_t want = 8ull * (compute_units ? compute_units : 256u);
   uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height / want);
-  rows = rows < 1 ? 1 : (rows > 32 ? 32 : rows);
+  rows = rows < 1 ? 1 : (rows > 16 ? 16 : rows);
   p.rows = rows;
+  // the kernel forms row offsets in 32 bits
+  if (static_cast<uint64_t>(p.height) * p.in_stride >= (1ull << 31) || static_cast<uint64_t>(p.out_height) * p.out_stride >= (1ull << 31)) return nullptr;
   const dim3 grid(cols, (p.out_height + rows - 1) / rows, 1);
   const size_t lds = static_cast<size_t>(p.table_encode_bytes) + p.table_unit_bytes + 1024;
   if (in_rgba16f) hipLaunchKernelGGL(render_scaled<true>, grid, dim3(kBlockThreads), lds, stream, p);

@@ -968,8 +968,10 @@ int bt709hip_render_scaled(bt709hip_context *ctx, const bt709hip_surface *in, co
   p.encode_offset = ctx->render_encode_offset;
   p.encode_shift = ctx->render_encode_shift;
   p.unit_magic = 8388608.0f / static_cast<float>(ctx->render_unit_n);
-  tl_kernel_name = launch_render_scaled(p, in->format == BT709HIP_FORMAT_RGBA16F,
-                                        static_cast<uint32_t>(ctx->props.multiProcessorCount), s);
+  const char *name = launch_render_scaled(p, in->format == BT709HIP_FORMAT_RGBA16F,
+                                          static_cast<uint32_t>(ctx->props.multiProcessorCount), s);
+  if (name == nullptr) return BT709HIP_ERR_UNSUPPORTED;  // a surface of 2 GiB or more
+  tl_kernel_name = name;
   return finish_launch(s, wait_until_completed);
 }
 
