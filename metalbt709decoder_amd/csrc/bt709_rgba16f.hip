@@ -9,8 +9,8 @@
 //   * below the curve's split point the reference multiplies by a constant: one exact float multiply
 //     and the hardware conversion (v_cvt_f16_f32, round to nearest even) give H directly;
 //   * above it, exp2(g * log2(base)) from v_log_f32 / v_exp_f32 is good to ~2^-20 -- far finer than a
-//     half's 2^-11 spacing -- so its half h0 is H or a neighbour, and the two thresholds around h0
-//     settle it exactly:  H = h0 + (x >= T[h0 + 1]) - (x < T[h0])   (transfer_tables.h HalfTable).
+//     half's 2^-11 spacing -- and is pushed down a little on purpose, so its half h0 is H or H - 1 and the
+//     one threshold above h0 settles it exactly:  H = h0 + (x >= T[h0 + 1])   (transfer_tables.h HalfTable).
 // T is indexed by the OUTPUT code: one entry per step of H, 24-34 KiB in LDS, staged once per
 // workgroup; a workgroup therefore walks several row pairs (the 8-bit kernel's 4 KiB table allows
 // one short-lived workgroup per row pair, this one's does not).
@@ -51,18 +51,8 @@ __device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
   float lowv = __fmul_rn(x, t.low_scale);  // exact below the split for 1/16; x itself when there is no curve
   asm("" : "+v"(lowv));
   if (!HAS_TABLE) return half_bits(lowv);
-#if defined(BT709_RGBA16F_TWO_SIDED)  // round 2's first form: unbiased candidate, both neighbours' thresholds, the low piece apart
-  const uint32_t low = half_bits(lowv);
-  float xb;  // max(x, split): keeps the candidate inside the table whatever x is
-  asm("v_max_f32 %0, %1, %2" : "=v"(xb) : "v"(x), "s"(t.split));
-  const float base = HAS_PRE ? __fmul_rn(__fadd_rn(xb, t.pre_add), t.pre_scale) : xb;
-  const float p = __builtin_amdgcn_exp2f(__fmul_rn(t.exponent, __builtin_amdgcn_logf(base)));  // v_log_f32 is log2
-  const uint32_t h0 = half_bits(p);
-  typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
-  const LdsFloatPtr e = reinterpret_cast<LdsFloatPtr>((h0 << 2) + t.table_off);
-  const uint32_t h = h0 + (xb >= e[1] ? 1u : 0u) - (xb < e[0] ? 1u : 0u);
-  return x < t.split ? low : h;
-#else
+  // (Round 2's first form -- unbiased candidate, both neighbours' thresholds, x clamped to the split, the low piece
+  // converted apart: commit 8e386e3 -- ran at 0.70 against 0.77, profiles/r02_ab_rgba16f.txt.)
   // Above the split the candidate is pushed DOWN by kHalfBias in the exponent (a factor 1 - 1.4e-5: several
   // times the error of v_log_f32 * g -> v_exp_f32, a thirtieth of a half's spacing), so its half is H or
   // H - 1, never H + 1, and ONE threshold settles it: H = h0 + (x >= T[h0 + 1]).  The bias rides in the fma
@@ -78,7 +68,6 @@ __device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
   const LdsFloatPtr e = reinterpret_cast<LdsFloatPtr>((max(h0, t.h_below) << 2) + t.table_off);
   return h0 + (x >= e[1] ? 1u : 0u);
-#endif
 }
 
 }  // namespace

@@ -146,9 +146,9 @@ bool build_uniform_table(int kind, uint32_t n_min, UniformTable *out);
 // a monotone step function of the saturated x with up to 15 360 steps: too many for a bucket table
 // that must sit in LDS beside resident workgroups.  Below the curve's split point the reference
 // multiplies by an exact constant and the hardware conversion gives H directly; above it the
-// kernel takes a CANDIDATE h0 from a fast exp2(g log2 x) (good to ~2^-20, so h0 is H or a
-// neighbour) and settles it against the two thresholds next to it:
-//     H = h0 + (x >= T[h0 + 1]) - (x < T[h0]),   T[h] = smallest float x with H(x) >= h
+// kernel takes a CANDIDATE h0 from a fast exp2(g log2 x) (good to ~2^-20 and biased downward by more
+// than that, so h0 is H or H - 1) and settles it against the threshold above it:
+//     H = h0 + (x >= T[h0 + 1]),   T[h] = smallest float x with H(x) >= h
 // T is indexed by the OUTPUT code, so it holds exactly one entry per step (8-9 k entries, ~34 KiB).
 struct HalfTable {
   int gamma = 0;
