@@ -707,6 +707,14 @@ def test_launch_limits_are_reported_not_launched(gh):
     assert dec.lastStatus == _capi.ERR_UNSUPPORTED
     tex = ctx.makeBGRATexture((4, 2 * 65536 + 4))
     assert not mb.BGRAToBT709Converter.convertIntoCoreVideoBuffer(tex, buf, mb.MetalBT709GammaSRGB, mb.MetalBT709GammaApple)
+    # the any-ratio kernels form row offsets in 32 bits: a plane of 2 GiB or more (here: by its pitch; nothing is
+    # dereferenced) is refused, not wrapped
+    import ctypes as C
+    view = ctx.makeBGRATexture((8, 8))
+    like = small.frame()
+    wide = _capi.Frame(like.y, 1 << 22, like.cbcr, 1 << 22, 16, 1024, like.matrix, like.transfer)
+    surf = _capi.Surface(view.ptr, 32, 8, 8, _capi.FORMAT_BGRA8_SRGB, 0)
+    assert ctx.lib.bt709hip_decode_scaled(dec._handle, C.byref(wide), None, C.byref(surf), None, 1) == _capi.ERR_UNSUPPORTED
 
 
 def test_lazily_built_tables_are_refused_inside_a_capture(gh, oracle):
