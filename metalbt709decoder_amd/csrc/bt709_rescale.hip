@@ -498,20 +498,45 @@ decode_nv12_half_rep(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 enum : int { TAPS_BYTES = 0, TAPS_PAIRS = 1, TAPS_WIDE = 2, TAPS_SHARED = 3 };
 
-// Output column `ox_raw` of frame `f`, output rows [oy0, oy1) (at most 64).
+// Vertical taps of a strip of at most 64 output rows starting at oy0: lane i holds row oy0 + i (sy = (oy + 0.5f) *
+// scale_y - 0.5f, y0 = floor(sy), fy = sy - y0).  gfx950 has no scalar float unit, so one evaluation costs 8 VALU
+// instructions per row whichever way it is written; done once per strip by the lanes in parallel, a row takes its
+// two numbers with v_readlane_b32 -- which also puts them in SGPRs, so row offsets and the row-cache tests are scalar
+// work.  MUST run while all 64 lanes of the wave are alive: v_readlane_b32 reads a lane's register whatever EXEC says,
+// but a lane that left before this point never wrote it.
+struct StripTaps {
+  float fy;
+  int yi;
+};
+__device__ __forceinline__ StripTaps strip_taps(uint32_t oy0, float scale_y) {
+  const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const float sy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy0 + lane), 0.5f), scale_y), -0.5f);
+  const float y0f = __builtin_floorf(sy);
+  StripTaps t;
+  t.fy = __fadd_rn(sy, -y0f);
+  t.yi = static_cast<int>(y0f);
+  // pinned HERE: the values are pure functions of the lane id, and hipcc otherwise sinks them past the caller's
+  // early return of the lanes beyond the row's end -- whose registers the other lanes read
+  asm volatile("" : "+v"(t.fy), "+v"(t.yi));
+  return t;
+}
+
+// Output column `ox_raw` of frame `f`, output rows [oy0, oy1) (at most 64).  `vt` = the strip's vertical taps,
+// worked out by ALL 64 lanes of the wave before any of them left (strip_taps): lane i holds row oy0 + i.
 //   TAPS_BYTES / TAPS_PAIRS / TAPS_WIDE: the lane fetches its own taps (see above); lanes past the
-//     row's end must not call.
+//     row's end must not call (a predicated store in their place cost 8 % in the same call).
 //   TAPS_SHARED (layout as TAPS_WIDE, 64 * scale_x + 12 <= 252): the WAVE fetches a source row -- lane l
 //     loads the l-th dword of the 256-byte span that starts at lane 0's window, one fully coalesced
 //     access per plane (4 cache accesses per wave instruction against ~17 for per-lane 8-byte windows at
 //     4-byte granularity) -- and a lane picks its windows out of its neighbours' registers with four
 //     ds_bpermute_b32 when (and only when) the row is decoded.  Pays when most fetched rows are not
-//     decoded, i.e. when enlarging; the launcher picks it for scale_y < 1.  All 64 lanes must call; `live`
-//     masks the store.
+//     decoded, i.e. when enlarging; the launcher picks it for scale_y < 1.  All 64 lanes must call;
+//     `live` masks the store.
 //   UNIFORM_ENCODE: the encode side goes through the uniform table (staged with sum_log2 = 0).
 template <int TAPS, bool HAS_ALPHA, bool UNIFORM_ENCODE>
 __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const RescaleLookup &r, const AlphaLookup &al,
-                                             const FramePlanes &f, uint32_t ox_raw, uint32_t oy0, uint32_t oy1) {
+                                             const FramePlanes &f, uint32_t ox_raw, uint32_t oy0, uint32_t oy1, const StripTaps &vt) {
+  // TAPS_SHARED: every lane of the wave stays alive; one past the row's end works on the last column again and does not store
   const bool live = ox_raw < p.out_width;
   const uint32_t ox = TAPS == TAPS_SHARED ? min(ox_raw, p.out_width - 1u) : ox_raw;
 
@@ -534,24 +559,16 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
   const uint32_t yoff = min(wybase + 4u * lane, p.width - 4u), coff = min(wcbase + 4u * lane, p.width - 4u);
   const uint32_t ysrc = ybase - wybase, csrc = cbase - wcbase;
 
-  // Vertical taps: the same for every lane.  gfx950 has no scalar float unit, so one evaluation costs 8
-  // VALU instructions per row whichever way it is written; instead lane i works out row oy0 + i of the strip
-  // once (a strip has at most 64 rows) and each row then takes its two numbers with v_readlane_b32 -- which
-  // also puts them in SGPRs, so row offsets and the row-cache tests are scalar work.
+  // vertical taps of a row: the same for every lane, taken from the strip's lanes (strip_taps)
   struct RowTaps {
     int ys[2];
     float fy;
   };
-  const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const float sy_l = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy0 + lane_id), 0.5f), p.scale_y), -0.5f);
-  const float y0f_l = __builtin_floorf(sy_l);
-  const float fy_l = __fadd_rn(sy_l, -y0f_l);
-  const int yi_l = static_cast<int>(y0f_l);
   auto row_taps = [&](uint32_t oy) {
     RowTaps rt;
     const int k = static_cast<int>(oy - oy0);
-    rt.fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy_l), k));
-    const int yi = __builtin_amdgcn_readlane(yi_l, k);
+    rt.fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vt.fy), k));
+    const int yi = __builtin_amdgcn_readlane(vt.yi, k);
     rt.ys[0] = min(max(yi, 0), hmax);
     rt.ys[1] = min(max(yi + 1, 0), hmax);
     return rt;
@@ -772,9 +789,10 @@ decode_nv12_scaled(const DecodeParams p) {
   const FramePlanes f = frame_planes(p, blockIdx.z);
   const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t oy0 = (blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y)) * p.scaled_rows;
-  if (oy0 >= p.out_height) return;
+  if (oy0 >= p.out_height) return;  // the whole wave
+  const StripTaps vt = strip_taps(oy0, p.scale_y);  // before any lane leaves
   if (TAPS != TAPS_SHARED && ox >= p.out_width) return;  // TAPS_SHARED: the wave fetches together
-  scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, al, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height));
+  scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, al, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height), vt);
 }
 
 // ---------------------------------------------------------------------------
@@ -813,6 +831,8 @@ render_scaled(const RenderParams p) {
   const uint32_t lin_off = lds_address(lds_raw + p.table_encode_bytes + p.table_unit_bytes);
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
 
+  const uint32_t oy0 = blockIdx.y * p.rows, oy1 = min(oy0 + p.rows, p.out_height);
+  const StripTaps vt = strip_taps(oy0, p.scale_y);  // before any lane leaves
   const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x;
   if (ox >= p.out_width) return;
   const float sx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ox), 0.5f), p.scale_x), -0.5f);
@@ -827,12 +847,6 @@ render_scaled(const RenderParams p) {
   // rows read them with v_readlane_b32), the two LINEARISED source rows of the previous output row kept
   // in registers and only rows not seen yet converted, fetches unconditional and one output row ahead in
   // two explicit register sets, the intermediate as a raw buffer resource (scalar row offset).
-  const uint32_t oy0 = blockIdx.y * p.rows, oy1 = min(oy0 + p.rows, p.out_height);
-  const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const float sy_l = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(oy0 + lane_id), 0.5f), p.scale_y), -0.5f);
-  const float y0f_l = __builtin_floorf(sy_l);
-  const float fy_l = __fadd_rn(sy_l, -y0f_l);
-  const int yi_l = static_cast<int>(y0f_l);
   struct RowTaps {
     int ys[2];
     float fy;
@@ -840,8 +854,8 @@ render_scaled(const RenderParams p) {
   auto row_taps = [&](uint32_t oy) {
     RowTaps rt;
     const int k = static_cast<int>(oy - oy0);
-    rt.fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy_l), k));
-    const int yi = __builtin_amdgcn_readlane(yi_l, k);
+    rt.fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vt.fy), k));
+    const int yi = __builtin_amdgcn_readlane(vt.yi, k);
     rt.ys[0] = min(max(yi, 0), hmax);
     rt.ys[1] = min(max(yi + 1, 0), hmax);
     return rt;
@@ -1050,6 +1064,7 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
 #ifndef BT709_SCALED_MAX_ROWS
 #define BT709_SCALED_MAX_ROWS 16
 #endif
+  static_assert(BT709_SCALED_MAX_ROWS <= 64, "one lane per row of a strip works out its vertical taps");
   const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
   const uint64_t want = static_cast<uint64_t>(BT709_SCALED_WG_PER_CU) * cus * kScaledStrips;
   uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height * static_cast<uint32_t>(frames) / want);

@@ -151,6 +151,42 @@ def test_gpu_scaled_batch(gh, oracle, count):
 
 
 @pytest.mark.gpu
+def test_gpu_scaled_strips_with_a_ragged_last_wave(gh, oracle):
+    """The vertical taps of a strip are worked out by its first lanes (lane i: row i) and read with
+    v_readlane_b32: an output width that leaves the last wave with FEWER live columns than a strip has rows
+    must not change that.  8 frames of 64x600 -> 65x600 / 130x300: several rows per strip, one live column in
+    the last wave; pass 2 alone on the same shapes."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    scale = mb.MetalScaleRenderContext()
+    assert scale.setupRenderPipelines(ctx)
+    for (w, h), (ow, oh), count in (((64, 600), (65, 600), 8), ((64, 600), (129, 1100), 8), ((256, 64), (321, 2500), 1)):
+        in_pitch, out_pitch = w * h * 3 // 2, ow * oh * 4
+        slab_in, slab_out = DeviceBuffer(ctx, count * in_pitch), DeviceBuffer(ctx, count * out_pitch)
+        frames = [_frame(w, h, 900 + i) for i in range(count)]
+        bufs, texs = [], []
+        for i, (y, c) in enumerate(frames):
+            base = slab_in.ptr + i * in_pitch
+            b = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h))
+            mb.BGRAToBT709Converter.setBT709Attributes(b)
+            b.upload_planes(y, c)
+            bufs.append(b)
+            texs.append(mb.BGRATexture(ctx, ow, oh, ow * 4, ptr=slab_out.ptr + i * out_pitch))
+        assert dec.decodeBT709ScaledBatch(bufs, texs, ctx.commandQueue.commandBuffer(), True), dec.lastStatus
+        for (y, c), t in zip(frames, texs):
+            got = ctx.getBGRATexturePixels(t).view(np.uint8).reshape(oh, ow * 4)
+            assert np.array_equal(got, oracle.decode_nv12_scaled(0, y, c, ow, oh)), (w, h, ow, oh)
+        # pass 2 alone from the 8-bit intermediate of frame 0
+        y, c = frames[0]
+        inter, view = ctx.makeBGRATexture((w, h)), ctx.makeBGRATexture((ow, oh))
+        assert dec.decodeBT709(bufs[0], None, inter, None, None, w, h, False)
+        assert scale.renderScaled(ctx, view, ow, oh, None, None, inter, True)
+        got = ctx.getBGRATexturePixels(view).view(np.uint8).reshape(oh, ow * 4)
+        assert np.array_equal(got, oracle.decode_nv12_scaled(0, y, c, ow, oh)), ("pass 2", w, h, ow, oh)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rep", ["0", "1"])
 def test_fuzzed_rescale_geometry(gh, oracle, rep):
     """Seeded fuzz over the rescale entry points: any 4-multiple source size, any plane pitch and
