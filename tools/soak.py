@@ -32,6 +32,8 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
         got = gh.gpu_decode_half(y, c, g, decoder=dec, alpha=a); want = oracle.decode_nv12_half(g, y, c, alpha=a)
     elif kind == 2:
         ow, oh = int(rng.integers(1, 2 * w)), int(rng.integers(1, 2 * h))
+        if rng.integers(0, 4) == 0:  # tall, narrow views: several output rows per strip, ragged last wave
+            ow, oh = int(rng.integers(1, 140)), int(rng.integers(4100, 12000))
         got = gh.gpu_decode_scaled(y, c, (ow, oh), g, alpha=a); want = oracle.decode_nv12_scaled(g, y, c, ow, oh, alpha=a)
     elif kind == 3:  # RGBA16Float target
         dec = gh.make_decoder(g, has_alpha=a is not None)
@@ -41,6 +43,8 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
     elif kind == 4:  # two passes, either intermediate
         fmt = mb.MTLPixelFormatRGBA16Float if rng.integers(0, 2) else mb.MTLPixelFormatBGRA8Unorm_sRGB
         ow, oh = int(rng.integers(1, 2 * w)), int(rng.integers(1, 2 * h))
+        if rng.integers(0, 4) == 0:
+            ow, oh = int(rng.integers(1, 140)), int(rng.integers(4100, 12000))
         dec = gh.make_decoder(g, has_alpha=a is not None)
         inter, view = ctx.makeBGRATexture((w, h), pixelFormat=fmt), ctx.makeBGRATexture((ow, oh))
         assert dec.decodeBT709(gh.make_buffer(y, c, dec.gamma), gh.make_alpha_buffer(a) if a is not None else None, inter, None, None, w, h, False)
