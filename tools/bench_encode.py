@@ -33,8 +33,12 @@ def main():
     ap.add_argument("--row-pairs", type=int, default=0, help="bt709hip_context_option ENCODE_ROW_PAIRS (0 = sized per launch)")
     ap.add_argument("--frames-per-launch", type=int, default=1,
                     help="> 1: bt709hip_encode_batch over a ring carved from one allocation")
+    ap.add_argument("--library", default=None, help="a variant build of libbt709hip.so (python -m metalbt709decoder_amd.build --variant)")
     args = ap.parse_args()
     W, H = args.width, args.height
+    if args.library:
+        from metalbt709decoder_amd import _capi as _c
+        _c.load(os.path.abspath(args.library))
     ctx = mb.MetalRenderContext(0)
     assert ctx.setupMetal()
     lib, h = ctx.lib, ctx.handle
