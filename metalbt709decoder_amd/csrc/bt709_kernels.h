@@ -48,10 +48,6 @@ struct DecodeParams {
   const void *table_encode_u;
   uint32_t table_encode_u_bytes;
   float encode_u_n;
-  // alpha decoders, rescale kernels: TransferBucketLinear[N + 1] whose values are byteNorm(byte)
-  // (transfer_tables.h buckets_bytenorm): pass 2 filters the alpha channel as a plain unorm
-  const void *table_alpha;
-  uint32_t table_alpha_bytes;
   uint32_t table_unit_bytes;
   uint32_t table_linear_bytes;
   uint32_t table_encode_bytes;
@@ -104,13 +100,12 @@ struct RenderParams {
   uint32_t width, height, out_width, out_height;
   float scale_x, scale_y;
   uint32_t rows;       // output rows a workgroup walks (filled by the launcher)
-  // tables (device): two-resolution sRGB-encode buckets, the sRGB-mode byte table (round(255 v): the alpha
-  // quantiser) and lin[256] = sRGB_nonLinearNormToLinear(byteNorm(b))
-  const void *table_encode, *table_unit, *table_lin;
-  uint32_t table_encode_bytes, table_unit_bytes;
+  // tables (device): two-resolution sRGB-encode buckets and lin[256] = sRGB_nonLinearNormToLinear(byteNorm(b))
+  // (the alpha channel is filtered and quantised in arithmetic)
+  const void *table_encode, *table_lin;
+  uint32_t table_encode_bytes;
   float encode_scale;  // n_fine of table_encode
   uint32_t encode_offset, encode_shift;
-  float unit_magic;    // 2^23 / N of table_unit
 };
 const char *launch_render_scaled(const RenderParams &p, bool in_rgba16f, uint32_t compute_units, hipStream_t stream);
 
@@ -183,7 +178,7 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
 // each walking tile rows workgroup, workgroup + grid, ...; fills the rep_*, tiles_x, tile_rows and cursor_*
 // fields of its copy of `p`.  Returns nullptr when the tables do not fit LDS (caller falls back).
 // lds_budget: LDS bytes one workgroup may take (kRepLdsBytes = one workgroup per CU).
-const char *launch_decode_half_rep(const DecodeParams &p, int frames, bool nontemporal, uint32_t workgroups,
+const char *launch_decode_half_rep(const DecodeParams &p, int frames, bool has_alpha, bool nontemporal, uint32_t workgroups,
                                    uint32_t lds_budget, hipStream_t stream);
 constexpr int kRepBlockThreads = 1024;      // one workgroup per CU: 16 waves
 constexpr uint32_t kRepLdsBytes = 160 * 1024;

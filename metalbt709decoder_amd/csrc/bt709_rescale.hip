@@ -162,62 +162,28 @@ __device__ __forceinline__ void linearise6(const RescaleLookup &r, const float *
 }
 
 // Alpha decoders only.  Pass 2 reads the alpha channel of the 8-bit intermediate as a plain unorm
-// (AAPLShaders.metal:411-438 writes it, the sampler of MetalScaleRenderContext.m:55-105 filters
-// it): each tap is byteNorm(decoded alpha byte), the result round(255 v).  The byteNorm table has
-// the decode table's buckets (an alpha decoder runs the sRGB mode, whose composite is round(255 x)),
-// and that same mode's byte table quantises the filtered value.  Both sit behind the two rescale
-// tables in LDS, single copies.
-struct AlphaLookup {
-  uint32_t norm_off;  // LDS address of the byteNorm table - (bits(magic) << 4)
-  UnitLookup unit;    // the decoder's byte table (sRGB mode: the quantiser)
-  float unscale;      // 2^40: the byteNorm values are stored times 2^-40 like the linear ones
-};
-
-__device__ __forceinline__ AlphaLookup stage_alpha_tables(unsigned char *lds, const DecodeParams &p) {
-  const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
-  u32x4 *d = reinterpret_cast<u32x4 *>(lds);
-  const u32x4 *a = reinterpret_cast<const u32x4 *>(p.table_alpha);
-  const u32x4 *u = reinterpret_cast<const u32x4 *>(p.table_unit);
-  const uint32_t na = p.table_alpha_bytes / 16, nu = p.table_unit_bytes / 16;
-  for (uint32_t i = tid; i < na; i += nthreads) d[i] = a[i];
-  for (uint32_t i = tid; i < nu; i += nthreads) d[na + i] = u[i];
-  AlphaLookup r;
-  r.norm_off = lds_address(lds) - (__float_as_uint(p.unit_magic) << 4);
-  r.unit = unit_lookup(p.unit_magic, lds + p.table_alpha_bytes);
-  r.unscale = __uint_as_float(static_cast<uint32_t>(127 - kLinearScaleLog2) << 23);
-  return r;
+// (AAPLShaders.metal:411-438 writes it, the sampler of MetalScaleRenderContext.m:55-105 filters it): each tap is
+// byteNorm(decoded alpha byte), the result round(255 v).  No tables: an alpha decoder runs the sRGB mode, whose
+// composite is the plain quantiser, so the decoded alpha byte of a sample is (int)round(x * 255.0f) of its
+// saturated luma term x (BT709.h:881-883) -- for v in [0, 255] round-half-away is trunc(v + 0.5f), and v + 0.5f is
+// exact there -- and byteNorm is byte * (1/255f) (sRGB.h:32-36).  For the exact 2:1 case the filtered value
+// (sum * 0.25f) * 255.0f is one rounding of sum * 63.75f (the quarter is exact).  8 VALU instructions per sample,
+// 7 per output pixel.  (Round 2's first form went through a byteNorm bucket table and the quantiser table in LDS:
+// 151 against 217 Gpixel/s on 8K -> 4K with alpha, and the tables kept alpha out of the persistent kernel.)
+__device__ __forceinline__ float alpha_norm_arith(float abyte) {
+  const float v = __fmul_rn(alpha_value(abyte), 255.0f);
+  return __fmul_rn(__builtin_truncf(__fadd_rn(v, 0.5f)), kInv255);
 }
 
-// byteNorm (times 2^-40) of the alpha bytes of four linear alpha samples
-__device__ __forceinline__ void alpha_norm4(const AlphaLookup &a, float magic, const float *abyte, float *n) {
-  float x[4];
-  uint32_t t[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = alpha_value(abyte[i]);
-  magic_index4(x, t, magic);
-  u32x4 e[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<LdsQuadPtr>((t[i] << 4) + a.norm_off);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    n[i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z), __fadd_rn(x[i], -__uint_as_float(e[i].x)));
+// (alpha byte << 24) of a filtered alpha value: round(255 * saturate(v))
+__device__ __forceinline__ uint32_t alpha_word_of(float v) {
+  return static_cast<uint32_t>(__fadd_rn(__fmul_rn(add_sat(v, 0.0f), 255.0f), 0.5f)) << 24;  // v_cvt_u32_f32 truncates
 }
 
-// (alpha byte << 24) of a filtered alpha value v in [0, 1]: round(255 v)
-__device__ __forceinline__ uint32_t alpha_quantise(const AlphaLookup &a, float v) {
-  const float x[4] = {v, 0.0f, 0.0f, 0.0f};
-  uint32_t t[4];
-  magic_index4(x, t, a.unit.magic);
-  return bucket_byte(a.unit, v, t[0]) << 24;
-}
-
-// alpha word of one 2:1 output pixel from its four alpha samples
-__device__ __forceinline__ uint32_t half_alpha(const AlphaLookup &a, float magic, float a00, float a01, float a10, float a11) {
-  const float ab[4] = {a00, a01, a10, a11};
-  float n[4];
-  alpha_norm4(a, magic, ab, n);
-  const float quarter = __fmul_rn(0.25f, a.unscale);
-  return alpha_quantise(a, __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(n[0], n[1]), n[2]), n[3]), quarter));
+__device__ __forceinline__ uint32_t half_alpha_arith(float a00, float a01, float a10, float a11) {
+  const float s = __fadd_rn(__fadd_rn(__fadd_rn(alpha_norm_arith(a00), alpha_norm_arith(a01)), alpha_norm_arith(a10)), alpha_norm_arith(a11));
+  const float v = __fmul_rn(s, 63.75f);
+  return static_cast<uint32_t>(__fadd_rn(v, 0.5f)) << 24;  // v_cvt_u32_f32 truncates
 }
 
 // One output pixel of the exact 2:1 rescale: the four source pixels of a 2x2 block share one
@@ -277,7 +243,6 @@ decode_nv12_half(const DecodeParams p) {
   const uint8_t *a0 = HAS_ALPHA ? f.alpha + static_cast<size_t>(2 * orow) * p.alpha_stride : nullptr;
   const uint8_t *a1 = HAS_ALPHA ? a0 + p.alpha_stride : nullptr;
   uint8_t *o = f.out + static_cast<size_t>(orow) * p.out_stride;
-  unsigned char *lds_alpha = lds_raw + p.table_linear_bytes + p.table_encode_bytes;
 
   if (WIDE) {
     constexpr int UNROLL = kQuadsPerLane;
@@ -296,8 +261,6 @@ decode_nv12_half(const DecodeParams p) {
       }
     }
     const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);  // after the tile's loads are in flight
-    AlphaLookup al = {};
-    if (HAS_ALPHA) al = stage_alpha_tables(lds_alpha, p);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {  // see 1:1 kernel
@@ -309,16 +272,14 @@ decode_nv12_half(const DecodeParams p) {
       const uint32_t q = q0 + u * blockDim.x;
       uint32_t aw0 = p.alpha_word, aw1 = p.alpha_word;
       if (HAS_ALPHA) {
-        aw0 = half_alpha(al, r.magic, byte_of(aa[u], 0), byte_of(aa[u], 1), byte_of(ab[u], 0), byte_of(ab[u], 1));
-        aw1 = half_alpha(al, r.magic, byte_of(aa[u], 2), byte_of(aa[u], 3), byte_of(ab[u], 2), byte_of(ab[u], 3));
+        aw0 = half_alpha_arith(byte_of(aa[u], 0), byte_of(aa[u], 1), byte_of(ab[u], 0), byte_of(ab[u], 1));
+        aw1 = half_alpha_arith(byte_of(aa[u], 2), byte_of(aa[u], 3), byte_of(ab[u], 2), byte_of(ab[u], 3));
       }
       const u32x2 v = half_quad(r, ya[u], yb[u], cw[u], aw0, aw1);
       if (q < quads && orow_raw < out_rows) store8<NT>(o + 8 * q, v);
     }
   } else {
     const RescaleLookup r = stage_rescale_tables(lds_raw, p, 0, 0);
-    AlphaLookup al = {};
-    if (HAS_ALPHA) al = stage_alpha_tables(lds_alpha, p);
     __syncthreads();
     const uint32_t out_w = p.width >> 1;
     for (uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x; ox < out_w && orow_raw < out_rows;
@@ -326,7 +287,7 @@ decode_nv12_half(const DecodeParams p) {
       const Chroma c = chroma_terms(byte_value(cc[2 * ox]), byte_value(cc[2 * ox + 1]));
       uint32_t aw = p.alpha_word;
       if (HAS_ALPHA)
-        aw = half_alpha(al, r.magic, byte_value(a0[2 * ox]), byte_value(a0[2 * ox + 1]), byte_value(a1[2 * ox]),
+        aw = half_alpha_arith(byte_value(a0[2 * ox]), byte_value(a0[2 * ox + 1]), byte_value(a1[2 * ox]),
                         byte_value(a1[2 * ox + 1]));
       reinterpret_cast<uint32_t *>(o)[ox] = half_px(r, byte_value(y0[2 * ox]), byte_value(y0[2 * ox + 1]),
                                                     byte_value(y1[2 * ox]), byte_value(y1[2 * ox + 1]), c, aw);
@@ -370,7 +331,7 @@ struct TileCursor {
 };
 
 struct QuadIn {
-  uint32_t ya, yb, cw;
+  uint32_t ya, yb, cw, aa, ab;  // aa / ab: the alpha plane's two rows (alpha decoders)
 };
 
 __device__ __forceinline__ void advance(TileCursor &c, const DecodeParams &p, uint32_t row_pairs) {
@@ -387,7 +348,7 @@ __device__ __forceinline__ void advance(TileCursor &c, const DecodeParams &p, ui
   }
 }
 
-template <bool NT>
+template <bool NT, bool HAS_ALPHA>
 __device__ __forceinline__ QuadIn load_quad(const DecodeParams &p, const TileCursor &c, uint32_t quads) {
   const FramePlanes f = frame_planes(p, c.f);
   const uint8_t *y0 = f.y + static_cast<size_t>(2 * c.rp) * p.y_stride;
@@ -397,12 +358,18 @@ __device__ __forceinline__ QuadIn load_quad(const DecodeParams &p, const TileCur
   in.ya = load32<NT>(y0 + 4 * q);
   in.yb = load32<NT>(y0 + p.y_stride + 4 * q);
   in.cw = load32<NT>(cc + 4 * q);
+  in.aa = in.ab = 0;
+  if (HAS_ALPHA) {
+    const uint8_t *a0 = f.alpha + static_cast<size_t>(2 * c.rp) * p.alpha_stride;
+    in.aa = load32<NT>(a0 + 4 * q);
+    in.ab = load32<NT>(a0 + p.alpha_stride + 4 * q);
+  }
   return in;
 }
 
 }  // namespace
 
-template <bool NT, int U>
+template <bool NT, int U, bool HAS_ALPHA>
 __global__ void __launch_bounds__(kRepBlockThreads)
 decode_nv12_half_rep(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -418,7 +385,7 @@ decode_nv12_half_rep(const DecodeParams p) {
 
   // A step is U tile rows t, t + G, ...: their loads are issued one whole step ahead (first ones:
   // before the tables are staged).  Past the end of the launch a slot repeats the step's first tile
-  // row -- same loads, same result, same store -- so every step is exactly 3U loads and U stores
+  // row -- same loads, same result, same store -- so every step is exactly 3U (5U with an alpha plane) loads and U stores
   // and the in-order vmcnt hipcc derives never has to cover a shorter path.
   QuadIn in[U];
   {
@@ -427,7 +394,7 @@ decode_nv12_half_rep(const DecodeParams p) {
     for (int u = 0; u < U; ++u) {
       const bool have = t + u * G < p.tile_rows;
       const TileCursor c = {have ? pre.tx : first.tx, have ? pre.rp : first.rp, have ? pre.f : first.f};
-      in[u] = load_quad<NT>(p, c, quads);
+      in[u] = load_quad<NT, HAS_ALPHA>(p, c, quads);
       advance(pre, p, row_pairs);
     }
   }
@@ -446,7 +413,7 @@ decode_nv12_half_rep(const DecodeParams p) {
         const bool have = t + (U + u) * G < p.tile_rows;
         const TileCursor a = have ? pre : first;
         const TileCursor c = {any ? a.tx : cur.tx, any ? a.rp : cur.rp, any ? a.f : cur.f};
-        nx[u] = load_quad<NT>(p, c, quads);
+        nx[u] = load_quad<NT, HAS_ALPHA>(p, c, quads);
         advance(pre, p, row_pairs);
       }
     }
@@ -455,7 +422,12 @@ decode_nv12_half_rep(const DecodeParams p) {
     for (int u = 0; u < U; ++u) {
       const bool have = t + u * G < p.tile_rows;
       const TileCursor c = {have ? cur.tx : first.tx, have ? cur.rp : first.rp, have ? cur.f : first.f};
-      const u32x2 v = half_quad<kRepUniformEncode>(r, in[u].ya, in[u].yb, in[u].cw, p.alpha_word, p.alpha_word);
+      uint32_t aw0 = p.alpha_word, aw1 = p.alpha_word;
+      if (HAS_ALPHA) {
+        aw0 = half_alpha_arith(byte_of(in[u].aa, 0), byte_of(in[u].aa, 1), byte_of(in[u].ab, 0), byte_of(in[u].ab, 1));
+        aw1 = half_alpha_arith(byte_of(in[u].aa, 2), byte_of(in[u].aa, 3), byte_of(in[u].ab, 2), byte_of(in[u].ab, 3));
+      }
+      const u32x2 v = half_quad<kRepUniformEncode>(r, in[u].ya, in[u].yb, in[u].cw, aw0, aw1);
       const FramePlanes f = frame_planes(p, c.f);
       uint8_t *o = f.out + static_cast<size_t>(c.rp) * p.out_stride;
       // lanes past the row's end loaded the last quad (clamp), hold its result and store it again
@@ -535,7 +507,7 @@ __device__ __forceinline__ StripTaps strip_taps(uint32_t oy0, float scale_y) {
 //     `live` masks the store.
 //   UNIFORM_ENCODE: the encode side goes through the uniform table (staged with sum_log2 = 0).
 template <int TAPS, bool HAS_ALPHA, bool UNIFORM_ENCODE>
-__device__ __forceinline__ void scaled_strip(const DecodeParams &p, const RescaleLookup &r, const AlphaLookup &al,
+__device__ __forceinline__ void scaled_strip(const DecodeParams &p, const RescaleLookup &r,
                                              const FramePlanes &f, uint32_t ox_raw, uint32_t oy0, uint32_t oy1, const StripTaps &vt) {
   // TAPS_SHARED: every lane of the wave stays alive; one past the row's end works on the last column again and does not store
   const bool live = ox_raw < p.out_width;
@@ -678,11 +650,8 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
     linearise6(r, x, rl.v);
     rl.a[0] = rl.a[1] = 0.0f;
     if (HAS_ALPHA) {
-      const float ab[4] = {byte_of(fr.aa, 0), byte_of(fr.aa, 1), 0.0f, 0.0f};
-      float n[4];
-      alpha_norm4(al, r.magic, ab, n);
-      rl.a[0] = n[0];
-      rl.a[1] = n[1];
+      rl.a[0] = alpha_norm_arith(byte_of(fr.aa, 0));
+      rl.a[1] = alpha_norm_arith(byte_of(fr.aa, 1));
     }
     return rl;
   };
@@ -730,7 +699,7 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
       av = __fadd_rn(av, __fmul_rn(w[1], top.a[1]));
       av = __fadd_rn(av, __fmul_rn(w[2], bot.a[0]));
       av = __fadd_rn(av, __fmul_rn(w[3], bot.a[1]));
-      aw = alpha_quantise(al, add_sat(__fmul_rn(av, al.unscale), 0.0f));
+      aw = alpha_word_of(av);
     }
     if (TAPS != TAPS_SHARED || live)
       __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, oy * p.out_stride, 0);
@@ -789,8 +758,6 @@ __global__ void __launch_bounds__(kBlockThreads *kScaledStrips)
 decode_nv12_scaled(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const RescaleLookup r = stage_rescale_tables<kScaledUniform>(lds_raw, p, 0, 0, 0);
-  AlphaLookup al = {};
-  if (HAS_ALPHA) al = stage_alpha_tables(lds_raw + p.table_linear_bytes + (kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes), p);
   __syncthreads();
   if (PERSISTENT) {
     const uint32_t strips = (p.out_height + p.scaled_rows - 1) / p.scaled_rows;
@@ -804,7 +771,7 @@ decode_nv12_scaled(const DecodeParams p) {
       if (oy0 >= p.out_height) continue;  // the whole wave
       const StripTaps vt = strip_taps(oy0, p.scale_y);  // before any lane is masked off
       if (TAPS == TAPS_SHARED || ox < p.out_width)
-        scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, al, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height), vt);
+        scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height), vt);
     }
     return;
   }
@@ -814,7 +781,7 @@ decode_nv12_scaled(const DecodeParams p) {
   if (oy0 >= p.out_height) return;  // the whole wave
   const StripTaps vt = strip_taps(oy0, p.scale_y);  // before any lane leaves
   if (TAPS != TAPS_SHARED && ox >= p.out_width) return;  // TAPS_SHARED: the wave fetches together
-  scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, al, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height), vt);
+  scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height), vt);
 }
 
 // ---------------------------------------------------------------------------
@@ -827,21 +794,20 @@ decode_nv12_scaled(const DecodeParams p) {
 //                decode), alpha a plain unorm (byte * (1/255f))
 //   IN_RGBA16F = true:  a tap is four halves, linear light already (v_cvt_f32_f16)
 // The sum is saturated (a unorm render target clamps), rgb goes through the sRGB-encode table,
-// alpha through the round(255 v) table.
+// alpha is round(255 v) in arithmetic (alpha_word_of).
 // ---------------------------------------------------------------------------
 template <bool IN_RGBA16F>
 __global__ void __launch_bounds__(kBlockThreads)
 render_scaled(const RenderParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  {  // stage: encode buckets | byte table | lin[256]
+  {  // stage: encode buckets | lin[256]
     const uint32_t tid = threadIdx.x, n = blockDim.x;
     u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
-    const u32x4 *e = reinterpret_cast<const u32x4 *>(p.table_encode), *u = reinterpret_cast<const u32x4 *>(p.table_unit);
+    const u32x4 *e = reinterpret_cast<const u32x4 *>(p.table_encode);
     const u32x4 *l = reinterpret_cast<const u32x4 *>(p.table_lin);
-    const uint32_t ne = p.table_encode_bytes / 16, nu = p.table_unit_bytes / 16;
+    const uint32_t ne = p.table_encode_bytes / 16;
     for (uint32_t i = tid; i < ne; i += n) d[i] = e[i];
-    for (uint32_t i = tid; i < nu; i += n) d[ne + i] = u[i];
-    for (uint32_t i = tid; i < 64; i += n) d[ne + nu + i] = l[i];
+    for (uint32_t i = tid; i < 64; i += n) d[ne + i] = l[i];
   }
   __syncthreads();
   RescaleLookup r = {};
@@ -849,8 +815,7 @@ render_scaled(const RenderParams p) {
   r.enc_off = lds_address(lds_raw);
   r.split_offset = p.encode_offset;
   r.split_shift = p.encode_shift;
-  const UnitLookup unit = unit_lookup(p.unit_magic, lds_raw + p.table_encode_bytes);
-  const uint32_t lin_off = lds_address(lds_raw + p.table_encode_bytes + p.table_unit_bytes);
+  const uint32_t lin_off = lds_address(lds_raw + p.table_encode_bytes);
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
 
   const uint32_t oy0 = blockIdx.y * p.rows, oy1 = min(oy0 + p.rows, p.out_height);
@@ -952,11 +917,7 @@ render_scaled(const RenderParams p) {
     const uint32_t R = encode_byte(r, __fmul_rn(add_sat(acc[0], 0.0f), p.encode_scale));
     const uint32_t G = encode_byte(r, __fmul_rn(add_sat(acc[1], 0.0f), p.encode_scale));
     const uint32_t B = encode_byte(r, __fmul_rn(add_sat(acc[2], 0.0f), p.encode_scale));
-    const float av = add_sat(acc[3], 0.0f);
-    const float ax[4] = {av, 0.f, 0.f, 0.f};
-    uint32_t at[4];
-    magic_index4(ax, at, unit.magic);
-    const uint32_t A = bucket_byte(unit, av, at[0]) << 24;
+    const uint32_t A = alpha_word_of(acc[3]);
     __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, A), rout, ox * 4u, oy * p.out_stride, 0);
   };
   const uint32_t last = oy1 - 1;
@@ -991,7 +952,7 @@ const char *launch_render_scaled(const RenderParams &p_in, bool in_rgba16f, uint
   // the kernel forms row offsets in 32 bits
   if (static_cast<uint64_t>(p.height) * p.in_stride >= (1ull << 31) || static_cast<uint64_t>(p.out_height) * p.out_stride >= (1ull << 31)) return nullptr;
   const dim3 grid(cols, (p.out_height + rows - 1) / rows, 1);
-  const size_t lds = static_cast<size_t>(p.table_encode_bytes) + p.table_unit_bytes + 1024;
+  const size_t lds = static_cast<size_t>(p.table_encode_bytes) + 1024;
   if (in_rgba16f) hipLaunchKernelGGL(render_scaled<true>, grid, dim3(kBlockThreads), lds, stream, p);
   else hipLaunchKernelGGL(render_scaled<false>, grid, dim3(kBlockThreads), lds, stream, p);
   return in_rgba16f ? "render_scaled<rgba16f>" : "render_scaled<bgra8>";
@@ -1009,8 +970,7 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
   const uint32_t by = wide ? quads_rows_per_block(block_threads, grid_x) : 1;
   const dim3 grid(grid_x, (p.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
   const dim3 block(block_threads, by, 1);
-  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes +
-                     (has_alpha ? static_cast<size_t>(p.table_alpha_bytes) + p.table_unit_bytes : 0);
+  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + p.table_encode_bytes;
   if (has_alpha) {
     if (wide) hipLaunchKernelGGL((decode_nv12_half<true, true, true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((decode_nv12_half<false, false, true>), grid, block, lds, stream, p);
@@ -1025,7 +985,7 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
   return "decode_nv12_half<narrow>";
 }
 
-const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool nontemporal, uint32_t workgroups,
+const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool has_alpha, bool nontemporal, uint32_t workgroups,
                                    uint32_t lds_budget, hipStream_t stream) {
   DecodeParams p = p_in;
   const uint64_t kRepLdsBytes = (lds_budget < 16384u ? 16384u : (lds_budget > bt709::kRepLdsBytes ? bt709::kRepLdsBytes : lds_budget));
@@ -1049,10 +1009,15 @@ const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool no
   p.cursor_rp = (workgroups / p.tiles_x) % row_pairs;
   p.cursor_f = (workgroups / p.tiles_x) / row_pairs;
   const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << r1) + (static_cast<size_t>(enc_bytes) << r2);
+  if (has_alpha) {
+    if (nontemporal) hipLaunchKernelGGL((decode_nv12_half_rep<true, BT709_REP_STEP, true>), dim3(workgroups), dim3(threads), lds, stream, p);
+    else hipLaunchKernelGGL((decode_nv12_half_rep<false, BT709_REP_STEP, true>), dim3(workgroups), dim3(threads), lds, stream, p);
+    return "decode_nv12_half_rep<alpha>";
+  }
   if (nontemporal)
-    hipLaunchKernelGGL((decode_nv12_half_rep<true, BT709_REP_STEP>), dim3(workgroups), dim3(threads), lds, stream, p);
+    hipLaunchKernelGGL((decode_nv12_half_rep<true, BT709_REP_STEP, false>), dim3(workgroups), dim3(threads), lds, stream, p);
   else
-    hipLaunchKernelGGL((decode_nv12_half_rep<false, BT709_REP_STEP>), dim3(workgroups), dim3(threads), lds, stream, p);
+    hipLaunchKernelGGL((decode_nv12_half_rep<false, BT709_REP_STEP, false>), dim3(workgroups), dim3(threads), lds, stream, p);
   return "decode_nv12_half_rep";
 }
 
@@ -1094,8 +1059,7 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
   p.scaled_rows = rows;
   const uint32_t strips = (p.out_height + rows - 1) / rows;
   const uint32_t strip_groups = (strips + kScaledStrips - 1) / kScaledStrips;
-  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + (kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes) +
-                     (has_alpha ? static_cast<size_t>(p.table_alpha_bytes) + p.table_unit_bytes : 0);
+  const size_t lds = static_cast<size_t>(p.table_linear_bytes) + (kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes);
   const dim3 block(kBlockThreads, kScaledStrips);
   const bool persistent = taps != TAPS_SHARED;
   dim3 grid(cols, strip_groups, static_cast<uint32_t>(frames));
@@ -1137,8 +1101,10 @@ hipError_t prepare_rescale_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_half<false, false, false>),
       reinterpret_cast<const void *>(&decode_nv12_half<true, true, true>),
       reinterpret_cast<const void *>(&decode_nv12_half<false, false, true>),
-      reinterpret_cast<const void *>(&decode_nv12_half_rep<true, BT709_REP_STEP>),
-      reinterpret_cast<const void *>(&decode_nv12_half_rep<false, BT709_REP_STEP>),
+      reinterpret_cast<const void *>(&decode_nv12_half_rep<true, BT709_REP_STEP, false>),
+      reinterpret_cast<const void *>(&decode_nv12_half_rep<false, BT709_REP_STEP, false>),
+      reinterpret_cast<const void *>(&decode_nv12_half_rep<true, BT709_REP_STEP, true>),
+      reinterpret_cast<const void *>(&decode_nv12_half_rep<false, BT709_REP_STEP, true>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_BYTES, false, true>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_PAIRS, false, true>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_WIDE, false, true>),

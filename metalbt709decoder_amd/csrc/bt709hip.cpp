@@ -42,9 +42,8 @@ struct bt709hip_context {
   std::mutex encoder_mutex;
   EncoderTables encoders[3][3];  // [input gamma][output gamma], built on first use
   // bt709hip_render_scaled (pass 2 alone): built on first use under encoder_mutex
-  void *d_render_encode = nullptr, *d_render_unit = nullptr, *d_render_lin = nullptr;
-  uint32_t render_encode_bytes = 0, render_unit_bytes = 0, render_encode_n = 0, render_encode_offset = 0,
-           render_encode_shift = 0, render_unit_n = 0;
+  void *d_render_encode = nullptr, *d_render_lin = nullptr;
+  uint32_t render_encode_bytes = 0, render_encode_n = 0, render_encode_offset = 0, render_encode_shift = 0;
 };
 
 struct bt709hip_decoder {
@@ -64,7 +63,6 @@ struct bt709hip_decoder {
   uint32_t table_unit_bytes = 0;
   void *d_table_linear = nullptr;  // TransferBucketLinear[N + 1] (rescale kernels, decode side)
   uint32_t table_linear_bytes = 0;
-  void *d_table_alpha = nullptr;   // alpha decoders: TransferBucketLinear[N + 1] with byteNorm values (rescale kernels)
   void *d_encode = nullptr;        // LINEAR-mode two-resolution TransferBucket[] (rescale kernels, encode side)
   uint32_t encode_bytes = 0;
   uint32_t encode_n = 0;
@@ -236,8 +234,6 @@ void set_tables(DecodeParams *p, const bt709hip_decoder *dec) {
   p->table_unit_bytes = dec->table_unit_bytes;
   p->table_linear = dec->d_table_linear;
   p->table_linear_bytes = dec->table_linear_bytes;
-  p->table_alpha = dec->d_table_alpha;
-  p->table_alpha_bytes = dec->d_table_alpha ? dec->table_linear_bytes : 0;
   p->table_encode_u = dec->d_encode_u;
   p->table_encode_u_bytes = dec->encode_u_bytes;
   p->encode_u_n = static_cast<float>(dec->encode_u_n);
@@ -384,7 +380,6 @@ int bt709hip_context_destroy(bt709hip_context *ctx) {
         if (t.d_from_linear) (void)hipFree(t.d_from_linear);
       }
     if (ctx->d_render_encode) (void)hipFree(ctx->d_render_encode);
-    if (ctx->d_render_unit) (void)hipFree(ctx->d_render_unit);
     if (ctx->d_render_lin) (void)hipFree(ctx->d_render_lin);
   }
   delete ctx;
@@ -592,7 +587,6 @@ int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
   if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) {
     if (dec->d_table_unit) (void)hipFree(dec->d_table_unit);
     if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
-    if (dec->d_table_alpha) (void)hipFree(dec->d_table_alpha);
     if (dec->d_encode) (void)hipFree(dec->d_encode);
     if (dec->d_encode_u) (void)hipFree(dec->d_encode_u);
     if (dec->half.table) (void)hipFree(const_cast<void *>(dec->half.table));
@@ -662,17 +656,15 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   dec->encode_shift = 0;
   for (float r = enc.coarse_scale; r < 1.0f; r *= 2.0f) ++dec->encode_shift;  // log2(fine buckets per coarse bucket)
   dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
-  void *d_unit = nullptr, *d_linear = nullptr, *d_alpha = nullptr, *d_enc = nullptr, *d_enc_u = nullptr;
+  void *d_unit = nullptr, *d_linear = nullptr, *d_enc = nullptr, *d_enc_u = nullptr;
   const uint32_t enc_u_bytes = static_cast<uint32_t>(enc_u.buckets.size() * sizeof(TransferBucket));
   int rc = upload_table(t.buckets_unit.data(), dec->table_unit_bytes, &d_unit);
   if (rc == BT709HIP_OK) rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &d_linear);
-  if (rc == BT709HIP_OK && dec->has_alpha) rc = upload_table(t.buckets_bytenorm.data(), dec->table_linear_bytes, &d_alpha);
   if (rc == BT709HIP_OK) rc = upload_table(enc.buckets.data(), dec->encode_bytes, &d_enc);
   if (rc == BT709HIP_OK) rc = upload_table(enc_u.buckets.data(), enc_u_bytes, &d_enc_u);
   if (rc != BT709HIP_OK) {  // a retry starts from scratch: nothing is published, nothing leaks
     if (d_unit) (void)hipFree(d_unit);
     if (d_linear) (void)hipFree(d_linear);
-    if (d_alpha) (void)hipFree(d_alpha);
     if (d_enc) (void)hipFree(d_enc);
     return rc;
   }
@@ -681,7 +673,6 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   dec->encode_u_n = enc_u.n;
   dec->d_table_unit = d_unit;
   dec->d_table_linear = d_linear;
-  dec->d_table_alpha = d_alpha;
   dec->d_encode = d_enc;
   dec->ready = true;
   return BT709HIP_OK;
@@ -836,10 +827,10 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   const uint32_t cus = static_cast<uint32_t>(dec->ctx->props.multiProcessorCount);
   const uint64_t tile_rows = static_cast<uint64_t>((p.width / 4 + kRepBlockThreads - 1) / kRepBlockThreads) *
                              (p.height / 2) * static_cast<uint32_t>(count);
-  const bool rep = wide && !dec->has_alpha && dec->half_rep != 0 && (dec->half_rep > 0 || tile_rows >= 8ull * cus);
+  const bool rep = wide && dec->half_rep != 0 && (dec->half_rep > 0 || tile_rows >= 8ull * cus);
   const uint32_t rep_groups = dec->half_workgroups > 0 ? static_cast<uint32_t>(dec->half_workgroups) : cus;
   const uint32_t rep_lds = (dec->half_lds_kb > 0 ? static_cast<uint32_t>(dec->half_lds_kb) : 160u) * 1024u;
-  const char *name = rep ? launch_decode_half_rep(p, count, dec->nontemporal, rep_groups, rep_lds, s) : nullptr;
+  const char *name = rep ? launch_decode_half_rep(p, count, dec->has_alpha != 0, dec->nontemporal, rep_groups, rep_lds, s) : nullptr;
   tl_kernel_name = name ? name : launch_decode_half(p, count, wide, dec->has_alpha != 0, dec->nontemporal, gx, threads, s);
   return finish_launch(s, wait_until_completed);
 }
@@ -887,37 +878,29 @@ int bt709hip_decoder_prepare_format(bt709hip_decoder *dec, int format) {
 namespace {
 
 // Tables of the stand-alone pass 2, built once per context: the two-resolution sRGB-encode buckets
-// (as a decoder's), the sRGB-mode byte table (round(255 v): quantises the filtered alpha) and
-// lin[256] = sRGB_nonLinearNormToLinear(byteNorm(b)) (the sRGB8 sampler's decode).
+// (as a decoder's) and lin[256] = sRGB_nonLinearNormToLinear(byteNorm(b)) (the sRGB8 sampler's decode).
 int render_tables(bt709hip_context *ctx, hipStream_t s) {
   std::lock_guard<std::mutex> lock(ctx->encoder_mutex);
   if (ctx->d_render_lin != nullptr) return BT709HIP_OK;
   if (capturing(s)) return BT709HIP_ERR_NOT_SETUP;
   SplitTable enc;
-  TransferTable unit;
-  if (!build_split_table(kGammaLinear, &enc) || !build_transfer_table(kGammaSRGB, &unit)) return BT709HIP_ERR_UNSUPPORTED;
+  if (!build_split_table(kGammaLinear, &enc)) return BT709HIP_ERR_UNSUPPORTED;
   float lin[256];
   for (int b = 0; b < 256; ++b) lin[b] = srgb_to_linear(b * (1.0f / 255.0f));
-  void *d_enc = nullptr, *d_unit = nullptr, *d_lin = nullptr;
+  void *d_enc = nullptr, *d_lin = nullptr;
   const uint32_t enc_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
-  const uint32_t unit_bytes = static_cast<uint32_t>(unit.buckets_unit.size() * sizeof(TransferBucket));
   int rc = upload_table(enc.buckets.data(), enc_bytes, &d_enc);
-  if (rc == BT709HIP_OK) rc = upload_table(unit.buckets_unit.data(), unit_bytes, &d_unit);
   if (rc == BT709HIP_OK) rc = upload_table(lin, sizeof lin, &d_lin);
   if (rc != BT709HIP_OK) {
     if (d_enc) (void)hipFree(d_enc);
-    if (d_unit) (void)hipFree(d_unit);
     return rc;
   }
   ctx->render_encode_bytes = enc_bytes;
-  ctx->render_unit_bytes = unit_bytes;
   ctx->render_encode_n = enc.n_fine;
   ctx->render_encode_offset = enc.coarse_offset;
   ctx->render_encode_shift = 0;
   for (float r = enc.coarse_scale; r < 1.0f; r *= 2.0f) ++ctx->render_encode_shift;
-  ctx->render_unit_n = unit.n;
   ctx->d_render_encode = d_enc;
-  ctx->d_render_unit = d_unit;
   ctx->d_render_lin = d_lin;  // the "built" marker: last
   return BT709HIP_OK;
 }
@@ -960,14 +943,11 @@ int bt709hip_render_scaled(bt709hip_context *ctx, const bt709hip_surface *in, co
   p.scale_x = static_cast<float>(in->width) / static_cast<float>(out->width);
   p.scale_y = static_cast<float>(in->height) / static_cast<float>(out->height);
   p.table_encode = ctx->d_render_encode;
-  p.table_unit = ctx->d_render_unit;
   p.table_lin = ctx->d_render_lin;
   p.table_encode_bytes = ctx->render_encode_bytes;
-  p.table_unit_bytes = ctx->render_unit_bytes;
   p.encode_scale = static_cast<float>(ctx->render_encode_n);
   p.encode_offset = ctx->render_encode_offset;
   p.encode_shift = ctx->render_encode_shift;
-  p.unit_magic = 8388608.0f / static_cast<float>(ctx->render_unit_n);
   const char *name = launch_render_scaled(p, in->format == BT709HIP_FORMAT_RGBA16F,
                                           static_cast<uint32_t>(ctx->props.multiProcessorCount), s);
   if (name == nullptr) return BT709HIP_ERR_UNSUPPORTED;  // a surface of 2 GiB or more

@@ -124,9 +124,6 @@ bool build_transfer_table(int gamma, TransferTable *out) {
   float lin_of_byte[257];
   for (int b = 0; b < 256; ++b) lin_of_byte[b] = srgb_to_linear(b * (1.0f / 255.0f));
   lin_of_byte[256] = lin_of_byte[255];
-  float norm_of_byte[257];  // byteNorm, Renderer/sRGB.h:32-36
-  for (int b = 0; b < 256; ++b) norm_of_byte[b] = b * (1.0f / 255.0f);
-  norm_of_byte[256] = norm_of_byte[255];
 
   const float inf = std::numeric_limits<float>::infinity();
   for (uint32_t n = 256; n <= 65536; n *= 2) {
@@ -154,17 +151,12 @@ bool build_transfer_table(int gamma, TransferTable *out) {
     while ((out->buckets_unit.size() * sizeof(TransferBucket)) % 16 != 0)
       out->buckets_unit.push_back(TransferBucket{inf, 255u});
     out->buckets_linear.resize(b.size());
-    out->buckets_bytenorm.resize(b.size());
     for (size_t q = 0; q < b.size(); ++q) {
       TransferBucketLinear &e = out->buckets_linear[q];
       e.edge_pred = b[q].edge == inf ? inf : std::nextafter(b[q].edge, -inf);
       e.base = b[q].base;
       e.lin_below = std::ldexp(lin_of_byte[b[q].base], kLinearScaleLog2);      // exact: power of two
       e.lin_above = std::ldexp(lin_of_byte[b[q].base + 1], kLinearScaleLog2);
-      TransferBucketLinear &a = out->buckets_bytenorm[q];
-      a = e;
-      a.lin_below = std::ldexp(norm_of_byte[b[q].base], kLinearScaleLog2);
-      a.lin_above = std::ldexp(norm_of_byte[b[q].base + 1], kLinearScaleLog2);
     }
     return true;
   }

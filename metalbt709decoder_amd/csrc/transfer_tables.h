@@ -70,9 +70,6 @@ struct TransferTable {
   // buckets 0..N (bucket N: x == 1.0), padded to a 16-byte multiple
   std::vector<TransferBucket> buckets_unit;
   std::vector<TransferBucketLinear> buckets_linear;  // the same N + 1 buckets, linearised outputs
-  // the same buckets with lin_* = 2^-40 * byteNorm(byte) (Renderer/sRGB.h:32-36): how pass 2 reads
-  // the ALPHA channel of the 8-bit intermediate (a plain unorm, no sRGB curve)
-  std::vector<TransferBucketLinear> buckets_bytenorm;
 };
 
 // q of the comment above, computed exactly as the kernels do (csrc/bt709_device.h magic_index).

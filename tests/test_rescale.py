@@ -151,6 +151,31 @@ def test_gpu_scaled_batch(gh, oracle, count):
 
 
 @pytest.mark.gpu
+def test_gpu_half_alpha_in_the_persistent_kernel(gh, oracle):
+    """The persistent 2:1 kernel computes the alpha channel WITHOUT tables (decoded alpha byte =
+    trunc(255 x + 0.5), byteNorm, sum * 63.75, trunc(. + 0.5)): every alpha byte as a constant 2x2 block, every
+    byte against every other in one block, and random planes -- equal to the oracle and to the per-tile kernel
+    (which goes through the byteNorm / quantiser tables)."""
+    w, h = 1024, 64
+    y, c = _frame(w, h, 4242)
+    a = np.random.default_rng(77).integers(0, 256, (h, w), dtype=np.uint8)
+    codes = np.arange(256, dtype=np.uint8)
+    a[0:2, 0:512] = np.repeat(codes, 2)[None, :]            # 256 constant blocks
+    a[2, 0:512:2], a[2, 1:512:2] = codes, codes[::-1]         # mixed blocks: (b, 255 - b) over (b, b)
+    a[3, 0:512] = np.repeat(codes, 2)
+    a[4:6, 512:1024] = np.repeat(np.roll(codes, 1), 2)[None, :] ^ np.tile(np.array([0, 1], np.uint8), 256)[None, :]
+    want = oracle.decode_nv12_half(mb.MetalBT709GammaSRGB, y, c, alpha=a)
+    got = {}
+    for kernel in (1, 0):
+        dec = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True, options={_capi.OPT_HALF_KERNEL: kernel, _capi.OPT_HALF_WORKGROUPS: 5})
+        got[kernel] = gh.gpu_decode_half(y, c, mb.MetalBT709GammaSRGB, decoder=dec, alpha=a)
+        name = gh.context().lib.bt709hip_last_kernel_name()
+        assert name == (b"decode_nv12_half_rep<alpha>" if kernel else b"decode_nv12_half<wide,alpha>"), name
+        assert np.array_equal(got[kernel], want), kernel
+    assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.gpu
 def test_gpu_scaled_strips_with_a_ragged_last_wave(gh, oracle):
     """The vertical taps of a strip are worked out by its first lanes (lane i: row i) and read with
     v_readlane_b32: an output width that leaves the last wave with FEWER live columns than a strip has rows
