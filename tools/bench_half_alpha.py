@@ -1,4 +1,4 @@
-"""2:1 rescale with and without an alpha plane, batched (runs on the GPU box): python tools/bench_half_alpha.py W H frames alpha(0|1)"""
+"""2:1 rescale with and without an alpha plane, batched (runs on the GPU box): python tools/bench_half_alpha.py W H frames alpha(0|1) [half kernel option: -1 auto, 0 per-tile, 1 persistent]"""
 import sys, os, ctypes as C, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
@@ -8,7 +8,8 @@ from metalbt709decoder_amd import _capi
 from metalbt709decoder_amd.decoder import DeviceBuffer
 W, H = int(sys.argv[1]), int(sys.argv[2]); ring = int(sys.argv[3]); alpha = int(sys.argv[4])
 ctx = gh.context(); lib, h = ctx.lib, ctx.handle
-dec = gh.make_decoder(mb.MetalBT709GammaSRGB if alpha else mb.MetalBT709GammaApple, has_alpha=bool(alpha))
+dec = gh.make_decoder(mb.MetalBT709GammaSRGB if alpha else mb.MetalBT709GammaApple, has_alpha=bool(alpha),
+                      options={_capi.OPT_HALF_KERNEL: int(sys.argv[5]) if len(sys.argv) > 5 else -1})
 in_pitch = (W * H * 3 // 2 + 255) // 256 * 256; a_pitch = W * H; out_pitch = (W // 2) * (H // 2) * 4
 si, sa, so = DeviceBuffer(ctx, ring * in_pitch), DeviceBuffer(ctx, ring * a_pitch), DeviceBuffer(ctx, ring * out_pitch)
 frames, alphas, surfs = (_capi.Frame * ring)(), (_capi.Frame * ring)(), (_capi.Surface * ring)()
