@@ -755,6 +755,38 @@ def test_lazily_built_tables_are_refused_inside_a_capture(gh, oracle):
     cb.release()
 
 
+def test_rescale_entry_points_record_into_a_graph(gh, oracle):
+    """The any-ratio kernel (whose launcher sizes a persistent grid with an occupancy query on first use), the exact
+    2:1 kernels and pass 2 alone inside a recorded graph: first use INSIDE the recording, replayed twice."""
+    ctx = gh.context()
+    w, hgt = 256, 96
+    y, c = gh.random_nv12(w, hgt, seed=21)
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    scale = mb.MetalScaleRenderContext()
+    assert scale.setupRenderPipelines(ctx)
+    buf = gh.make_buffer(y, c, dec.gamma)
+    views = {(200, 50): ctx.makeBGRATexture((200, 50)), (128, 48): ctx.makeBGRATexture((128, 48)), (300, 130): ctx.makeBGRATexture((300, 130))}
+    inter, view2 = ctx.makeBGRATexture((w, hgt)), ctx.makeBGRATexture((77, 31))
+    cb = ctx.commandQueue.commandBuffer(new_stream=True)
+    cb.beginRecording()
+    for (ow, oh), tex in views.items():
+        assert dec.decodeBT709Scaled(buf, tex, cb, False), dec.lastStatus
+    assert dec.decodeBT709(buf, None, inter, cb, None, w, hgt, False)
+    assert scale.renderScaled(ctx, view2, 77, 31, cb, None, inter, False)
+    rec = cb.endRecording()
+    for _ in range(2):
+        rec.replay(cb)
+    cb.waitUntilCompleted()
+    for (ow, oh), tex in views.items():
+        got = ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(oh, ow * 4)
+        want = oracle.decode_nv12_half(0, y, c) if (ow, oh) == (w // 2, hgt // 2) else oracle.decode_nv12_scaled(0, y, c, ow, oh)
+        assert np.array_equal(got, want), (ow, oh)
+    got = ctx.getBGRATexturePixels(view2).view(np.uint8).reshape(31, 77 * 4)
+    assert np.array_equal(got, oracle.decode_nv12_scaled(0, y, c, 77, 31))
+    rec.release()
+    cb.release()
+
+
 def test_copy_probe_and_stream_join(gh):
     """The benchmark's copy ceiling really copies (every byte, odd multiples of 16 included, nothing
     beyond), and bt709hip_stream_wait_event orders two streams without blocking the host."""
