@@ -4,20 +4,22 @@
 // is smaller than the frame -- is ONE kernel here: the 132.7 MB 8K intermediate is never written.
 //
 // Two-pass-equivalent arithmetic ("rescale"; the reference has no CPU twin of pass 2,
-// so parity is against the oracle's restatement of this definition): each source pixel is
+// so parity is against the oracle's restatement of this definition, itself pinned to goldens composed
+// of the reference's own inlines, tests/golden/pass2.json): each source pixel is
 // decoded to its 8-bit sRGB value and linearised as the sRGB8 sampler would -- the decode-side
 // table returns that linear float directly, {edge, lin(base), lin(base + 1)} in one 16-byte
 // bucket (transfer_tables.h TransferBucketLinear) -- the taps are combined in linear light, and the result is sRGB-encoded and quantised
 // through the LINEAR-mode composite, held as a two-resolution bucket table (transfer_tables.h
 // SplitTable).
 //
-// All three kernels are VALU-bound (12 decode-side + 3 encode-side lookups per output pixel), so
-// everything is counted in cycles (bt709_device.h, VALU BUDGET): per decode-side lookup
-// 2 (saturating add) + 2 (magic add) + 4 (address) + 2 + 4 (subtract, median-of-three select).
+// The kernels are bound by VALU issue slots and by the LDS pipe together (12 decode-side + 3 encode-side lookups
+// per output pixel; DESIGN.md 6.0 has the counters): per decode-side lookup a saturating add, the magic add, the
+// address, a subtract and a median-of-three select.  The alpha channel of an alpha decoder is pure arithmetic.
 //
-//   decode_nv12_half       exact 2:1, one short-lived workgroup per tile of an output row
-//   decode_nv12_half_rep   exact 2:1, persistent workgroups, bank-conflict-free LDS tables
-//   decode_nv12_scaled     any output size, bilinear taps, one lane per output pixel
+//   decode_nv12_half       exact 2:1, one short-lived workgroup per tile of an output row (small launches, any layout)
+//   decode_nv12_half_rep   exact 2:1, persistent workgroups, bank-conflict-free LDS tables (with and without alpha)
+//   decode_nv12_scaled     any output size, bilinear taps, one lane per output column walking strips of rows
+//   render_scaled          pass 2 alone from an 8-bit or RGBA16Float intermediate
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -452,8 +454,8 @@ decode_nv12_half_rep(const DecodeParams p) {
 // One lane per output column, walking a strip of `rows` consecutive output rows (grid = (ceil(OW /
 // blockDim), strips, frames)): the horizontal tap positions and weights are computed once per lane, the
 // vertical ones once per strip (lane i does row i; rows read them with v_readlane_b32), the 14 KiB of
-// tables are staged once per workgroup.  What round 2 changed (204 -> 240 Gpixel/s on 4K -> 1440p, 439 ->
-// 373 ... see DESIGN 6.5 for every shape):
+// tables are staged once per workgroup -- of the launch, in the persistent form (see the kernel).  What round 2
+// changed (4K -> 1440p, 8 frames per launch: 204 -> 255 Gpixel/s out; DESIGN 6.5 has every shape and every step):
 //   * the ROW CACHE: which source rows an output row needs is the same for every lane, and consecutive
 //     output rows share source rows whenever the vertical ratio is below 2 (always when enlarging), so
 //     the two linearised rows of the previous output row stay in registers and only rows not seen yet are
