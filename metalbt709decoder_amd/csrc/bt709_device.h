@@ -114,6 +114,13 @@ __device__ __forceinline__ float alpha_value(float abyte) {
   return add_sat(__fmul_rn(centre_norm(abyte, 16.0f), kMY), 0.0f);
 }
 
+// (int)round(x * 255.0f) of a saturated x (BT709.h:881-883), the whole composite of the sRGB mode ("no curve at
+// all", BT709.h:977-983) and therefore of every channel of an alpha decoder: for v in [0, 255] round-half-away is
+// trunc(v + 0.5f), v + 0.5f is exact there, and v_cvt_u32_f32 truncates.  Three VALU instructions, no table.
+__device__ __forceinline__ uint32_t quantise_byte(float x) {
+  return static_cast<uint32_t>(__fadd_rn(__fmul_rn(x, 255.0f), 0.5f));
+}
+
 // t[i] = bits(x[i] + magic) for saturated x: bits(magic) + bucket index (transfer_tables.h).  The
 // default build uses the add as it stands (round to nearest even: bucket q is centred on q / N).
 // -DBT709_INDEX_RTZ builds round 1's floor(x N) form for A/B runs: the adds of a batch sit in one

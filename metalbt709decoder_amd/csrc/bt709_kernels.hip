@@ -40,26 +40,22 @@ __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, ui
 #pragma unroll
   for (int px = 0; px < 8; ++px)
     pixel_rgb(byte_of(px < 4 ? ya : yb, px & 3), (px & 2) ? c1 : c0, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
-  uint32_t t[24];
-  magic_index12(x, t, u.magic);
-  magic_index12(x + 12, t + 12, u.magic);
-  uint32_t byte[24];
-#pragma unroll
-  for (int i = 0; i < 24; ++i) byte[i] = bucket_byte(u, x[i], t[i]);
-  uint32_t al[8];
-#pragma unroll
-  for (int px = 0; px < 8; ++px) al[px] = alpha_word;
+  uint32_t byte[24], al[8];
   if (HAS_ALPHA) {
-    // an alpha decoder always runs the identity (sRGB-mode) table, which is exactly round(x*255)
-    float a[12];
-    uint32_t ta[12];
+    // An alpha decoder always runs the sRGB mode, whose composite is the plain quantiser: every channel, alpha
+    // included, is quantise_byte of its saturated value -- no table, no LDS in the alpha kernels.
 #pragma unroll
-    for (int px = 0; px < 8; ++px) a[px] = alpha_value(byte_of(px < 4 ? aa : ab, px & 3));
+    for (int i = 0; i < 24; ++i) byte[i] = quantise_byte(x[i]);
 #pragma unroll
-    for (int i = 8; i < 12; ++i) a[i] = 0.0f;
-    magic_index12(a, ta, u.magic);
+    for (int px = 0; px < 8; ++px) al[px] = quantise_byte(alpha_value(byte_of(px < 4 ? aa : ab, px & 3))) << 24;
+  } else {
+    uint32_t t[24];
+    magic_index12(x, t, u.magic);
+    magic_index12(x + 12, t + 12, u.magic);
 #pragma unroll
-    for (int px = 0; px < 8; ++px) al[px] = bucket_byte(u, a[px], ta[px]) << 24;
+    for (int i = 0; i < 24; ++i) byte[i] = bucket_byte(u, x[i], t[i]);
+#pragma unroll
+    for (int px = 0; px < 8; ++px) al[px] = alpha_word;
   }
   top.x = pack_bgra(byte[0], byte[1], byte[2], al[0]);
   top.y = pack_bgra(byte[3], byte[4], byte[5], al[1]);
@@ -79,22 +75,19 @@ __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[
   float x[12];
 #pragma unroll
   for (int px = 0; px < 4; ++px) pixel_rgb(y[px], c, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
+  if (HAS_ALPHA) {  // sRGB mode: the plain quantiser for every channel (see decode_quad)
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+      out[px] = pack_bgra(quantise_byte(x[3 * px]), quantise_byte(x[3 * px + 1]), quantise_byte(x[3 * px + 2]),
+                          quantise_byte(alpha_value(a[px])) << 24);
+    return;
+  }
   uint32_t t[12];
   magic_index12(x, t, u.magic);
-  uint32_t al[4] = {alpha_word, alpha_word, alpha_word, alpha_word};
-  if (HAS_ALPHA) {
-    float av[4];
-    uint32_t ta[4];
-#pragma unroll
-    for (int px = 0; px < 4; ++px) av[px] = alpha_value(a[px]);
-    magic_index4(av, ta, u.magic);
-#pragma unroll
-    for (int px = 0; px < 4; ++px) al[px] = bucket_byte(u, av[px], ta[px]) << 24;
-  }
 #pragma unroll
   for (int px = 0; px < 4; ++px)
     out[px] = pack_bgra(bucket_byte(u, x[3 * px], t[3 * px]), bucket_byte(u, x[3 * px + 1], t[3 * px + 1]),
-                        bucket_byte(u, x[3 * px + 2], t[3 * px + 2]), al[px]);
+                        bucket_byte(u, x[3 * px + 2], t[3 * px + 2]), alpha_word);
 }
 
 }  // namespace
@@ -147,8 +140,10 @@ decode_nv12_quads(const DecodeParams p) {
       ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
     }
   }
-  stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
-  __syncthreads();
+  if (!HAS_ALPHA) {  // alpha decoders need no table (decode_quad)
+    stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
+    __syncthreads();
+  }
   // Pin every loaded dword here: hipcc then waits for all of the tile's loads once, before any
   // store is issued, instead of emitting s_waitcnt vmcnt(0) between the first quad's stores and
   // the second quad's arithmetic (which would wait for the stores' write acknowledgements).
@@ -181,8 +176,10 @@ template <bool HAS_ALPHA>
 __global__ void __launch_bounds__(kBlockThreads)
 decode_nv12_blocks(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  stage_table(lds_raw, p.table_unit, p.table_unit_bytes);
-  __syncthreads();
+  if (!HAS_ALPHA) {
+    stage_table(lds_raw, p.table_unit, p.table_unit_bytes);
+    __syncthreads();
+  }
 
   const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
   const FramePlanes f = frame_planes(p, blockIdx.y);
@@ -222,7 +219,7 @@ decode_nv12_blocks(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
-  const size_t lds = p.table_unit_bytes;
+  const size_t lds = has_alpha ? 0 : p.table_unit_bytes;
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
     const uint32_t by = quads_rows_per_block(block_threads, grid_x);

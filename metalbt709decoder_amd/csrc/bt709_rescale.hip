@@ -179,7 +179,7 @@ __device__ __forceinline__ float alpha_norm_arith(float abyte) {
 
 // (alpha byte << 24) of a filtered alpha value: round(255 * saturate(v))
 __device__ __forceinline__ uint32_t alpha_word_of(float v) {
-  return static_cast<uint32_t>(__fadd_rn(__fmul_rn(add_sat(v, 0.0f), 255.0f), 0.5f)) << 24;  // v_cvt_u32_f32 truncates
+  return quantise_byte(add_sat(v, 0.0f)) << 24;
 }
 
 __device__ __forceinline__ uint32_t half_alpha_arith(float a00, float a01, float a10, float a11) {

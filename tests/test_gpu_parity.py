@@ -92,6 +92,20 @@ def test_exhaustive_2_24_sweep(gh, oracle, refdata, gamma):
     assert (out.reshape(-1, 4)[:, 3] == 0xFF).all()
 
 
+def test_exhaustive_2_24_sweep_through_an_alpha_decoder(gh, oracle, refdata):
+    """An alpha decoder runs the sRGB mode in ARITHMETIC (no table: quantise_byte for R, G, B and alpha): every
+    (Y,Cb,Cr) triple must still hash to the reference headers' sRGB-mode table, and every alpha byte to the oracle's."""
+    y, c = gh.exhaustive_frame()
+    a = np.random.default_rng(24).integers(0, 256, y.shape, dtype=np.uint8)
+    a[0, :256] = np.arange(256, dtype=np.uint8)
+    out = gh.gpu_decode(y, c, mb.MetalBT709GammaSRGB, alpha=a)
+    assert out is not None and gh.context().lib.bt709hip_last_kernel_name() == b"decode_nv12_quads<alpha>"
+    table = gh.exhaustive_to_table(out, y, c)
+    assert hashlib.sha256(table.tobytes()).hexdigest() == refdata["table_sha256"][GAMMA_NAMES[mb.MetalBT709GammaSRGB]]
+    alpha_map = np.array([oracle.lib.bt709o_decode_alpha(int(v)) for v in range(256)], np.uint8)
+    assert np.array_equal(out.reshape(y.shape[0], -1, 4)[:, :, 3], alpha_map[a])
+
+
 # ------------------------------------------------------------------ frames vs oracle
 
 @pytest.mark.parametrize("gamma", GAMMAS)

@@ -1,0 +1,40 @@
+"""4K 1:1 decode in the sRGB mode with and without an alpha plane, 32 frames per launch (runs on the GPU box): python tools/bench_alpha11.py"""
+import sys, os, ctypes as C
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import gpu_helpers as gh
+import metalbt709decoder_amd as mb
+from metalbt709decoder_amd import _capi
+from metalbt709decoder_amd.decoder import DeviceBuffer
+W, H, ring = 3840, 2160, 32
+if len(sys.argv) > 1: _capi.load(os.path.abspath(sys.argv[1]))
+ctx = gh.context(); lib, h = ctx.lib, ctx.handle
+for alpha in (1, 0):
+    dec = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=bool(alpha))
+    in_pitch = W * H * 3 // 2; a_pitch = W * H; out_pitch = W * H * 4
+    si, sa, so = DeviceBuffer(ctx, ring * in_pitch), DeviceBuffer(ctx, ring * a_pitch), DeviceBuffer(ctx, ring * out_pitch)
+    frames, alphas, surfs = (_capi.Frame * ring)(), (_capi.Frame * ring)(), (_capi.Surface * ring)()
+    y, c = gh.random_nv12(W, H, seed=1); a = np.random.default_rng(2).integers(0, 256, (H, W), dtype=np.uint8)
+    for i in range(ring):
+        b = si.ptr + i * in_pitch
+        ctx._upload(b, W, y, None); ctx._upload(b + W * H, W, c, None); ctx._upload(sa.ptr + i * a_pitch, W, a, None); ctx._sync(None)
+        buf = mb.CVPixelBuffer(ctx, W, H, W, W, planes=(b, b + W * H))
+        buf.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2); buf.setAttachment("TransferFunction", gh.TRANSFER_FOR_GAMMA[dec.gamma])
+        frames[i] = buf.frame()
+        ab = mb.CVPixelBuffer(ctx, W, H, W, W, planes=(sa.ptr + i * a_pitch, b + W * H))
+        ab.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2); ab.setAttachment("TransferFunction", mb.kCVImageBufferTransferFunction_Linear)
+        alphas[i] = ab.frame()
+        surfs[i] = _capi.Surface(so.ptr + i * out_pitch, W * 4, W, H, _capi.FORMAT_BGRA8_SRGB, 0)
+    def step():
+        rc = lib.bt709hip_decode_batch(dec._handle, ring, frames, alphas if alpha else None, surfs, None, 0); assert rc == 0, rc
+    for _ in range(10): step()
+    ctx._sync(None)
+    e0, e1 = C.c_void_p(), C.c_void_p(); lib.bt709hip_event_create(h, C.byref(e0)); lib.bt709hip_event_create(h, C.byref(e1))
+    lib.bt709hip_event_record(h, e0, None)
+    n = 20
+    for _ in range(n): step()
+    lib.bt709hip_event_record(h, e1, None); ctx._sync(None)
+    ms = C.c_float(); lib.bt709hip_event_elapsed_ms(h, e0, e1, C.byref(ms))
+    us = ms.value * 1e3 / (n * ring)
+    nbytes = W * H * 3 // 2 + (W * H if alpha else 0) + out_pitch
+    print("4K 1:1 sRGB mode alpha=%d: %.2f us/frame %.1f Gpx/s %.3f of 8TB/s %s" % (alpha, us, W * H / us / 1e3, nbytes / us / 1e3 / 8000, lib.bt709hip_last_kernel_name().decode()))
