@@ -168,7 +168,8 @@ const char *launch_copy_probe(void *dst, const void *src, size_t bytes, hipStrea
 // are read by the caller with hipGetLastError().
 // decode: variant kVariantQuads -> grid = (grid_x tiles, H/2, frames) x block_threads;
 //         variant kVariantBlocks -> grid = (grid_x, frames) x kBlockThreads, grid-strided.
-const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
+// quantiser: the decoder's mode is sRGB (arithmetic transfer step, no table); implied by has_alpha
+const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
 // half: grid = (grid_x, H/2 output rows, frames) x block_threads.
 const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool has_alpha, bool nontemporal,

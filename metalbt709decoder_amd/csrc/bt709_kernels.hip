@@ -31,7 +31,10 @@ namespace bt709 {
 namespace {
 
 // One 4x2 quad: 8 pixels x (R, G, B) = 24 lookups.  Pixel p = 0..3 top row, 4..7 bottom row.
-template <bool HAS_ALPHA>
+// QUANT: the decoder's mode is sRGB, whose composite is the plain quantiser ("no curve at all", BT709.h:977-983):
+// every channel is quantise_byte of its saturated value -- no table, no LDS.  Always set for alpha decoders
+// (hasAlphaChannel forces the sRGB mode, MetalBT709Decoder.m:165-169).
+template <bool HAS_ALPHA, bool QUANT>
 __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, uint32_t yb, uint32_t cw, uint32_t aa,
                                             uint32_t ab, uint32_t alpha_word, u32x4 &top, u32x4 &bot) {
   const Chroma c0 = chroma_terms(byte_of(cw, 0), byte_of(cw, 1));
@@ -40,23 +43,21 @@ __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, ui
 #pragma unroll
   for (int px = 0; px < 8; ++px)
     pixel_rgb(byte_of(px < 4 ? ya : yb, px & 3), (px & 2) ? c1 : c0, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
+  static_assert(QUANT || !HAS_ALPHA, "an alpha decoder runs the sRGB mode");
   uint32_t byte[24], al[8];
-  if (HAS_ALPHA) {
-    // An alpha decoder always runs the sRGB mode, whose composite is the plain quantiser: every channel, alpha
-    // included, is quantise_byte of its saturated value -- no table, no LDS in the alpha kernels.
+  if (QUANT) {
 #pragma unroll
     for (int i = 0; i < 24; ++i) byte[i] = quantise_byte(x[i]);
-#pragma unroll
-    for (int px = 0; px < 8; ++px) al[px] = quantise_byte(alpha_value(byte_of(px < 4 ? aa : ab, px & 3))) << 24;
   } else {
     uint32_t t[24];
     magic_index12(x, t, u.magic);
     magic_index12(x + 12, t + 12, u.magic);
 #pragma unroll
     for (int i = 0; i < 24; ++i) byte[i] = bucket_byte(u, x[i], t[i]);
-#pragma unroll
-    for (int px = 0; px < 8; ++px) al[px] = alpha_word;
   }
+#pragma unroll
+  for (int px = 0; px < 8; ++px)
+    al[px] = HAS_ALPHA ? quantise_byte(alpha_value(byte_of(px < 4 ? aa : ab, px & 3))) << 24 : alpha_word;
   top.x = pack_bgra(byte[0], byte[1], byte[2], al[0]);
   top.y = pack_bgra(byte[3], byte[4], byte[5], al[1]);
   top.z = pack_bgra(byte[6], byte[7], byte[8], al[2]);
@@ -68,18 +69,18 @@ __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, ui
 }
 
 // One 2x2 block (general path): 4 pixels x (R, G, B); y = {tl, tr, bl, br}
-template <bool HAS_ALPHA>
+template <bool HAS_ALPHA, bool QUANT>
 __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[4], float cb, float cr, const float a[4],
                                              uint32_t alpha_word, uint32_t out[4]) {
   const Chroma c = chroma_terms(cb, cr);
   float x[12];
 #pragma unroll
   for (int px = 0; px < 4; ++px) pixel_rgb(y[px], c, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
-  if (HAS_ALPHA) {  // sRGB mode: the plain quantiser for every channel (see decode_quad)
+  if (QUANT) {  // sRGB mode: the plain quantiser for every channel (see decode_quad)
 #pragma unroll
     for (int px = 0; px < 4; ++px)
       out[px] = pack_bgra(quantise_byte(x[3 * px]), quantise_byte(x[3 * px + 1]), quantise_byte(x[3 * px + 2]),
-                          quantise_byte(alpha_value(a[px])) << 24);
+                          HAS_ALPHA ? quantise_byte(alpha_value(a[px])) << 24 : alpha_word);
     return;
   }
   uint32_t t[12];
@@ -97,7 +98,7 @@ __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[
 // alpha pointers and strides 4-byte aligned; output pointer and stride 16-byte
 // aligned.  grid = (tiles, H/2, frames); a tile is blockDim * kQuadsPerLane quads.
 // ---------------------------------------------------------------------------
-template <bool HAS_ALPHA, bool NT>
+template <bool HAS_ALPHA, bool NT, bool QUANT>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_quads(const DecodeParams p) {
   constexpr int UNROLL = kQuadsPerLane;
@@ -140,7 +141,7 @@ decode_nv12_quads(const DecodeParams p) {
       ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
     }
   }
-  if (!HAS_ALPHA) {  // alpha decoders need no table (decode_quad)
+  if (!QUANT) {  // the sRGB mode needs no table (decode_quad)
     stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
     __syncthreads();
   }
@@ -158,7 +159,7 @@ decode_nv12_quads(const DecodeParams p) {
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = (q0 + u * blockDim.x);
     u32x4 top, bot;
-    decode_quad<HAS_ALPHA>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
+    decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
                            bot);
     if (q < quads && rp_raw < row_pairs) {
       store16<NT>(o0 + 16 * q, top);
@@ -172,11 +173,11 @@ decode_nv12_quads(const DecodeParams p) {
 // aligned output.  One lane per 2x2 block, grid-strided over row pairs.  Correctness
 // first; used for ragged or misaligned frames only.
 // ---------------------------------------------------------------------------
-template <bool HAS_ALPHA>
+template <bool HAS_ALPHA, bool QUANT>
 __global__ void __launch_bounds__(kBlockThreads)
 decode_nv12_blocks(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  if (!HAS_ALPHA) {
+  if (!QUANT) {
     stage_table(lds_raw, p.table_unit, p.table_unit_bytes);
     __syncthreads();
   }
@@ -205,7 +206,7 @@ decode_nv12_blocks(const DecodeParams p) {
         a[3] = byte_value(a1[2 * bx + 1]);
       }
       uint32_t out[4];
-      decode_block<HAS_ALPHA>(ul, y, byte_value(cc[2 * bx]), byte_value(cc[2 * bx + 1]), a, p.alpha_word, out);
+      decode_block<HAS_ALPHA, QUANT>(ul, y, byte_value(cc[2 * bx]), byte_value(cc[2 * bx + 1]), a, p.alpha_word, out);
       o0[2 * bx] = out[0];
       o0[2 * bx + 1] = out[1];
       o1[2 * bx] = out[2];
@@ -217,44 +218,57 @@ decode_nv12_blocks(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 // host-callable launchers (no HIP types in the signature beyond hipStream_t)
 // ---------------------------------------------------------------------------
-const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool nontemporal,
+const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
-  const size_t lds = has_alpha ? 0 : p.table_unit_bytes;
+  const bool quant = quantiser || has_alpha;  // the sRGB mode: arithmetic, no table
+  const size_t lds = quant ? 0 : p.table_unit_bytes;
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
     const uint32_t by = quads_rows_per_block(block_threads, grid_x);
     const dim3 grid(grid_x, (p.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
     const dim3 block(block_threads, by, 1);
     if (has_alpha) {
-      hipLaunchKernelGGL((decode_nv12_quads<true, true>), grid, block, lds, stream, p);
+      hipLaunchKernelGGL((decode_nv12_quads<true, true, true>), grid, block, lds, stream, p);
       return "decode_nv12_quads<alpha>";
     }
+    if (quant) {
+      if (nontemporal) hipLaunchKernelGGL((decode_nv12_quads<false, true, true>), grid, block, lds, stream, p);
+      else hipLaunchKernelGGL((decode_nv12_quads<false, false, true>), grid, block, lds, stream, p);
+      return nontemporal ? "decode_nv12_quads<nt,quantiser>" : "decode_nv12_quads<quantiser>";
+    }
     if (nontemporal) {
-      hipLaunchKernelGGL((decode_nv12_quads<false, true>), grid, block, lds, stream, p);
+      hipLaunchKernelGGL((decode_nv12_quads<false, true, false>), grid, block, lds, stream, p);
       return "decode_nv12_quads<nt>";
     }
-    hipLaunchKernelGGL((decode_nv12_quads<false, false>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((decode_nv12_quads<false, false, false>), grid, block, lds, stream, p);
     return "decode_nv12_quads";
   }
   // grid_x = workgroups per frame, grid-strided over row pairs
   const dim3 grid(grid_x, static_cast<uint32_t>(frames), 1);
   const dim3 block(kBlockThreads, 1, 1);
   if (has_alpha) {
-    hipLaunchKernelGGL((decode_nv12_blocks<true>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((decode_nv12_blocks<true, true>), grid, block, lds, stream, p);
     return "decode_nv12_blocks<alpha>";
   }
-  hipLaunchKernelGGL((decode_nv12_blocks<false>), grid, block, lds, stream, p);
+  if (quant) {
+    hipLaunchKernelGGL((decode_nv12_blocks<false, true>), grid, block, lds, stream, p);
+    return "decode_nv12_blocks<quantiser>";
+  }
+  hipLaunchKernelGGL((decode_nv12_blocks<false, false>), grid, block, lds, stream, p);
   return "decode_nv12_blocks";
 }
 
 hipError_t prepare_kernels() {
   const int cap = 160 * 1024;  // gfx950: 160 KiB LDS per workgroup
   const void *fns[] = {
-      reinterpret_cast<const void *>(&decode_nv12_quads<true, true>),
-      reinterpret_cast<const void *>(&decode_nv12_quads<false, true>),
-      reinterpret_cast<const void *>(&decode_nv12_quads<false, false>),
-      reinterpret_cast<const void *>(&decode_nv12_blocks<true>),
-      reinterpret_cast<const void *>(&decode_nv12_blocks<false>),
+      reinterpret_cast<const void *>(&decode_nv12_quads<true, true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_quads<false, true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_quads<false, false, true>),
+      reinterpret_cast<const void *>(&decode_nv12_quads<false, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_quads<false, false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_blocks<true, true>),
+      reinterpret_cast<const void *>(&decode_nv12_blocks<false, true>),
+      reinterpret_cast<const void *>(&decode_nv12_blocks<false, false>),
   };
   for (const void *fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

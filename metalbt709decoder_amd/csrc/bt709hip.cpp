@@ -793,7 +793,7 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
   const uint32_t gx = fast ? quads_tiles(p.width) : grid_x_for(dec->ctx, p.height / 2, count);
   const uint32_t threads = quads_block_threads(p.width);
   tl_kernel_name = launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
-                                 dec->nontemporal, gx, threads, s);
+                                 dec->gamma == kGammaSRGB, dec->nontemporal, gx, threads, s);
   return finish_launch(s, wait_until_completed);
 }
 
