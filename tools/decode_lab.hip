@@ -111,8 +111,11 @@ struct Ring {
       DecodeParams &p = params[l];
       std::memset(&p, 0, sizeof p);
       for (int i = 0; i < batch; ++i) {
-        uint8_t *base = d_in + size_t(l * batch + i) * in_stride;
-        p.frames[i] = FramePlanes{base, base + yb, nullptr, d_out + size_t(l * batch + i) * out_stride};
+        // LAB_SAME_INPUT=1: every frame reads ring frame 0 (the input stays in L2 / MALL): what the kernel does when its loads are short
+        uint8_t *base = d_in + (std::getenv("LAB_SAME_INPUT") ? 0 : size_t(l * batch + i) * in_stride);
+        // alpha: the luma plane of the ring frame half a ring away (bytes no workgroup of this launch reads): what profiles/r02_decode_lab_ceiling.txt's
+        // extra-loads run read through a lab macro of that commit
+        p.frames[i] = FramePlanes{base, base + yb, d_in + size_t((l * batch + i + ring / 2) % ring) * in_stride, d_out + size_t(l * batch + i) * out_stride};
       }
       p.table_unit = d_table_unit;
       p.table_unit_bytes = uint32_t(tub);
