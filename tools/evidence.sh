@@ -16,6 +16,7 @@ python tools/bench_encode.py --frames-per-launch 32 > $O/bench_encode.json 2>/de
 python tools/bench_encode.py --frames-per-launch 1 > $O/bench_encode_single.json 2>/dev/null
 tools/bench_paths.sh > $O/bench_paths.txt 2>&1
 python tools/stream_bench.py > $O/stream_bench.txt 2>&1
+{ python tools/bench_alpha11.py; python tools/bench_half_alpha.py 7680 4320 8 1; python tools/bench_half_alpha.py 7680 4320 8 0; python tools/bench_half_alpha.py 3840 2160 16 1; } > $O/bench_alpha.txt 2>&1
 tools/profile_gpu.sh 4k > /dev/null 2>&1
 tools/profile_gpu.sh 8k-half --workload 8k-half > /dev/null 2>&1
 PROFILE_PROG=tools/bench_encode.py tools/profile_gpu.sh encode --frames-per-launch 32 > /dev/null 2>&1
