@@ -39,6 +39,7 @@
 
 #include "bt709_constants.h"
 #include "bt709_kernels.h"
+#include "bt709_quantise.h"
 
 namespace bt709 {
 namespace {
@@ -115,10 +116,12 @@ __device__ __forceinline__ float alpha_value(float abyte) {
 }
 
 // (int)round(x * 255.0f) of a saturated x (BT709.h:881-883), the whole composite of the sRGB mode ("no curve at
-// all", BT709.h:977-983) and therefore of every channel of an alpha decoder: for v in [0, 255] round-half-away is
-// trunc(v + 0.5f), v + 0.5f is exact there, and v_cvt_u32_f32 truncates.  Three VALU instructions, no table.
+// all", BT709.h:977-983) and therefore of every channel of an alpha decoder, in its three-instruction form
+// trunc(x * 255.0f + 0.5f).  That form is NOT exact for every float (bt709_quantise.h: x = 0x3b008080 comes out 1, the
+// reference gives 0); it is used here only on the 1:1 kernels' arguments, a finite set that the exhaustive sweeps
+// enumerate (2^24 triples, 256 alpha codes).  Filtered values go through quantise_exact.
 __device__ __forceinline__ uint32_t quantise_byte(float x) {
-  return static_cast<uint32_t>(__fadd_rn(__fmul_rn(x, 255.0f), 0.5f));
+  return quantise_enumerated(x);
 }
 
 // t[i] = bits(x[i] + magic) for saturated x: bits(magic) + bucket index (transfer_tables.h).  The

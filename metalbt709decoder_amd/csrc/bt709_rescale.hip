@@ -167,25 +167,26 @@ __device__ __forceinline__ void linearise6(const RescaleLookup &r, const float *
 // (AAPLShaders.metal:411-438 writes it, the sampler of MetalScaleRenderContext.m:55-105 filters it): each tap is
 // byteNorm(decoded alpha byte), the result round(255 v).  No tables: an alpha decoder runs the sRGB mode, whose
 // composite is the plain quantiser, so the decoded alpha byte of a sample is (int)round(x * 255.0f) of its
-// saturated luma term x (BT709.h:881-883) -- for v in [0, 255] round-half-away is trunc(v + 0.5f), and v + 0.5f is
-// exact there -- and byteNorm is byte * (1/255f) (sRGB.h:32-36).  For the exact 2:1 case the filtered value
-// (sum * 0.25f) * 255.0f is one rounding of sum * 63.75f (the quarter is exact).  8 VALU instructions per sample,
-// 7 per output pixel.  (Round 2's first form went through a byteNorm bucket table and the quantiser table in LDS:
+// saturated luma term x (BT709.h:881-883) and byteNorm is byte * (1/255f) (sRGB.h:32-36).  The arithmetic lives in
+// bt709_quantise.h, compiled for the host too: tests/test_quantiser_exact.py replays it against the oracle over
+// every input it can meet (256 sample codes, 256^4 ordered tap tuples of the 2:1 filter, every float in [0, 1] for
+// the any-ratio filter's result).  8 VALU instructions per sample, 7 per output pixel of the 2:1 filter.
+// (Round 2's first form went through a byteNorm bucket table and the quantiser table in LDS:
 // 151 against 217 Gpixel/s on 8K -> 4K with alpha, and the tables kept alpha out of the persistent kernel.)
 __device__ __forceinline__ float alpha_norm_arith(float abyte) {
-  const float v = __fmul_rn(alpha_value(abyte), 255.0f);
-  return __fmul_rn(__builtin_truncf(__fadd_rn(v, 0.5f)), kInv255);
+  return alpha_norm_of_unit(alpha_value(abyte));
 }
 
-// (alpha byte << 24) of a filtered alpha value: round(255 * saturate(v))
+// (alpha byte << 24) of a FILTERED alpha value: round(255 * saturate(v)).  The argument is a weighted sum (any
+// ratio) or comes out of an RGBA16Float intermediate: not enumerable, so the quantiser is the one that is exact
+// for every float (round 2 used the three-instruction form here: one LSB off at v * 255 = 0.49999997).
 __device__ __forceinline__ uint32_t alpha_word_of(float v) {
-  return quantise_byte(add_sat(v, 0.0f)) << 24;
+  return quantise_exact(add_sat(v, 0.0f)) << 24;
 }
 
+// exact 2:1: the four taps of a block, each one of 256 values -- all 256^4 ordered tuples are replayed on the host
 __device__ __forceinline__ uint32_t half_alpha_arith(float a00, float a01, float a10, float a11) {
-  const float s = __fadd_rn(__fadd_rn(__fadd_rn(alpha_norm_arith(a00), alpha_norm_arith(a01)), alpha_norm_arith(a10)), alpha_norm_arith(a11));
-  const float v = __fmul_rn(s, 63.75f);
-  return static_cast<uint32_t>(__fadd_rn(v, 0.5f)) << 24;  // v_cvt_u32_f32 truncates
+  return half_alpha_sum_to_byte(alpha_norm_arith(a00), alpha_norm_arith(a01), alpha_norm_arith(a10), alpha_norm_arith(a11)) << 24;
 }
 
 // One output pixel of the exact 2:1 rescale: the four source pixels of a 2x2 block share one

@@ -48,6 +48,13 @@ def patterns():
     return np.load(os.path.join(GOLDEN, "patterns.npz"))
 
 
+@pytest.fixture(scope="session")
+def full_patterns():
+    """WHOLE bundled test images as NV12 (reference encoder) + sha256 of the reference headers' decode."""
+    meta = json.load(open(os.path.join(GOLDEN, "patterns_full.json")))
+    return meta["images"], np.load(os.path.join(GOLDEN, "patterns_full.npz"))
+
+
 def gpu_available():
     try:
         import torch

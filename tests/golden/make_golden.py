@@ -15,6 +15,10 @@ Outputs (all committed):
                     running the reference headers (oracle/_ref)
   patterns.npz      crops of the bundled test images as NV12 (reference encoder) with the
                     reference decode of each crop in every gamma mode
+  patterns_full.npz WHOLE bundled test images as NV12 (reference encoder): the 1920x1080 QuickTime pattern in
+                    both of its renditions and the 512x512 Image.tga; patterns_full.json holds the sha256 of
+                    the reference headers' decode of each in every gamma mode, and of decode + 2:1 pass 2
+                    (`python tests/golden/make_golden.py --full-patterns` regenerates only these two)
   pass2.json        sha256 of decode + pass 2 (2:1 and any-ratio rescale) composed of the reference's
                     own inlines (oracle/ref_harness.c) on seeded frames and on the pattern crops;
                     pass2_small.npz holds the small outputs themselves
@@ -261,6 +265,42 @@ def collect_patterns(ref):
     return arrays, meta
 
 
+FULL_IMAGES = [
+    ("qt_hd_srgb_full", "Renderer/QuickTime_Test_Pattern_HD_sRGB.png"),                # 1920 x 1080: BASELINE config 1's frame
+    ("qt_hd_calibrated_full", "Renderer/QuickTime_Test_Pattern_HD_calibrated_RGB.png"),  # 1920 x 1080
+    ("image_tga_full", "Renderer/Image.tga"),                                           # 512 x 512
+]
+
+
+def collect_full_patterns(ref):
+    """Whole bundled images -> NV12 by the reference's encoder (sRGB in, Apple 1.96 out: the app's default) ->
+    sha256 of the reference headers' decode in each gamma mode and of decode + exact 2:1 pass 2."""
+    arrays, meta = {}, []
+    for tag, rel in FULL_IMAGES:
+        bgra = load_bgra(os.path.join(REF, rel))
+        H, W = bgra.shape
+        yp, uv = ref.encode_nv12(np.ascontiguousarray(bgra).reshape(-1), W, H, 1, 0)
+        arrays[tag + "_y"], arrays[tag + "_uv"] = yp, uv
+        rec = {"tag": tag, "image": rel, "image_size": [W, H], "nv12_sha256": hashlib.sha256(yp.tobytes() + uv.tobytes()).hexdigest(),
+               "bgra_sha256": {}, "half_sha256": {}}
+        for g, n in ((0, "apple"), (1, "srgb"), (2, "linear"), (3, "itu709")):
+            rec["bgra_sha256"][n] = hashlib.sha256(decode_ref(ref, g, yp, uv).tobytes()).hexdigest()
+            rec["half_sha256"][n] = hashlib.sha256(ref.decode_nv12_half(g, yp, uv).tobytes()).hexdigest()
+        meta.append(rec)
+        print("full pattern", tag, W, H, flush=True)
+    return arrays, meta
+
+
+def write_full_patterns(ref):
+    arrays, meta = collect_full_patterns(ref)
+    np.savez_compressed(os.path.join(HERE, "patterns_full.npz"), **arrays)
+    json.dump({"note": "whole bundled images through the reference's encoder (cvpbu_ycbcr_subsample / "
+                       "BT709_average_pixel_values, sRGB in, Apple out) and the reference headers' decode "
+                       "(alpha byte 0xFF); half = decode + exact 2:1 pass 2 as in pass2.json",
+               "images": meta}, open(os.path.join(HERE, "patterns_full.json"), "w"), indent=1)
+    print("patterns_full.npz", os.path.getsize(os.path.join(HERE, "patterns_full.npz")), "bytes")
+
+
 # ----------------------------------------------------------------- pass 2 (reference-composed)
 
 def collect_pass2(ref, pattern_arrays):
@@ -304,6 +344,9 @@ def collect_pass2(ref, pattern_arrays):
 
 def main():
     ref = Reference()
+    if "--full-patterns" in sys.argv:
+        write_full_patterns(ref)
+        return
     vec = collect_vectors()
     vec["histograms"] = collect_histograms()
     print({k: len(v) for k, v in vec.items()})
@@ -320,6 +363,7 @@ def main():
     json.dump(p2, open(os.path.join(HERE, "pass2.json"), "w"), indent=1)
     np.savez_compressed(os.path.join(HERE, "pass2_small.npz"), **{k.replace("/", "_"): v for k, v in stored.items()})
     print("pass2.json", len(p2["cases"]), "cases,", len(p2["patterns"]), "patterns")
+    write_full_patterns(ref)
 
 
 if __name__ == "__main__":

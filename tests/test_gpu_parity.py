@@ -207,6 +207,20 @@ def test_bundled_pattern_crops(gh, refdata, patterns):
         assert np.array_equal(gh.gpu_decode(y, c, mb.MetalBT709GammaApple), patterns[rec["tag"] + "_bgra_apple"])
 
 
+def test_whole_bundled_patterns(gh, full_patterns):
+    """The WHOLE bundled test images (1920x1080 QuickTime pattern in both renditions = BASELINE config 1's frame,
+    512x512 Image.tga): GPU bytes hash to what the reference headers produce, every gamma, 1:1 and through the
+    fused exact 2:1 rescale."""
+    images, planes = full_patterns
+    for rec in images:
+        y, c = planes[rec["tag"] + "_y"], planes[rec["tag"] + "_uv"]
+        for gamma in GAMMAS:
+            out = gh.gpu_decode(y, c, gamma)
+            assert hashlib.sha256(out.tobytes()).hexdigest() == rec["bgra_sha256"][GAMMA_NAMES[gamma]], rec["tag"]
+            half = gh.gpu_decode_half(y, c, gamma)
+            assert hashlib.sha256(half.tobytes()).hexdigest() == rec["half_sha256"][GAMMA_NAMES[gamma]], rec["tag"]
+
+
 def test_4k_full_size(gh, oracle):
     """BASELINE config 3 geometry, full size, against the oracle (threads split rows)."""
     from concurrent.futures import ThreadPoolExecutor

@@ -160,6 +160,24 @@ def test_bundled_pattern_crops(oracle, refdata, patterns):
         assert np.array_equal(oracle.decode_nv12(GAMMA_APPLE, y, uv), patterns[rec["tag"] + "_bgra_apple"])
 
 
+def test_whole_bundled_patterns(oracle, full_patterns):
+    """north_star: "bit-exact on the bundled test patterns" -- the WHOLE 1920x1080 QuickTime test pattern (both
+    renditions; BASELINE config 1's frame on the CPU path) and the 512x512 Image.tga, encoded to NV12 and decoded
+    by the reference headers in every gamma, and through decode + exact 2:1 pass 2: the oracle reproduces every
+    byte (hashes: tests/golden/patterns_full.json)."""
+    images, planes = full_patterns
+    assert {tuple(r["image_size"]) for r in images} == {(1920, 1080), (512, 512)} and len(images) == 3
+    for rec in images:
+        y, uv = planes[rec["tag"] + "_y"], planes[rec["tag"] + "_uv"]
+        assert y.shape == (rec["image_size"][1], rec["image_size"][0])
+        assert hashlib.sha256(y.tobytes() + uv.tobytes()).hexdigest() == rec["nv12_sha256"]
+        for gamma in GAMMAS:
+            out = oracle.decode_nv12(gamma, y, uv)
+            assert hashlib.sha256(out.tobytes()).hexdigest() == rec["bgra_sha256"][GAMMA_NAMES[gamma]], rec["tag"]
+        half = oracle.decode_nv12_half(GAMMA_APPLE, y, uv)
+        assert hashlib.sha256(half.tobytes()).hexdigest() == rec["half_sha256"]["apple"], rec["tag"]
+
+
 # ------------------------------------------------------------ live reference (here)
 
 def test_live_reference_pixels(oracle, reference):
