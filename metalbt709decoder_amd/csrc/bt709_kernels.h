@@ -76,6 +76,8 @@ struct DecodeParams {
   uint32_t rep_dec_log2, rep_enc_log2;
   uint32_t tiles_x, tile_rows;
   uint32_t cursor_tx, cursor_rp, cursor_f;
+  // tools/walk_lab.hip only (persistent 1:1 lab kernel): start-up stagger and the CU count
+  uint32_t walk_stagger, walk_cus;
 };
 
 // Pass 1 into an RGBA16Float target (bt709_rgba16f.hip): the threshold table of transfer_tables.h

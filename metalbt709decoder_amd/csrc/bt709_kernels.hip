@@ -103,6 +103,9 @@ __global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_quads(const DecodeParams p) {
   constexpr int UNROLL = kQuadsPerLane;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+#if defined(BT709_LAB_PRIO_LOADS)  // tools/ab_prio.sh: a new wave's address arithmetic and loads ahead of the resident waves' arithmetic (-5 %)
+  __builtin_amdgcn_s_setprio(3);
+#endif
 
   const FramePlanes f = frame_planes(p, blockIdx.z);
   const uint32_t quads = p.width >> 2;
@@ -141,6 +144,12 @@ decode_nv12_quads(const DecodeParams p) {
       ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
     }
   }
+#if defined(BT709_LAB_PRIO_LOADS)
+  __builtin_amdgcn_s_setprio(0);
+#endif
+#if defined(BT709_LAB_PRIO_STORES)  // lab: the other way round: a wave that has its data finishes ahead of younger ones
+  __builtin_amdgcn_s_setprio(BT709_LAB_PRIO_STORES);
+#endif
   if (!QUANT) {  // the sRGB mode needs no table (decode_quad)
     stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
     __syncthreads();
