@@ -41,7 +41,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout or a signature in this file changes.  Bindings compare
  * it with bt709hip_abi_version() so that a library older than the header is refused, not mis-called. */
-#define BT709HIP_VERSION 200
+#define BT709HIP_VERSION 300
 
 typedef struct bt709hip_context bt709hip_context; /* ~ MetalRenderContext */
 typedef struct bt709hip_decoder bt709hip_decoder; /* ~ MetalBT709Decoder  */
@@ -324,6 +324,38 @@ int bt709hip_pool_acquire(bt709hip_pool *pool, int *slot, void **y, size_t *y_st
 int bt709hip_pool_alpha_plane(bt709hip_pool *pool, int slot, void **alpha, size_t *alpha_stride);
 int bt709hip_pool_submit(bt709hip_pool *pool, int slot);
 int bt709hip_pool_wait(bt709hip_pool *pool, int slot, const void **bgra, size_t *stride);
+/* Hands an acquired slot back without submitting it (nothing is enqueued).  A FAILED bt709hip_pool_submit
+ * hands its slot back by itself: a slot never stays "acquired" behind an error. */
+int bt709hip_pool_release(bt709hip_pool *pool, int slot);
+
+/* ------------------------------------------------------------ frame sharder */
+/* ONE process driving SEVERAL GPUs: independent frames shard with no exchange step, frame i (in submission
+ * order) goes to lane i mod n.  The reference is one process with one device, one queue and N frames in
+ * flight (Renderer/MetalRenderContext.m:59-63, Renderer/AAPLRenderer.m:34, 874-985); its counterpart on an
+ * 8-GPU node is this dispatcher over n lanes, each lane = its own bt709hip_context + decoder + in-flight pool
+ * of `depth` slots (one HIP stream, pinned staging and device buffers per slot) on device_ordinals[lane].
+ * Ordinals may repeat (several lanes on one GPU).  No collective, no peer access, nothing crosses GPUs.
+ *   acquire -> ticket + pinned Y / CbCr (/ alpha) planes of the next frame's slot (waits for that slot's previous frame)
+ *   commit  -> upload, decode, download enqueued on the slot's stream of the ticket's lane; returns at once
+ *   submit  -> acquire + copy of caller-owned host planes (any pitch; tags validated as -decodeBT709: does) + commit
+ *   wait    -> the frame's pinned BGRA rows, valid until lanes * depth further frames have been handed out
+ *   cancel  -> hands an acquired, uncommitted ticket back
+ * Threading: a shard is driven by ONE thread at a time (like a pool); that thread only enqueues, the lanes'
+ * streams run concurrently.  Several feeding threads use a shard each (contexts are per shard). */
+typedef struct bt709hip_shard bt709hip_shard;
+int bt709hip_shard_create(const int *device_ordinals, int lanes, int gamma, int has_alpha, int width, int height, int depth,
+                          bt709hip_shard **out);
+int bt709hip_shard_destroy(bt709hip_shard *shard);
+int bt709hip_shard_lanes(const bt709hip_shard *shard);
+int bt709hip_shard_lane_device(const bt709hip_shard *shard, int lane);
+bt709hip_decoder *bt709hip_shard_lane_decoder(bt709hip_shard *shard, int lane); /* for set_option / set_alpha_fill */
+int bt709hip_shard_acquire(bt709hip_shard *shard, uint64_t *ticket, void **y, size_t *y_stride, void **cbcr, size_t *cbcr_stride,
+                           void **alpha, size_t *alpha_stride);
+int bt709hip_shard_commit(bt709hip_shard *shard, uint64_t ticket);
+int bt709hip_shard_cancel(bt709hip_shard *shard);
+int bt709hip_shard_submit(bt709hip_shard *shard, const bt709hip_frame *host_frame, const bt709hip_frame *host_alpha,
+                          uint64_t *ticket);
+int bt709hip_shard_wait(bt709hip_shard *shard, uint64_t ticket, const void **bgra, size_t *stride);
 
 /* ------------------------------------------------------------------ encoder */
 /* The step before the decode path, on the GPU: 8-bit BGRA -> NV12 BT.709 video range with

@@ -24,7 +24,7 @@ class Surface(C.Structure):  # bt709hip_surface
                 ("format", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 200  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
+ABI_VERSION = 300  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
 
 # bt709hip_format
 FORMAT_BGRA8_SRGB = 0
@@ -91,6 +91,19 @@ SYMBOLS = {
     "bt709hip_pool_alpha_plane": (_I, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bt709hip_pool_submit": (_I, [_P, _I]),
     "bt709hip_pool_wait": (_I, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "bt709hip_pool_release": (_I, [_P, _I]),
+    "bt709hip_shard_create": (_I, [C.POINTER(C.c_int), _I, _I, _I, _I, _I, _I, C.POINTER(C.c_void_p)]),
+    "bt709hip_shard_destroy": (_I, [_P]),
+    "bt709hip_shard_lanes": (_I, [_P]),
+    "bt709hip_shard_lane_device": (_I, [_P, _I]),
+    "bt709hip_shard_lane_decoder": (_P, [_P, _I]),
+    "bt709hip_shard_acquire": (_I, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_size_t)]),
+    "bt709hip_shard_commit": (_I, [_P, C.c_uint64]),
+    "bt709hip_shard_cancel": (_I, [_P]),
+    "bt709hip_shard_submit": (_I, [_P, _FP, _FP, C.POINTER(C.c_uint64)]),
+    "bt709hip_shard_wait": (_I, [_P, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bt709hip_graph_begin_capture": (_I, [_P, _P]),
     "bt709hip_graph_end_capture": (_I, [_P, _P, C.POINTER(C.c_void_p)]),
     "bt709hip_graph_launch": (_I, [_P, _P, _P]),

@@ -1042,7 +1042,14 @@ int bt709hip_pool_submit(bt709hip_pool *pool, int slot) {
   if (!s.acquired) return BT709HIP_ERR_INVALID_ARG;
   if (int rc = bind(pool->dec->ctx)) return rc;
   const int w = pool->width, h = pool->height;
-  HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, pool->in_bytes, hipMemcpyHostToDevice, s.stream));
+  {
+    const hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, pool->in_bytes, hipMemcpyHostToDevice, s.stream);
+    if (e != hipSuccess) {
+      s.acquired = false;  // handed back, see below
+      s.busy = true;
+      return hip_fail(e);
+    }
+  }
   bt709hip_frame f;
   std::memset(&f, 0, sizeof f);
   f.y = s.d_in;
@@ -1063,10 +1070,21 @@ int bt709hip_pool_submit(bt709hip_pool *pool, int slot) {
   a.y = s.d_in + static_cast<size_t>(w) * h * 3 / 2;
   a.cbcr = nullptr;
   a.transfer = BT709HIP_TRANSFER_LINEAR;
-  if (int rc = bt709hip_decode(pool->dec, &f, pool->dec->has_alpha ? &a : nullptr, &o, w, h, s.stream, 0)) return rc;
-  HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, pool->out_bytes, hipMemcpyDeviceToHost, s.stream));
+  // From here on the slot is no longer "acquired" whatever happens: a failed submit hands it back (its staging
+  // may hold a partly enqueued frame, so it counts as busy until its stream has drained) instead of leaving a
+  // slot that can be neither submitted nor acquired again.
   s.acquired = false;
   s.busy = true;
+  if (int rc = bt709hip_decode(pool->dec, &f, pool->dec->has_alpha ? &a : nullptr, &o, w, h, s.stream, 0)) return rc;
+  HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, pool->out_bytes, hipMemcpyDeviceToHost, s.stream));
+  return BT709HIP_OK;
+}
+
+int bt709hip_pool_release(bt709hip_pool *pool, int slot) {
+  if (pool == nullptr || slot < 0 || static_cast<size_t>(slot) >= pool->slots.size()) return BT709HIP_ERR_INVALID_ARG;
+  bt709hip_pool::Slot &s = pool->slots[static_cast<size_t>(slot)];
+  if (!s.acquired) return BT709HIP_ERR_INVALID_ARG;
+  s.acquired = false;  // nothing was enqueued: the slot is free at once
   return BT709HIP_OK;
 }
 
@@ -1083,6 +1101,153 @@ int bt709hip_pool_wait(bt709hip_pool *pool, int slot, const void **bgra, size_t 
   *bgra = s.h_out;
   if (stride) *stride = static_cast<size_t>(pool->width) * 4;
   return BT709HIP_OK;
+}
+
+// ------------------------------------------------------------------ frame sharder
+
+struct bt709hip_shard {
+  struct Lane {
+    bt709hip_context *ctx = nullptr;
+    bt709hip_decoder *dec = nullptr;
+    bt709hip_pool *pool = nullptr;
+  };
+  std::vector<Lane> lanes;
+  int width = 0, height = 0, depth = 0, has_alpha = 0, gamma = 0;
+  uint64_t next = 0;       // ticket of the next frame = frames handed out so far
+  bool open = false;       // a ticket is acquired and not yet committed
+  int open_slot = -1;
+  std::vector<int> slot_of;  // [ticket % (lanes * depth)] -> pool slot the frame went to
+};
+
+int bt709hip_shard_destroy(bt709hip_shard *sh) {
+  if (sh == nullptr) return BT709HIP_OK;
+  for (auto &l : sh->lanes) {
+    if (l.pool) bt709hip_pool_destroy(l.pool);
+    if (l.dec) bt709hip_decoder_destroy(l.dec);
+    if (l.ctx) bt709hip_context_destroy(l.ctx);
+  }
+  delete sh;
+  return BT709HIP_OK;
+}
+
+int bt709hip_shard_create(const int *device_ordinals, int lanes, int gamma, int has_alpha, int width, int height, int depth,
+                          bt709hip_shard **out) {
+  if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (device_ordinals == nullptr || lanes <= 0 || lanes > 64 || depth <= 0 || depth > 64 || width <= 0 || height <= 0)
+    return BT709HIP_ERR_INVALID_ARG;
+  if (gamma < 0 || gamma >= kGammaCount) return BT709HIP_ERR_INVALID_ARG;
+  if ((width & 1) || (height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;
+  bt709hip_shard *sh = new (std::nothrow) bt709hip_shard();
+  if (sh == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  sh->width = width, sh->height = height, sh->depth = depth, sh->has_alpha = has_alpha ? 1 : 0;
+  sh->lanes.resize(static_cast<size_t>(lanes));
+  sh->slot_of.assign(static_cast<size_t>(lanes) * depth, -1);
+  int rc = BT709HIP_OK;
+  for (int i = 0; i < lanes && rc == BT709HIP_OK; ++i) {
+    bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(i)];
+    rc = bt709hip_context_create(device_ordinals[i], &l.ctx);
+    if (rc == BT709HIP_OK) rc = bt709hip_decoder_create(l.ctx, gamma, has_alpha, &l.dec);
+    if (rc == BT709HIP_OK) rc = bt709hip_pool_create(l.dec, width, height, depth, &l.pool);
+  }
+  if (rc != BT709HIP_OK) {
+    bt709hip_shard_destroy(sh);
+    return rc;
+  }
+  sh->gamma = sh->lanes[0].dec->gamma;
+  *out = sh;
+  return BT709HIP_OK;
+}
+
+int bt709hip_shard_lanes(const bt709hip_shard *sh) { return sh ? static_cast<int>(sh->lanes.size()) : BT709HIP_ERR_INVALID_ARG; }
+
+int bt709hip_shard_lane_device(const bt709hip_shard *sh, int lane) {
+  if (sh == nullptr || lane < 0 || static_cast<size_t>(lane) >= sh->lanes.size()) return BT709HIP_ERR_INVALID_ARG;
+  return sh->lanes[static_cast<size_t>(lane)].ctx->device;
+}
+
+bt709hip_decoder *bt709hip_shard_lane_decoder(bt709hip_shard *sh, int lane) {
+  if (sh == nullptr || lane < 0 || static_cast<size_t>(lane) >= sh->lanes.size()) return nullptr;
+  return sh->lanes[static_cast<size_t>(lane)].dec;
+}
+
+int bt709hip_shard_acquire(bt709hip_shard *sh, uint64_t *ticket, void **y, size_t *y_stride, void **cbcr, size_t *cbcr_stride,
+                           void **alpha, size_t *alpha_stride) {
+  if (sh == nullptr || ticket == nullptr || y == nullptr || cbcr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (sh->has_alpha && alpha == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (sh->open) return BT709HIP_ERR_INVALID_ARG;  // one frame is being filled: commit or cancel it first
+  bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(sh->next % sh->lanes.size())];  // frame i -> lane i mod n
+  int slot = -1;
+  if (int rc = bt709hip_pool_acquire(l.pool, &slot, y, y_stride, cbcr, cbcr_stride)) return rc;
+  if (alpha != nullptr) {
+    *alpha = nullptr;
+    if (sh->has_alpha) {
+      if (int rc = bt709hip_pool_alpha_plane(l.pool, slot, alpha, alpha_stride)) {
+        (void)bt709hip_pool_release(l.pool, slot);
+        return rc;
+      }
+    }
+  }
+  sh->open = true;
+  sh->open_slot = slot;
+  *ticket = sh->next;
+  return BT709HIP_OK;
+}
+
+int bt709hip_shard_cancel(bt709hip_shard *sh) {
+  if (sh == nullptr || !sh->open) return BT709HIP_ERR_INVALID_ARG;
+  bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(sh->next % sh->lanes.size())];
+  sh->open = false;
+  return bt709hip_pool_release(l.pool, sh->open_slot);
+}
+
+int bt709hip_shard_commit(bt709hip_shard *sh, uint64_t ticket) {
+  if (sh == nullptr || !sh->open || ticket != sh->next) return BT709HIP_ERR_INVALID_ARG;
+  bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(ticket % sh->lanes.size())];
+  sh->open = false;  // pool_submit hands the slot back on failure; the ticket is then void and the lane is reused
+  if (int rc = bt709hip_pool_submit(l.pool, sh->open_slot)) return rc;
+  sh->slot_of[static_cast<size_t>(ticket % sh->slot_of.size())] = sh->open_slot;
+  ++sh->next;
+  return BT709HIP_OK;
+}
+
+int bt709hip_shard_submit(bt709hip_shard *sh, const bt709hip_frame *frame, const bt709hip_frame *alpha, uint64_t *ticket) {
+  if (sh == nullptr || frame == nullptr || ticket == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  // the reference's order (MetalBT709Decoder.m:272-368): sizes, matrix tag, transfer tag, alpha's transfer tag
+  if (frame->width != sh->width || frame->height != sh->height) return BT709HIP_ERR_SIZE_MISMATCH;
+  if (alpha != nullptr && (alpha->width != frame->width || alpha->height != frame->height)) return BT709HIP_ERR_SIZE_MISMATCH;
+  if (frame->matrix != BT709HIP_MATRIX_ITU_R_709_2) return BT709HIP_ERR_MATRIX;
+  if (frame->transfer != required_transfer(sh->gamma)) return BT709HIP_ERR_TRANSFER;
+  if (alpha != nullptr && alpha->transfer != BT709HIP_TRANSFER_LINEAR) return BT709HIP_ERR_ALPHA_TRANSFER;
+  if (sh->has_alpha && (alpha == nullptr || alpha->y == nullptr)) return BT709HIP_ERR_INVALID_ARG;
+  if (frame->y == nullptr || frame->cbcr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  const size_t w = static_cast<size_t>(sh->width), h = static_cast<size_t>(sh->height);
+  if (frame->y_stride < w || frame->cbcr_stride < w || (sh->has_alpha && alpha->y_stride < w)) return BT709HIP_ERR_STRIDE;
+  void *y = nullptr, *c = nullptr, *a = nullptr;
+  size_t ys = 0, cs = 0, as = 0;
+  uint64_t t = 0;
+  if (int rc = bt709hip_shard_acquire(sh, &t, &y, &ys, &c, &cs, sh->has_alpha ? &a : nullptr, &as)) return rc;
+  for (size_t r = 0; r < h; ++r)
+    std::memcpy(static_cast<uint8_t *>(y) + r * ys, static_cast<const uint8_t *>(frame->y) + r * frame->y_stride, w);
+  for (size_t r = 0; r < h / 2; ++r)
+    std::memcpy(static_cast<uint8_t *>(c) + r * cs, static_cast<const uint8_t *>(frame->cbcr) + r * frame->cbcr_stride, w);
+  if (sh->has_alpha)
+    for (size_t r = 0; r < h; ++r)
+      std::memcpy(static_cast<uint8_t *>(a) + r * as, static_cast<const uint8_t *>(alpha->y) + r * alpha->y_stride, w);
+  if (int rc = bt709hip_shard_commit(sh, t)) return rc;
+  *ticket = t;
+  return BT709HIP_OK;
+}
+
+int bt709hip_shard_wait(bt709hip_shard *sh, uint64_t ticket, const void **bgra, size_t *stride) {
+  if (sh == nullptr || bgra == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  // a frame's rows stay valid until its slot is handed out again: lanes * depth submissions later
+  if (ticket >= sh->next || sh->next - ticket > sh->slot_of.size()) return BT709HIP_ERR_INVALID_ARG;
+  bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(ticket % sh->lanes.size())];
+  const int slot = sh->slot_of[static_cast<size_t>(ticket % sh->slot_of.size())];
+  if (slot < 0) return BT709HIP_ERR_INVALID_ARG;
+  if (sh->open && ticket % sh->lanes.size() == sh->next % sh->lanes.size() && slot == sh->open_slot) return BT709HIP_ERR_INVALID_ARG;
+  return bt709hip_pool_wait(l.pool, slot, bgra, stride);
 }
 
 // ------------------------------------------------------------------ encoder

@@ -148,6 +148,69 @@ class InFlightFramePool:
             self.handle = None
 
 
+class FrameSharder:
+    """ONE process, several GPUs (bt709hip_shard_*): frame i -> lane i mod n, each lane its own context, decoder and
+    in-flight pool on devices[lane]; no collective.  What AAPLRenderer's single queue with MaxBuffersInFlight frames
+    (Renderer/AAPLRenderer.m:34, 874-985) becomes on an 8-GPU node.  Frames are host numpy planes."""
+
+    def __init__(self, devices, size, gamma=MetalBT709GammaApple, hasAlphaChannel=False, depth=3):
+        self.lib = _capi.load()
+        self.width, self.height = size
+        self.hasAlphaChannel = bool(hasAlphaChannel)
+        self.gamma = MetalBT709GammaSRGB if hasAlphaChannel else gamma
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        self.lastStatus = self.lib.bt709hip_shard_create(arr, len(devices), int(gamma), int(self.hasAlphaChannel), self.width,
+                                                         self.height, int(depth), C.byref(h))
+        self.handle = h.value if self.lastStatus == _capi.OK else None
+        self.lanes = len(devices) if self.handle else 0
+
+    def submit(self, y, cbcr, alpha=None, transfer=None):
+        """Copies the planes into the next lane's pinned staging and enqueues upload, decode, download there.
+        Returns the frame's ticket, or None (lastStatus says why)."""
+        if not self.handle:
+            return None
+        y = np.ascontiguousarray(y, dtype=np.uint8)
+        cbcr = np.ascontiguousarray(cbcr, dtype=np.uint8)
+        tag = transfer if transfer is not None else {MetalBT709GammaSRGB: kCVImageBufferTransferFunction_sRGB,
+                                                      MetalBT709GammaLinear: kCVImageBufferTransferFunction_Linear}.get(
+                                                          self.gamma, kCVImageBufferTransferFunction_ITU_R_709_2)
+        f = Frame(y.ctypes.data, y.shape[1], cbcr.ctypes.data, cbcr.shape[1], y.shape[1], y.shape[0],
+                  kCVImageBufferYCbCrMatrix_ITU_R_709_2, tag)
+        a = None
+        if alpha is not None:
+            alpha = np.ascontiguousarray(alpha, dtype=np.uint8)
+            a = Frame(alpha.ctypes.data, alpha.shape[1], None, alpha.shape[1], alpha.shape[1], alpha.shape[0],
+                      kCVImageBufferYCbCrMatrix_ITU_R_709_2, kCVImageBufferTransferFunction_Linear)
+        t = C.c_uint64()
+        self.lastStatus = self.lib.bt709hip_shard_submit(self.handle, C.byref(f), C.byref(a) if a is not None else None,
+                                                         C.byref(t))
+        return t.value if self.lastStatus == _capi.OK else None
+
+    def wait(self, ticket):
+        """(H, W*4) uint8 BGRA rows of that frame (a copy), or None."""
+        p, stride = C.c_void_p(), C.c_size_t()
+        self.lastStatus = self.lib.bt709hip_shard_wait(self.handle, int(ticket), C.byref(p), C.byref(stride))
+        if self.lastStatus != _capi.OK:
+            return None
+        raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.height, stride.value))
+        return raw[:, :self.width * 4].copy()
+
+    def laneDevice(self, lane):
+        return self.lib.bt709hip_shard_lane_device(self.handle, int(lane))
+
+    def release(self):
+        if self.handle:
+            self.lib.bt709hip_shard_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class RecordedCommands:
     """Everything issued on a command buffer between beginRecording and endRecording; replay()
     re-issues it with one launch."""

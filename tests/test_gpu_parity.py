@@ -291,6 +291,44 @@ def test_batch_equals_single(gh, oracle):
     assert not dec.decodeBT709Batch(too_many, texs * 5) and dec.lastStatus == _capi.ERR_UNSUPPORTED
 
 
+def test_frame_sharder_four_lanes_on_one_device(gh, oracle):
+    """The in-process multi-GPU dispatcher (bt709hip_shard_*): frame i -> lane i mod n, each lane its own context,
+    decoder and in-flight pool.  Here the four lanes all sit on device 0 (ordinals may repeat), 64 frames go
+    through, every one is byte-compared with the oracle; then tag / size validation and the ticket window."""
+    w, h, lanes, depth = 320, 64, 4, 2
+    sh = mb.FrameSharder([0] * lanes, (w, h), gamma=mb.MetalBT709GammaApple, depth=depth)
+    assert sh.handle, sh.lastStatus
+    assert [sh.laneDevice(i) for i in range(lanes)] == [0] * lanes and sh.lib.bt709hip_shard_lanes(sh.handle) == lanes
+    frames = [gh.random_nv12(w, h, seed=4000 + i) for i in range(64)]
+    window = lanes * depth
+    tickets = []
+    for i, (y, c) in enumerate(frames):
+        t = sh.submit(y, c)
+        assert t == i, sh.lastStatus
+        tickets.append(t)
+        if i >= window - 1:  # collect the oldest frame still held: its slot is the next one to be reused
+            j = i - (window - 1)
+            assert np.array_equal(sh.wait(tickets[j]), oracle.decode_nv12(0, *frames[j])), j
+    for j in range(64 - (window - 1), 64):
+        assert np.array_equal(sh.wait(tickets[j]), oracle.decode_nv12(0, *frames[j])), j
+    assert sh.wait(64) is None and sh.lastStatus == _capi.ERR_INVALID_ARG          # never submitted
+    assert sh.wait(64 - window - 1) is None and sh.lastStatus == _capi.ERR_INVALID_ARG  # its slot has been reused
+    y, c = frames[0]
+    assert sh.submit(y[:32], c[:16]) is None and sh.lastStatus == _capi.ERR_SIZE_MISMATCH
+    assert sh.submit(y, c, transfer=mb.kCVImageBufferTransferFunction_sRGB) is None and sh.lastStatus == _capi.ERR_TRANSFER
+    assert sh.submit(y, c) == 64  # a refused frame takes no ticket and no lane
+    assert np.array_equal(sh.wait(64), oracle.decode_nv12(0, y, c))
+    sh.release()
+    # alpha decoder (sRGB forced), two lanes
+    a = np.random.default_rng(5).integers(0, 256, (h, w), dtype=np.uint8)
+    sh = mb.FrameSharder([0, 0], (w, h), hasAlphaChannel=True)
+    assert sh.handle and sh.gamma == mb.MetalBT709GammaSRGB
+    ts = [sh.submit(y, c, alpha=a) for y, c in frames[:5]]
+    for t, (y, c) in zip(ts, frames[:5]):
+        assert np.array_equal(sh.wait(t), oracle.decode_nv12(1, y, c, alpha=a))
+    sh.release()
+
+
 def test_evenly_spaced_batch_beyond_table_limit(gh, oracle):
     """Frames carved at a constant pitch from one allocation (a ring) need no pointer table:
     one launch takes more than BT709HIP_MAX_BATCH of them."""

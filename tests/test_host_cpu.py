@@ -192,6 +192,31 @@ def test_pool_entry_points_reject_bad_arguments(lib):
     assert lib.bt709hip_pool_destroy(None) == 0
 
 
+def test_shard_entry_points_reject_bad_arguments(lib):
+    """bt709hip_shard_*: argument errors before any device is touched, and NO_DEVICE (never a CPU path) here."""
+    h = C.c_void_p()
+    dev = (C.c_int * 2)(0, 0)
+    assert lib.bt709hip_shard_create(None, 2, 0, 0, 64, 32, 2, C.byref(h)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_create(dev, 0, 0, 0, 64, 32, 2, C.byref(h)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_create(dev, 2, 9, 0, 64, 32, 2, C.byref(h)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_create(dev, 2, 0, 0, 64, 32, 0, C.byref(h)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_create(dev, 2, 0, 0, 63, 32, 2, C.byref(h)) == _capi.ERR_ODD_DIMENSIONS
+    assert lib.bt709hip_shard_create(dev, 2, 0, 0, 64, 32, 2, None) == _capi.ERR_INVALID_ARG
+    if lib.bt709hip_device_count() <= 0:
+        assert lib.bt709hip_shard_create(dev, 2, 0, 0, 64, 32, 2, C.byref(h)) == _capi.ERR_NO_DEVICE and not h.value
+        sh = mb.FrameSharder([0, 0], (64, 32))
+        assert sh.handle is None and sh.lastStatus == _capi.ERR_NO_DEVICE and sh.submit(np.zeros((32, 64), np.uint8), np.zeros((16, 64), np.uint8)) is None
+    t = C.c_uint64()
+    p = C.c_void_p()
+    assert lib.bt709hip_shard_submit(None, None, None, C.byref(t)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_wait(None, 0, C.byref(p), None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_commit(None, 0) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_cancel(None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_lanes(None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_destroy(None) == _capi.OK
+    assert lib.bt709hip_pool_release(None, 0) == _capi.ERR_INVALID_ARG
+
+
 def test_graph_entry_points_reject_bad_arguments(lib):
     """No device needed: argument checks come first, and a NULL context never reaches HIP."""
     g = C.c_void_p()
