@@ -181,6 +181,12 @@ struct HostTexture {  // BGRA8Unorm_sRGB pixels in host memory
   size_t stride = 0;
   int width = 0, height = 0;
 };
+// MTLRenderPassDescriptor as far as the decoder reads it: colorAttachments[0].texture, the view's drawable.  The
+// reference renders straight into it when bgraSRGBTexture is nil (MetalBT709Decoder.m:272-281 guards the size check
+// with `if (bgraSRGBTexture != nil)`, :462-466 picks the render-pass route; caller: AAPLRenderer.m:927-934).
+struct HostRenderPassDescriptor {
+  HostTexture colorAttachment0Texture;
+};
 
 // Pass 2 on its own (Renderer/MetalScaleRenderContext.h:17-40); the view's drawable is a BGRATexture.
 class MetalScaleRenderContext {
@@ -256,16 +262,26 @@ class MetalBT709Decoder {
   // The SAME selector for a caller whose buffers are in host memory, as the reference's are
   // (AAPLRenderer.m:927-957, MetalBT709DecoderTests.m:248-255): planes are copied into the pinned
   // staging of an in-flight slot, upload + decode + download are enqueued on the slot's stream, and
-  // the pixels are copied out of the slot when it completes.  waitUntilCompleted == false returns
-  // at once; the texture is filled by the next call that recycles the slot or by finishHostFrames().
+  // the pixels are copied out of the slot when it completes.
+  //   bgraSRGBTexture == nullptr: the one-pass route -- the target is renderPassDescriptor's colour attachment 0
+  //     (the view's drawable; the frame lands in its top-left renderWidth x renderHeight viewport, .m:575-599).
+  //   waitUntilCompleted == true: the texture holds the frame when the call returns (.m:486-489).
+  //   waitUntilCompleted == false: the reference only ENCODES here, and whatever the caller encodes next into the
+  //     same command buffer (-renderScaled: sampling the intermediate, AAPLRenderer.m:950-976; presentDrawable, :936)
+  //     sees the frame.  A host texture has no command buffer to order against, so by default the frame is complete
+  //     on return as well -- every reference call site works unchanged.  deferredCompletion = true keeps the frame
+  //     in flight instead (up to maxBuffersInFlight of them): the texture is filled when its slot is recycled or by
+  //     finishHostFrames(), which such a caller invokes where it would commit the command buffer.
   // alphaPixelBuffer: required iff hasAlphaChannel (only its Y plane is read).
   bool decodeBT709(const HostPixelBuffer &yCbCrInputTexture, const HostPixelBuffer *alphaPixelBuffer,
-                   const HostTexture &bgraSRGBTexture, const void * /*commandBuffer*/,
-                   const void * /*renderPassDescriptor*/, int renderWidth, int renderHeight, bool waitUntilCompleted) {
+                   const HostTexture *bgraSRGBTexture, const void * /*commandBuffer*/,
+                   const HostRenderPassDescriptor *renderPassDescriptor, int renderWidth, int renderHeight,
+                   bool waitUntilCompleted) {
     if (!setupMetal()) return false;
     const HostPixelBuffer &in = yCbCrInputTexture;
     // the checks -processBT709ToSRGB: makes before it touches a plane (.m:272-368), in its order
-    if (bgraSRGBTexture.width != in.width || bgraSRGBTexture.height != in.height) return fail(BT709HIP_ERR_SIZE_MISMATCH);
+    if (bgraSRGBTexture != nullptr && (bgraSRGBTexture->width != in.width || bgraSRGBTexture->height != in.height))
+      return fail(BT709HIP_ERR_SIZE_MISMATCH);
     if (renderWidth != in.width || renderHeight != in.height) return fail(BT709HIP_ERR_SIZE_MISMATCH);
     if (alphaPixelBuffer && (alphaPixelBuffer->width != in.width || alphaPixelBuffer->height != in.height))
       return fail(BT709HIP_ERR_SIZE_MISMATCH);
@@ -274,35 +290,59 @@ class MetalBT709Decoder {
     if (alphaPixelBuffer && alphaPixelBuffer->transfer != BT709HIP_TRANSFER_LINEAR) return fail(BT709HIP_ERR_ALPHA_TRANSFER);
     if ((in.width & 1) || (in.height & 1)) return fail(BT709HIP_ERR_ODD_DIMENSIONS);
     if (hasAlphaChannel && alphaPixelBuffer == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
+    // the output: the texture, or -- texture nil -- the render pass's colour attachment (.m:462-470)
+    if (bgraSRGBTexture == nullptr && renderPassDescriptor == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
+    HostTexture target = bgraSRGBTexture ? *bgraSRGBTexture : renderPassDescriptor->colorAttachment0Texture;
+    if (bgraSRGBTexture == nullptr) {  // viewport = renderWidth x renderHeight at the attachment's origin
+      if (target.width < in.width || target.height < in.height) return fail(BT709HIP_ERR_SIZE_MISMATCH);
+      target.width = in.width;
+      target.height = in.height;
+    }
     if (in.width == 0 || in.height == 0) return ok();
-    if (in.y == nullptr || in.cbcr == nullptr || bgraSRGBTexture.bgra == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
+    if (in.y == nullptr || in.cbcr == nullptr || target.bgra == nullptr) return fail(BT709HIP_ERR_INVALID_ARG);
     if (in.yStride < static_cast<size_t>(in.width) || in.cbcrStride < static_cast<size_t>(in.width) ||
-        bgraSRGBTexture.stride < static_cast<size_t>(in.width) * 4)
+        target.stride < static_cast<size_t>(in.width) * 4)
       return fail(BT709HIP_ERR_STRIDE);
     if (!hostPool(in.width, in.height)) return false;
 
     int slot = -1;
     void *py = nullptr, *pc = nullptr;
     size_t ys = 0, cs = 0;
-    if (pending_[next_].valid && !finishSlot(next_)) return false;  // the slot about to be recycled still owes its pixels
+    // the pool hands its slots out round-robin and next_ follows it at every acquire (not at submit: a frame that
+    // fails after acquire still consumed its turn); the slot about to be recycled may still owe its pixels
+    if (pending_[next_].valid && !finishSlot(next_)) return false;
     int rc = bt709hip_pool_acquire(pool_, &slot, &py, &ys, &pc, &cs);
     if (rc != BT709HIP_OK) return fail(rc);
+    next_ = (static_cast<size_t>(slot) + 1) % pending_.size();
     copyRows(py, ys, in.y, in.yStride, static_cast<size_t>(in.width), in.height);
     copyRows(pc, cs, in.cbcr, in.cbcrStride, static_cast<size_t>(in.width), in.height / 2);
     if (hasAlphaChannel) {
       void *pa = nullptr;
       size_t as = 0;
       rc = bt709hip_pool_alpha_plane(pool_, slot, &pa, &as);
-      if (rc != BT709HIP_OK) return fail(rc);
+      if (rc != BT709HIP_OK) {
+        bt709hip_pool_release(pool_, slot);  // nothing was enqueued: hand the slot back
+        return fail(rc);
+      }
       copyRows(pa, as, alphaPixelBuffer->y, alphaPixelBuffer->yStride, static_cast<size_t>(in.width), in.height);
     }
     rc = bt709hip_pool_submit(pool_, slot);
-    if (rc != BT709HIP_OK) return fail(rc);
-    pending_[static_cast<size_t>(slot)] = {true, bgraSRGBTexture};
-    next_ = (static_cast<size_t>(slot) + 1) % pending_.size();
-    if (waitUntilCompleted) return finishSlot(static_cast<size_t>(slot));  // .m:486-489
+    if (rc != BT709HIP_OK) return fail(rc);  // a failed submit has handed the slot back itself
+    pending_[static_cast<size_t>(slot)] = {true, target};
+    if (waitUntilCompleted || !deferredCompletion) return finishSlot(static_cast<size_t>(slot));  // .m:486-489
     return ok();
   }
+  // the same with the texture by reference (it cannot be nil)
+  bool decodeBT709(const HostPixelBuffer &yCbCrInputTexture, const HostPixelBuffer *alphaPixelBuffer,
+                   const HostTexture &bgraSRGBTexture, const void *commandBuffer,
+                   const HostRenderPassDescriptor *renderPassDescriptor, int renderWidth, int renderHeight,
+                   bool waitUntilCompleted) {
+    return decodeBT709(yCbCrInputTexture, alphaPixelBuffer, &bgraSRGBTexture, commandBuffer, renderPassDescriptor, renderWidth,
+                       renderHeight, waitUntilCompleted);
+  }
+  // false (default): a host-memory frame is complete when -decodeBT709: returns, whatever waitUntilCompleted says;
+  // true: frames submitted with waitUntilCompleted == false stay in flight until their slot is recycled or finishHostFrames()
+  bool deferredCompletion = false;
 
   // Completes every frame submitted with waitUntilCompleted == false (fills their textures).
   bool finishHostFrames() {

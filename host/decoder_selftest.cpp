@@ -20,6 +20,7 @@ using namespace bt709;
 // submitted without waiting (three in flight), then finished and compared.
 static int run_host_vectors(MetalBT709Decoder &metalDecoder, int argc, char **argv) {
   const int width = 6, height = 4, n = (argc - 1) / 6;
+  metalDecoder.deferredCompletion = true;  // keep three frames in flight; finishHostFrames() below
   std::vector<std::vector<uint8_t>> ys(n), cs(n), outs(n);
   int failures = 0;
   for (int v = 0; v < n; ++v) {
@@ -71,6 +72,36 @@ static int run_host_vectors(MetalBT709Decoder &metalDecoder, int argc, char **ar
   if (metalDecoder.decodeBT709(bad, nullptr, tex, nullptr, nullptr, width, height, true) ||
       metalDecoder.lastStatus() != BT709HIP_ERR_MATRIX)
     ++failures;
+  // The one-pass route of the renderer (AAPLRenderer.m:927-934): bgraSRGBTexture nil, the target is the render pass
+  // descriptor's colour attachment -- here a drawable LARGER than the frame, the frame in its top-left viewport --
+  // and waitUntilCompleted FALSE with the default (non-deferred) completion: the pixels are there on return.
+  metalDecoder.deferredCompletion = false;
+  {
+    const int dw = width + 4, dh = height + 2, i = 1;
+    std::vector<uint8_t> drawable(static_cast<size_t>(dw) * 4 * dh, 0x5A);
+    HostRenderPassDescriptor rpd;
+    rpd.colorAttachment0Texture = HostTexture{drawable.data(), static_cast<size_t>(dw) * 4, dw, dh};
+    HostPixelBuffer buf = bad;
+    buf.matrix = BT709HIP_MATRIX_ITU_R_709_2;
+    if (!metalDecoder.decodeBT709(buf, nullptr, static_cast<const HostTexture *>(nullptr), nullptr, &rpd, width, height, false)) ++failures;
+    const uint32_t want = 0xFF000000u | (static_cast<uint32_t>(std::atoi(argv[i + 3])) << 16) |
+                          (static_cast<uint32_t>(std::atoi(argv[i + 4])) << 8) | static_cast<uint32_t>(std::atoi(argv[i + 5]));
+    for (int row = 0; row < dh; ++row)
+      for (int col = 0; col < dw; ++col) {
+        uint32_t px;
+        std::memcpy(&px, drawable.data() + (static_cast<size_t>(row) * dw + col) * 4, 4);
+        if (px != (row < height && col < width ? want : 0x5A5A5A5Au)) ++failures;
+      }
+    // nil texture AND nil descriptor: nothing to render into
+    if (metalDecoder.decodeBT709(buf, nullptr, static_cast<const HostTexture *>(nullptr), nullptr, nullptr, width, height, true) ||
+        metalDecoder.lastStatus() != BT709HIP_ERR_INVALID_ARG)
+      ++failures;
+    // a drawable smaller than the frame cannot hold the viewport
+    rpd.colorAttachment0Texture.width = width - 2;
+    if (metalDecoder.decodeBT709(buf, nullptr, static_cast<const HostTexture *>(nullptr), nullptr, &rpd, width, height, true) ||
+        metalDecoder.lastStatus() != BT709HIP_ERR_SIZE_MISMATCH)
+      ++failures;
+  }
   std::printf("%s: %d host vectors, %d failures\n", failures ? "FAIL" : "ok", n, failures);
   return failures ? 1 : 0;
 }

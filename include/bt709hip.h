@@ -258,6 +258,16 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count,
                           const bt709hip_surface *outs,
                           void *stream, int wait_until_completed);
 
+/* +[BGRAToBT709Converter unconvert:outBGRAPixels:width:height:type:] on the GPU
+ * (Renderer/BGRAToBT709Converter.h:34-46; the Software type, .m:61-85 -> unconvertSoftware .m:146-198): `ycbcr_words` are
+ * PACKED 4:4:4 pixels in device memory, one 32-bit word Y | Cb << 8 | Cr << 16 each (every pixel its own chroma), rows
+ * in_stride bytes apart; `out` receives (A << 24) | (R << 16) | (G << 8) | B with the decoder's gamma (the reference
+ * hard-selects Apple196, the default) and A = the decoder's alpha fill (bt709hip_decoder_set_alpha_fill(dec, 0)
+ * reproduces unconvertSoftware's words).  Odd width or height -> BT709HIP_ERR_ODD_DIMENSIONS (.m:69-74); a decoder with
+ * an alpha channel -> BT709HIP_ERR_UNSUPPORTED. */
+int bt709hip_unconvert(bt709hip_decoder *dec, const void *ycbcr_words, size_t in_stride, int width, int height,
+                       const bt709hip_surface *out, void *stream, int wait_until_completed);
+
 /* Pass 1 + pass 2 (MetalScaleRenderContext -renderScaled:, bilinear) fused for the
  * exact 2:1 ratio: out is (W/2) x (H/2).  Frame W,H must be multiples of 4.
  * Two-pass-equivalent arithmetic: each output channel is the linear-light mean of

@@ -9,7 +9,7 @@ from . import _capi
 from ._capi import Bt709Error, load as load_library
 from .decoder import (BGRATexture, BGRAToBT709Converter, CommandBuffer, CVPixelBuffer, FrameSharder, InFlightFramePool, MetalBT709Decoder,
                       MetalBT709GammaApple, MetalBT709GammaITU709, MetalBT709GammaLinear, MetalBT709GammaSRGB,
-                      MetalRenderContext, MetalScaleRenderContext, MTLPixelFormatBGRA8Unorm_sRGB, MTLPixelFormatRGBA16Float,
+                      MetalRenderContext, MetalScaleRenderContext, MTLRenderPassDescriptor, MTLPixelFormatBGRA8Unorm_sRGB, MTLPixelFormatRGBA16Float,
                       kCVImageBufferTransferFunction_ITU_R_709_2, kCVImageBufferTransferFunction_Linear,
                       kCVImageBufferTransferFunction_sRGB, kCVImageBufferYCbCrMatrix_ITU_R_601_4,
                       kCVImageBufferYCbCrMatrix_ITU_R_709_2)

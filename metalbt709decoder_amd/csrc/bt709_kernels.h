@@ -173,6 +173,9 @@ const char *launch_copy_probe(void *dst, const void *src, size_t bytes, hipStrea
 // quantiser: the decoder's mode is sRGB (arithmetic transfer step, no table); implied by has_alpha
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
                           uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
+// +unconvert: on packed 4:4:4 words (bt709_kernels.hip unconvert_packed444); `tables` supplies table_unit*, unit_magic, alpha_word
+const char *launch_unconvert(const DecodeParams &tables, const void *in, size_t in_stride, void *out, size_t out_stride, uint32_t width,
+                             uint32_t height, bool vec, bool quantiser, hipStream_t stream);
 // half: grid = (grid_x, H/2 output rows, frames) x block_threads.
 const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool has_alpha, bool nontemporal,
                                uint32_t grid_x, uint32_t block_threads, hipStream_t stream);

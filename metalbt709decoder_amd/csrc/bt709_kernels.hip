@@ -225,6 +225,95 @@ decode_nv12_blocks(const DecodeParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// +[BGRAToBT709Converter unconvert:outBGRAPixels:width:height:type:] on its actual input
+// (Renderer/BGRAToBT709Converter.h:34-46; .m:146-198 unconvertSoftware): PACKED 4:4:4 words Y | Cb << 8 | Cr << 16, one
+// per pixel, every pixel with its own chroma -> BGRA words.  Same per-pixel function as the NV12 kernels (the decoder's
+// gamma; the reference hard-selects Apple196 at .m:165-173), alpha byte = the decoder's alpha fill (0 reproduces
+// unconvertSoftware's words, .m:187-193).  4 B read + 4 B written per pixel.  VEC: a lane owns 4 consecutive pixels
+// (16-byte load and store); otherwise one pixel per lane.  grid = (tiles, rows).
+// ---------------------------------------------------------------------------
+struct UnconvertParams {
+  const uint8_t *in;   // packed words
+  uint8_t *out;        // BGRA words
+  uint32_t in_stride, out_stride, width, height;
+  const void *table_unit;
+  uint32_t table_unit_bytes;
+  float unit_magic;
+  uint32_t alpha_word;
+};
+
+template <bool VEC, bool QUANT>
+__global__ void __launch_bounds__(kBlockThreads)
+unconvert_packed444(const UnconvertParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  if (!QUANT) {
+    stage_table(lds_raw, p.table_unit, p.table_unit_bytes);
+    __syncthreads();
+  }
+  const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
+  const uint32_t row = blockIdx.y;
+  const uint8_t *in = p.in + static_cast<size_t>(row) * p.in_stride;
+  uint8_t *out = p.out + static_cast<size_t>(row) * p.out_stride;
+  constexpr uint32_t N = VEC ? 4 : 1;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // group of N pixels
+  if (i * N >= p.width) return;
+  uint32_t w[N], o[N];
+  if (VEC) {
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(in + 16 * i);
+    w[0] = v.x, w[N > 1 ? 1 : 0] = v.y, w[N > 2 ? 2 : 0] = v.z, w[N > 3 ? 3 : 0] = v.w;
+  } else {
+    w[0] = *reinterpret_cast<const uint32_t *>(in + 4 * i);
+  }
+  float x[3 * N];
+#pragma unroll
+  for (uint32_t k = 0; k < N; ++k) {
+    const Chroma c = chroma_terms(byte_of(w[k], 1), byte_of(w[k], 2));
+    pixel_rgb(byte_of(w[k], 0), c, x[3 * k], x[3 * k + 1], x[3 * k + 2]);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < N; ++k) {
+    uint32_t b[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)));
+    o[k] = pack_bgra(b[0], b[1], b[2], p.alpha_word);
+  }
+  if (VEC) {
+    u32x4 v;
+    v.x = o[0], v.y = o[N > 1 ? 1 : 0], v.z = o[N > 2 ? 2 : 0], v.w = o[N > 3 ? 3 : 0];
+    *reinterpret_cast<u32x4 *>(out + 16 * i) = v;
+  } else {
+    *reinterpret_cast<uint32_t *>(out + 4 * i) = o[0];
+  }
+}
+
+const char *launch_unconvert(const DecodeParams &t, const void *in, size_t in_stride, void *out, size_t out_stride, uint32_t width,
+                             uint32_t height, bool vec, bool quantiser, hipStream_t stream) {
+  UnconvertParams p;
+  p.in = static_cast<const uint8_t *>(in);
+  p.out = static_cast<uint8_t *>(out);
+  p.in_stride = static_cast<uint32_t>(in_stride);
+  p.out_stride = static_cast<uint32_t>(out_stride);
+  p.width = width;
+  p.height = height;
+  p.table_unit = t.table_unit;
+  p.table_unit_bytes = t.table_unit_bytes;
+  p.unit_magic = t.unit_magic;
+  p.alpha_word = t.alpha_word;
+  const uint32_t groups = vec ? width / 4 : width;
+  const dim3 grid((groups + kBlockThreads - 1) / kBlockThreads, height, 1);
+  const size_t lds = quantiser ? 0 : t.table_unit_bytes;
+  if (vec) {
+    if (quantiser) hipLaunchKernelGGL((unconvert_packed444<true, true>), grid, dim3(kBlockThreads), lds, stream, p);
+    else hipLaunchKernelGGL((unconvert_packed444<true, false>), grid, dim3(kBlockThreads), lds, stream, p);
+  } else {
+    if (quantiser) hipLaunchKernelGGL((unconvert_packed444<false, true>), grid, dim3(kBlockThreads), lds, stream, p);
+    else hipLaunchKernelGGL((unconvert_packed444<false, false>), grid, dim3(kBlockThreads), lds, stream, p);
+  }
+  return vec ? "unconvert_packed444<vec>" : "unconvert_packed444";
+}
+
+// ---------------------------------------------------------------------------
 // host-callable launchers (no HIP types in the signature beyond hipStream_t)
 // ---------------------------------------------------------------------------
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
@@ -275,6 +364,8 @@ hipError_t prepare_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false, true>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, true, false>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false, false>),
+      reinterpret_cast<const void *>(&unconvert_packed444<true, false>),
+      reinterpret_cast<const void *>(&unconvert_packed444<false, false>),
       reinterpret_cast<const void *>(&decode_nv12_blocks<true, true>),
       reinterpret_cast<const void *>(&decode_nv12_blocks<false, true>),
       reinterpret_cast<const void *>(&decode_nv12_blocks<false, false>),

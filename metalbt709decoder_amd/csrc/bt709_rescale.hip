@@ -1079,14 +1079,30 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
     if (items > 0x7fffffffull) return nullptr;
     p.tiles_x = cols;
     p.tile_rows = static_cast<uint32_t>(items);
-    // as many workgroups as the chip holds at once (what the registers and the tables' LDS allow per CU)
-    static std::atomic<int> cached[8];  // per (tap mode, alpha): the tables' sizes do not depend on the gamma
-    std::atomic<int> &slot = cached[(taps & 3) * 2 + (has_alpha ? 1 : 0)];
-    int per_cu = slot.load(std::memory_order_relaxed);
+    // as many workgroups as the chip holds at once (what the registers and the tables' LDS allow per CU).  The answer
+    // depends on the kernel variant, on the dynamic LDS (the decode-side table's size follows the gamma's bucket count)
+    // and on the device: a small cache keyed on all three (a miss just asks
+    // again; a torn entry can only mis-size the grid -- the item loop strides by gridDim.x -- never change a result)
+    struct Occupancy {
+      std::atomic<const void *> fn{nullptr};
+      std::atomic<uint64_t> key{0};
+      std::atomic<int> per_cu{0};
+    };
+    static Occupancy cache[16];
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const uint64_t key = (static_cast<uint64_t>(lds) << 16) | static_cast<uint32_t>(device & 0xffff);
+    Occupancy &slot = cache[((reinterpret_cast<uintptr_t>(fn) >> 4) ^ lds ^ static_cast<uint32_t>(device)) & 15];
+    int per_cu = 0;
+    if (slot.fn.load(std::memory_order_acquire) == fn && slot.key.load(std::memory_order_relaxed) == key)
+      per_cu = slot.per_cu.load(std::memory_order_relaxed);
     if (per_cu == 0) {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, static_cast<int>(kBlockThreads * kScaledStrips), lds) != hipSuccess || per_cu < 1)
         per_cu = 4;
-      slot.store(per_cu, std::memory_order_relaxed);
+      slot.fn.store(nullptr, std::memory_order_release);  // invalidate while the fields change
+      slot.key.store(key, std::memory_order_relaxed);
+      slot.per_cu.store(per_cu, std::memory_order_relaxed);
+      slot.fn.store(fn, std::memory_order_release);
     }
     const uint64_t resident = static_cast<uint64_t>(per_cu) * cus;
     grid = dim3(static_cast<uint32_t>(items < resident ? items : resident), 1, 1);

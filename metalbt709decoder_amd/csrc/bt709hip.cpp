@@ -741,8 +741,9 @@ int gather_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
   fold_align(&info->in_align, f0.cbcr_stride);
   if (planes_a) fold_align(&info->in_align, alphas[0].y_stride);
   fold_align(&info->out_align, o0.stride);
-  // the row-pair / output-row dimension of every kernel is gridDim.y
-  if (f0.height / 2 > kMaxGridYZ || o0.height > 2 * kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;
+  // the row-pair dimension of the 1:1 and 2:1 kernels is gridDim.y; the any-ratio kernel walks strips of OUTPUT rows
+  // in a 1-D grid and has its own (documented) limits: 65535 output rows, planes under 2 GiB
+  if (shape != OutShape::kAny && (f0.height / 2 > kMaxGridYZ || o0.height > 2 * kMaxGridYZ)) return BT709HIP_ERR_UNSUPPORTED;
   if (f0.width == 0 || f0.height == 0 || o0.width == 0 || o0.height == 0) return BT709HIP_OK;
 
   if (info->uniform && count > 1) {
@@ -807,6 +808,33 @@ int bt709hip_decode(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt
                         render_height))
     return rc;
   return bt709hip_decode_batch(dec, 1, frame, alpha, out, stream, wait_until_completed);
+}
+
+int bt709hip_unconvert(bt709hip_decoder *dec, const void *ycbcr_words, size_t in_stride, int width, int height,
+                       const bt709hip_surface *out, void *stream, int wait_until_completed) {
+  if (dec == nullptr || out == nullptr || width < 0 || height < 0) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = ensure_setup(dec, stream)) return rc;
+  if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;  // the packed words carry no alpha sample
+  if (out->width != width || out->height != height) return BT709HIP_ERR_SIZE_MISMATCH;
+  if ((width & 1) || (height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;  // BGRAToBT709Converter.m:69-74
+  if (out->format != BT709HIP_FORMAT_BGRA8_SRGB || out->reserved != 0) return BT709HIP_ERR_UNSUPPORTED;
+  if (width == 0 || height == 0) return BT709HIP_OK;
+  if (ycbcr_words == nullptr || out->bgra == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  const size_t row = static_cast<size_t>(width) * 4;
+  if (in_stride < row || (in_stride & 3) || !aligned(ycbcr_words, 4) || out->stride < row || (out->stride & 3) || !aligned(out->bgra, 4) ||
+      in_stride > 0xffffffffu || out->stride > 0xffffffffu)
+    return BT709HIP_ERR_STRIDE;
+  if (height > kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;
+  if (int rc = bind(dec->ctx)) return rc;
+  DecodeParams t;
+  std::memset(&t, 0, sizeof t);
+  set_tables(&t, dec);
+  t.alpha_word = dec->alpha_fill << 24;
+  const bool vec = (width % 4) == 0 && (in_stride % 16) == 0 && (out->stride % 16) == 0 && aligned(ycbcr_words, 16) && aligned(out->bgra, 16);
+  hipStream_t s = pick(dec->ctx, stream);
+  tl_kernel_name = launch_unconvert(t, ycbcr_words, in_stride, out->bgra, out->stride, static_cast<uint32_t>(width),
+                                    static_cast<uint32_t>(height), vec, dec->gamma == kGammaSRGB, s);
+  return finish_launch(s, wait_until_completed);
 }
 
 int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,

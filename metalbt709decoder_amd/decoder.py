@@ -261,6 +261,19 @@ class BGRATexture:
         return Surface(self.ptr, self.stride, self.width, self.height, _FORMAT_OF[self.pixelFormat], 0)
 
 
+class MTLRenderPassDescriptor:
+    """As far as the decoder reads it: colorAttachments[0].texture, the view's drawable (a BGRATexture).  The
+    reference renders straight into it when bgraSRGBTexture is nil (MetalBT709Decoder.m:272-281, 462-466;
+    caller AAPLRenderer.m:927-934)."""
+
+    class _Attachment:
+        texture = None
+
+    def __init__(self, texture=None):
+        self.colorAttachments = [MTLRenderPassDescriptor._Attachment()]
+        self.colorAttachments[0].texture = texture
+
+
 class CVPixelBuffer:
     """kCVPixelFormatType_420YpCbCr8BiPlanarVideoRange buffer in device memory plus the
     attachments -processBT709ToSRGB: validates (MetalBT709Decoder.m:311-368)."""
@@ -481,6 +494,30 @@ class BGRAToBT709Converter:
         return True
 
     @staticmethod
+    def unconvert(decoder, inBT709Pixels, outBGRATexture, width, height, commandBuffer=None):
+        """+unconvert:outBGRAPixels:width:height:type: (BGRAToBT709Converter.h:34-46, Software type) on the GPU:
+        packed 4:4:4 words Y | Cb << 8 | Cr << 16 (a host array here, uploaded into a scratch buffer) -> BGRA words in
+        outBGRATexture, with `decoder`'s gamma and alpha fill (alphaFill = 0 gives unconvertSoftware's words).
+        Returns True/False like the reference (odd sizes are refused, .m:69-74)."""
+        if not decoder.setupMetal():
+            return False
+        ctx = decoder.metalRenderContext
+        words = np.ascontiguousarray(inBT709Pixels, dtype=np.uint32).reshape(int(height), int(width)) if width and height \
+            else np.zeros((0, 0), np.uint32)
+        stride = _align_up(int(width) * 4, 16)
+        scratch = DeviceBuffer(ctx, max(stride * int(height), 16))
+        if words.size:
+            ctx._upload(scratch.ptr, stride, words.view(np.uint8).reshape(int(height), int(width) * 4), commandBuffer)
+        surf = outBGRATexture.surface()
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = ctx.lib.bt709hip_unconvert(decoder._handle, scratch.ptr, stride, int(width), int(height), C.byref(surf), stream, 1)
+        scratch.free()
+        if rc != _capi.OK:
+            return decoder._fail(rc, "unconvert")
+        decoder.lastStatus = _capi.OK
+        return True
+
+    @staticmethod
     def copyBT709ToCoreVideo(inBT709Pixels, cvPixelBuffer):
         """Packed (Cr<<16)|(Cb<<8)|Y words -> NV12 planes (BGRAToBT709Converter.m:1042-1099):
         Y of every pixel; CbCr of every even column, every row writing into row/2, so the
@@ -552,16 +589,25 @@ class MetalBT709Decoder:
     def decodeBT709(self, yCbCrInputTexture, alphaPixelBuffer=None, bgraSRGBTexture=None, commandBuffer=None,
                     renderPassDescriptor=None, renderWidth=0, renderHeight=0, waitUntilCompleted=False):
         """Returns True on success, False on any validation or launch failure
-        (MetalBT709Decoder.h:65-72).  renderPassDescriptor has no HIP meaning: a view
-        drawable is just another BGRATexture, pass it as bgraSRGBTexture."""
+        (MetalBT709Decoder.h:65-72).  bgraSRGBTexture None: the one-pass route -- the target is
+        renderPassDescriptor.colorAttachments[0].texture (the view's drawable, a BGRATexture at least as large
+        as the frame; the frame lands in its top-left renderWidth x renderHeight viewport), as
+        MetalBT709Decoder.m:272-281, 462-466 and the renderer's call at AAPLRenderer.m:927-934."""
         if not self.setupMetal():
             return False
-        if yCbCrInputTexture is None or bgraSRGBTexture is None:
+        target = bgraSRGBTexture
+        if target is None and renderPassDescriptor is not None:
+            target = renderPassDescriptor.colorAttachments[0].texture
+        if yCbCrInputTexture is None or target is None:
             return self._fail(_capi.ERR_INVALID_ARG, "decodeBT709")
         lib = self.metalRenderContext.lib
         frame = yCbCrInputTexture.frame()
         alpha = alphaPixelBuffer.frame() if alphaPixelBuffer is not None else None
-        surf = bgraSRGBTexture.surface()
+        surf = target.surface()
+        if bgraSRGBTexture is None:  # the reference checks a texture's size only when one is passed (.m:272-281)
+            if surf.width < frame.width or surf.height < frame.height:
+                return self._fail(_capi.ERR_SIZE_MISMATCH, "decodeBT709")
+            surf.width, surf.height = frame.width, frame.height
         stream = commandBuffer.stream if commandBuffer is not None else None
         rc = lib.bt709hip_decode(self._handle, C.byref(frame), C.byref(alpha) if alpha is not None else None,
                                  C.byref(surf), int(renderWidth), int(renderHeight), stream,

@@ -1,35 +1,30 @@
 // Source-only: the Objective-C binding a maintainer of mdejong/MetalBT709Decoder would add to route
 // the decode to libbt709hip.so (include/bt709hip.h).  There is no Objective-C runtime, Foundation,
 // CoreVideo or Metal on the ROCm image, so this file is NOT built or run here; the flow it implements
-// -- host planes -> in-flight pool -> host pixels, behind the unchanged 8-argument selector -- is built
-// and tested as host/MetalBT709Decoder.hpp's HostPixelBuffer overload
-// (tests/test_gpu_parity.py::test_cpp_host_mirror_host_memory_overload).  Kept in sync with
-// INTEGRATION.md section 2.
+// -- host planes -> in-flight pool -> host pixels, behind the unchanged 8-argument selector, the nil-texture /
+// render-pass-descriptor route included -- is built and tested as host/MetalBT709Decoder.hpp's HostPixelBuffer
+// overload (tests/test_gpu_parity.py::test_cpp_host_mirror_host_memory_overload).  Kept in sync with
+// INTEGRATION.md section 2 (a CPU test compares the two).
 //
-// The reference's public header (Renderer/MetalBT709Decoder.h) does not change and neither does any
-// caller: AAPLRenderer.m:927-957 and MetalBT709DecoderTests.m:248-255 keep calling
-//   -decodeBT709:alphaPixelBuffer:bgraSRGBTexture:commandBuffer:renderPassDescriptor:
-//    renderWidth:renderHeight:waitUntilCompleted:
-// This file REPLACES the method bodies of Renderer/MetalBT709Decoder.m (it is compiled instead of that
-// file's -setupMetal / -decodeBT709: implementations on a machine whose GPU is an MI355X).
+// The reference's public header (Renderer/MetalBT709Decoder.h) does not change.  This file REPLACES the method
+// bodies of Renderer/MetalBT709Decoder.m (it is compiled instead of that file's -setupMetal / -decodeBT709:
+// implementations on a machine whose GPU is an MI355X).  Which reference call sites work unchanged: INTEGRATION.md 2.
 #import "MetalBT709Decoder.h"
 #import "MetalRenderContext.h"
 #import <CoreVideo/CoreVideo.h>
 #include "bt709hip.h"
 
-// Frames the caller did not wait for: their pixels still have to reach the caller's texture.
-typedef struct {
-  BOOL valid;
-  __unsafe_unretained id<MTLTexture> texture;
-} BT709HIPPending;
+enum { BT709HIPMaxInFlight = 3 };  // MaxBuffersInFlight, AAPLRenderer.m:34
 
 @interface MetalBT709Decoder () {
   bt709hip_context *_hipContext;   // HIP twin of metalRenderContext.device / commandQueue
   bt709hip_decoder *_hipDecoder;
   bt709hip_pool *_hipPool;         // CVPixelBufferPool + texture cache + in-flight semaphore (AAPLRenderer.m:34)
   int _poolWidth, _poolHeight;
-  BT709HIPPending _pending[3];
-  int _nextSlot;
+  // Frames the caller did not wait for: their pixels still have to reach the caller's texture.  STRONG references
+  // (ARC object array): a renderer may drop its per-frame texture before the frame is finished.
+  id<MTLTexture> _pendingTexture[BT709HIPMaxInFlight];   // nil = the slot owes nothing
+  int _nextSlot;                   // the slot bt709hip_pool_acquire hands out next (follows every acquire)
 }
 @end
 
@@ -72,27 +67,35 @@ static void BT709HIPCopyPlane(void *dst, size_t dstStride, CVPixelBufferRef pb, 
   return TRUE;
 }
 
-// Copies a finished slot's pinned BGRA rows into the texture the caller passed for that frame.
+// Copies a finished slot's pinned BGRA rows into the texture the caller passed for that frame: its top-left
+// frame-sized region (the whole texture for bgraSRGBTexture; the viewport for a larger drawable, .m:575-599).
 - (BOOL) finishHIPSlot:(int)slot {
   const void *bgra = NULL; size_t stride = 0;
   if (bt709hip_pool_wait(_hipPool, slot, &bgra, &stride) != BT709HIP_OK) return FALSE;
-  id<MTLTexture> tex = _pending[slot].texture;
+  id<MTLTexture> tex = _pendingTexture[slot];
   // raw bytes into an sRGB texture: -replaceRegion: does not convert, and the HIP kernel already wrote sRGB-encoded bytes
-  [tex replaceRegion:MTLRegionMake2D(0, 0, tex.width, tex.height) mipmapLevel:0 withBytes:bgra bytesPerRow:stride];
-  _pending[slot].valid = FALSE;
+  [tex replaceRegion:MTLRegionMake2D(0, 0, _poolWidth, _poolHeight) mipmapLevel:0 withBytes:bgra bytesPerRow:stride];
+  _pendingTexture[slot] = nil;
   return TRUE;
 }
 
-// Completes every frame submitted with waitUntilCompleted:FALSE.
+// Completes every frame that is still in flight (hipDeferredCompletion callers: before -commit).
 - (BOOL) finishHIPFrames {
   BOOL all = TRUE;
-  for (int s = 0; s < 3; s++) if (_pending[s].valid) all = [self finishHIPSlot:s] && all;
+  for (int s = 0; s < BT709HIPMaxInFlight; s++) if (_pendingTexture[s] != nil) all = [self finishHIPSlot:s] && all;
   return all;
 }
 
-// The UNCHANGED selector (MetalBT709Decoder.h:65-72).  commandBuffer and renderPassDescriptor have no HIP
-// meaning: the pool's per-slot HIP stream plays the command buffer's role, and a view drawable is a
-// texture like any other (pass it as bgraSRGBTexture).
+// The UNCHANGED selector (MetalBT709Decoder.h:65-72).
+//   bgraSRGBTexture nil: the one-pass route (AAPLRenderer.m:927-934) -- the target is
+//     renderPassDescriptor.colorAttachments[0].texture, the view's drawable (.m:272-281 skips the size check for a nil
+//     texture; .m:462-466 renders through the descriptor).
+//   waitUntilCompleted TRUE: the texture holds the frame on return (.m:486-489).
+//   waitUntilCompleted FALSE: the reference only ENCODES into the caller's command buffer, and whatever the caller
+//     encodes next (-renderScaled: sampling the intermediate, AAPLRenderer.m:950-976; presentDrawable, :936) sees the
+//     frame.  The HIP decode is not part of that command buffer, so by default the frame is complete on return as
+//     well: every reference call site keeps working, unchanged.  A caller that sets hipDeferredCompletion = YES keeps
+//     up to three frames in flight instead and calls -finishHIPFrames before it commits the command buffer.
 - (BOOL) decodeBT709:(CVPixelBufferRef)yCbCrPixelBuffer
     alphaPixelBuffer:(CVPixelBufferRef)alphaPixelBuffer
      bgraSRGBTexture:(id<MTLTexture>)bgraSRGBTexture
@@ -105,7 +108,7 @@ renderPassDescriptor:(MTLRenderPassDescriptor*)renderPassDescriptor
   if (![self setupMetal]) return FALSE;
   const int width = (int)CVPixelBufferGetWidth(yCbCrPixelBuffer), height = (int)CVPixelBufferGetHeight(yCbCrPixelBuffer);
   // -processBT709ToSRGB:'s checks, in its order (.m:272-368)
-  if ((int)bgraSRGBTexture.width != width || (int)bgraSRGBTexture.height != height) return FALSE;
+  if (bgraSRGBTexture != nil && ((int)bgraSRGBTexture.width != width || (int)bgraSRGBTexture.height != height)) return FALSE;
   if (renderWidth != width || renderHeight != height) return FALSE;
   if (alphaPixelBuffer && ((int)CVPixelBufferGetWidth(alphaPixelBuffer) != width ||
                            (int)CVPixelBufferGetHeight(alphaPixelBuffer) != height)) return FALSE;
@@ -116,38 +119,43 @@ renderPassDescriptor:(MTLRenderPassDescriptor*)renderPassDescriptor
   if (BT709HIPTransferTag(yCbCrPixelBuffer) != wantTransfer) { NSLog(@"TransferFunction does not match gamma"); return FALSE; }
   if (alphaPixelBuffer && BT709HIPTransferTag(alphaPixelBuffer) != BT709HIP_TRANSFER_LINEAR) return FALSE;
   if (self.hasAlphaChannel && alphaPixelBuffer == NULL) return FALSE;
+  // the output: the texture, or -- texture nil -- the render pass's colour attachment (.m:462-470)
+  id<MTLTexture> target = bgraSRGBTexture != nil ? bgraSRGBTexture : renderPassDescriptor.colorAttachments[0].texture;
+  if (target == nil || (int)target.width < width || (int)target.height < height) return FALSE;
 
   if (_hipPool == NULL || _poolWidth != width || _poolHeight != height) {   // one pool per frame size
     if (_hipPool && ![self finishHIPFrames]) return FALSE;
     bt709hip_pool_destroy(_hipPool); _hipPool = NULL;
-    if (bt709hip_pool_create(_hipDecoder, width, height, 3, &_hipPool) != BT709HIP_OK) return FALSE;
+    if (bt709hip_pool_create(_hipDecoder, width, height, BT709HIPMaxInFlight, &_hipPool) != BT709HIP_OK) return FALSE;
     _poolWidth = width; _poolHeight = height; _nextSlot = 0;
   }
-  if (_pending[_nextSlot].valid && ![self finishHIPSlot:_nextSlot]) return FALSE;  // the slot about to be recycled
+  if (_pendingTexture[_nextSlot] != nil && ![self finishHIPSlot:_nextSlot]) return FALSE;  // the slot about to be recycled
 
   int slot; void *y, *cbcr; size_t ys, cs;
   if (bt709hip_pool_acquire(_hipPool, &slot, &y, &ys, &cbcr, &cs) != BT709HIP_OK) return FALSE;
+  _nextSlot = (slot + 1) % BT709HIPMaxInFlight;   // follows the pool at every acquire: a frame that fails below still took its turn
   CVPixelBufferLockBaseAddress(yCbCrPixelBuffer, kCVPixelBufferLock_ReadOnly);
   BT709HIPCopyPlane(y, ys, yCbCrPixelBuffer, 0, (size_t)width);       // Y:    W x H bytes
   BT709HIPCopyPlane(cbcr, cs, yCbCrPixelBuffer, 1, (size_t)width);    // CbCr: (W/2) x (H/2) byte pairs
   CVPixelBufferUnlockBaseAddress(yCbCrPixelBuffer, kCVPixelBufferLock_ReadOnly);
   if (self.hasAlphaChannel) {
     void *a; size_t as;
-    if (bt709hip_pool_alpha_plane(_hipPool, slot, &a, &as) != BT709HIP_OK) return FALSE;
+    if (bt709hip_pool_alpha_plane(_hipPool, slot, &a, &as) != BT709HIP_OK) {
+      bt709hip_pool_release(_hipPool, slot);                          // nothing was enqueued: hand the slot back
+      return FALSE;
+    }
     CVPixelBufferLockBaseAddress(alphaPixelBuffer, kCVPixelBufferLock_ReadOnly);
     BT709HIPCopyPlane(a, as, alphaPixelBuffer, 0, (size_t)width);     // only the Y plane of the alpha buffer is read
     CVPixelBufferUnlockBaseAddress(alphaPixelBuffer, kCVPixelBufferLock_ReadOnly);
   }
   int status = bt709hip_pool_submit(_hipPool, slot);                  // upload + decode + download on the slot's stream
-  if (status != BT709HIP_OK) { NSLog(@"decodeBT709: %s", bt709hip_strerror(status)); return FALSE; }
-  _pending[slot].valid = TRUE;
-  _pending[slot].texture = bgraSRGBTexture;
-  _nextSlot = (slot + 1) % 3;
-  if (waitUntilCompleted) return [self finishHIPSlot:slot];           // .m:486-489
-  // Asynchronous, like the reference: the frame is in flight on its own HIP stream.  Its pixels reach the
-  // texture when the slot is recycled (three calls later) or when the caller invokes -finishHIPFrames --
-  // on this same thread (the pool is single-threaded), at the point where the reference's renderer
-  // presents the drawable (AAPLRenderer.m:979-1069).
+  if (status != BT709HIP_OK) {                                        // a failed submit has handed the slot back itself
+    NSLog(@"decodeBT709: %s", bt709hip_strerror(status)); return FALSE; }
+  _pendingTexture[slot] = target;
+  if (waitUntilCompleted || !self.hipDeferredCompletion) return [self finishHIPSlot:slot];   // .m:486-489
+  // hipDeferredCompletion: the frame stays in flight on its own HIP stream; its pixels reach the texture when the slot is
+  // recycled (three calls later) or in -finishHIPFrames, which this caller invokes -- on this same thread, the pool is
+  // single-threaded -- before [commandBuffer commit].
   return TRUE;
 }
 @end

@@ -712,6 +712,56 @@ def _decode_status(gh, dec, buf, tex, rw, rh, alpha=None):
     return ok, dec.lastStatus
 
 
+@pytest.mark.parametrize("gamma", GAMMAS)
+def test_unconvert_packed_444_words(gh, oracle, vectors, gamma):
+    """+[BGRAToBT709Converter unconvert:...] (BGRAToBT709Converter.h:34-46, .m:146-198) on its actual input: packed
+    4:4:4 words, every pixel its own chroma.  Random words in every gamma, the vectorised and the per-pixel layout, the
+    reference's alpha byte 0 (unconvertSoftware's words), odd sizes refused; and -- default gamma -- the 28 (Y,Cb,Cr) ->
+    (R,G,B) expectations the reference's XCTest file asserts, as one frame."""
+    ctx = gh.context()
+    rng = np.random.default_rng(40 + gamma)
+    dec = gh.make_decoder(gamma, alpha_fill=0)
+    for w, h in ((64, 8), (30, 6), (1024, 2)):
+        words = rng.integers(0, 1 << 24, (h, w), dtype=np.uint32)
+        tex = ctx.makeBGRATexture((w, h))
+        assert mb.BGRAToBT709Converter.unconvert(dec, words, tex, w, h), dec.lastStatus
+        assert (b"<vec>" in ctx.lib.bt709hip_last_kernel_name()) == (w % 4 == 0)
+        assert np.array_equal(ctx.getBGRATexturePixels(tex).reshape(-1), oracle.unconvert_packed(gamma, words, w, h))
+    tex = ctx.makeBGRATexture((5, 4))
+    assert not mb.BGRAToBT709Converter.unconvert(dec, np.zeros((4, 5), np.uint32), tex, 5, 4) and dec.lastStatus == _capi.ERR_ODD_DIMENSIONS
+    if gamma == mb.MetalBT709GammaApple:
+        recs = vectors["metal_decode"]
+        words = np.array([[r["ycbcr"][0] | (r["ycbcr"][1] << 8) | (r["ycbcr"][2] << 16) for r in recs]] * 2, np.uint32)
+        tex = ctx.makeBGRATexture((len(recs), 2))
+        assert mb.BGRAToBT709Converter.unconvert(dec, words, tex, len(recs), 2)
+        got = ctx.getBGRATexturePixels(tex)
+        want = np.array([(r["rgb_out"][0] << 16) | (r["rgb_out"][1] << 8) | r["rgb_out"][2] for r in recs], np.uint32)
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+def test_one_pass_route_nil_texture_and_render_pass_descriptor(gh, oracle):
+    """AAPLRenderer.m:927-934: -decodeBT709: with bgraSRGBTexture:nil and the view's render pass descriptor -- the
+    decoder renders into colorAttachments[0].texture (MetalBT709Decoder.m:272-281, 462-466).  Here the drawable is
+    larger than the frame: the frame fills the renderWidth x renderHeight viewport at its origin, nothing else."""
+    ctx = gh.context()
+    w, h = 64, 16
+    y, c = gh.random_nv12(w, h, seed=77)
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    buf = gh.make_buffer(y, c, dec.gamma)
+    drawable = ctx.makeBGRATexture((w + 16, h + 4))
+    _capi.check(ctx.lib.bt709hip_memset(ctx.handle, drawable.ptr, 0x3C, drawable.stride * drawable.height, None))
+    rpd = mb.MTLRenderPassDescriptor(drawable)
+    assert dec.decodeBT709(buf, None, None, ctx.commandQueue.commandBuffer(), rpd, w, h, True), dec.lastStatus
+    got = ctx.getBGRATexturePixels(drawable).view(np.uint8).reshape(h + 4, (w + 16) * 4)
+    assert np.array_equal(got[:h, :w * 4], oracle.decode_nv12(0, y, c))
+    assert (got[h:] == 0x3C).all() and (got[:h, w * 4:] == 0x3C).all()
+    # nil texture and nil descriptor; a drawable smaller than the frame; render size != frame size
+    assert not dec.decodeBT709(buf, None, None, None, None, w, h, True) and dec.lastStatus == _capi.ERR_INVALID_ARG
+    small = mb.MTLRenderPassDescriptor(ctx.makeBGRATexture((w - 2, h)))
+    assert not dec.decodeBT709(buf, None, None, None, small, w, h, True) and dec.lastStatus == _capi.ERR_SIZE_MISMATCH
+    assert not dec.decodeBT709(buf, None, None, None, rpd, w + 16, h + 4, True) and dec.lastStatus == _capi.ERR_SIZE_MISMATCH
+
+
 def test_error_behaviour(gh):
     """FALSE on every validation failure, in the reference's order
     (MetalBT709Decoder.m:272-368)."""

@@ -369,8 +369,12 @@ def test_integration_doc_shows_the_shipped_objc_binding():
                  "renderPassDescriptor:(MTLRenderPassDescriptor*)renderPassDescriptor", "renderWidth:(int)renderWidth",
                  "renderHeight:(int)renderHeight", "waitUntilCompleted:(BOOL)waitUntilCompleted", "-(BOOL)setupMetal"):
         assert part in flat, part
-    for call in ("bt709hip_pool_acquire", "bt709hip_pool_submit", "bt709hip_pool_wait", "bt709hip_pool_alpha_plane"):
+    for call in ("bt709hip_pool_acquire", "bt709hip_pool_submit", "bt709hip_pool_wait", "bt709hip_pool_alpha_plane",
+                 "bt709hip_pool_release"):
         assert call in body
+    # the one-pass route: a nil texture is guarded and the render pass descriptor's attachment is the target
+    assert "bgraSRGBTexture!=nil&&" in flat and "renderPassDescriptor.colorAttachments[0].texture" in body
+    assert "__unsafe_unretained" not in body  # pending textures are held strongly
 
 
 def test_product_never_touches_the_oracle():
