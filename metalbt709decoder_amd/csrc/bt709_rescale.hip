@@ -130,7 +130,15 @@ __device__ __forceinline__ uint32_t encode_byte(const RescaleLookup &r, float xs
 constexpr int kLinBatch = BT709_LIN_BATCH;  // 6 or 12 (12: one wait per pixel, 48 VGPRs of buckets in flight)
 __device__ __forceinline__ void linearise12(const RescaleLookup &r, const float *x, float *lin) {
   uint32_t t[12];
+#if defined(BT709_LAB_BOUND_SHARED_INDEX)
+  // tools/ab_half_bounds.sh, WRONG OUTPUT: G and B reuse R's four bucket indices -- what the launch would take if the
+  // index of a block's 12 evaluations cost 4 adds instead of 12 (the ceiling of any "index from the luma term alone" form)
+  magic_index4(x, t, r.magic);
+#pragma unroll
+  for (int i = 4; i < 12; ++i) t[i] = t[i & 3];
+#else
   magic_index12(x, t, r.magic);
+#endif
 #pragma unroll
   for (int h = 0; h < 12 / kLinBatch; ++h) {
     u32x4 e[kLinBatch];  // {edge, lin(base), lin(base + 1), base}: whole vectors keep the read a ds_read_b128
@@ -206,6 +214,14 @@ __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, f
   const float sr = __fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]);
   const float sg = __fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]);
   const float sb = __fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]);
+#if defined(BT709_LAB_BOUND_ONE_ENCODE)
+  // tools/ab_half_bounds.sh, WRONG OUTPUT: one encode-side lookup instead of three (sg, sb still formed and consumed): the
+  // ceiling of any form that folds the three encode lookups of a pixel into one
+  if (UNIFORM_ENCODE) {
+    const uint32_t e = encode_byte_uniform(r, sr);
+    return pack_bgra(e, e + (sg > sr ? 1u : 0u), e + (sb > sr ? 1u : 0u), alpha_word);
+  }
+#endif
   if (UNIFORM_ENCODE) return pack_bgra(encode_byte_uniform(r, sr), encode_byte_uniform(r, sg), encode_byte_uniform(r, sb), alpha_word);
   return pack_bgra(encode_byte(r, __fmul_rn(sr, r.quarter_scale)), encode_byte(r, __fmul_rn(sg, r.quarter_scale)),
                    encode_byte(r, __fmul_rn(sb, r.quarter_scale)), alpha_word);
