@@ -279,6 +279,14 @@ const char *launch_encode(const EncodeParams &params, int frames, bool fast, hip
   if (fast) {
     const uint32_t quads = p.width / 4;
     uint32_t threads = p.block_threads ? p.block_threads : encode_block_threads(p.width);
+    // One picture per launch (what a caller of +convertIntoCoreVideoBuffer: issues) is one under-filled generation of
+    // workgroups: tiles of up to 512 lanes (3840 -> 2 x 512 instead of 3 x 320) ran 7-8 % faster there
+    // (tools/encode_single_shapes.sh, round 3: 665 -> 718-722 Gpixel/s); batched launches keep the 320-lane tiles.
+    if (p.block_threads == 0 && frames == 1) {
+      const uint32_t tiles = (quads + 511) / 512;
+      threads = ((quads + tiles - 1) / tiles + 63) / 64 * 64;
+      if (threads < 64) threads = 64;
+    }
     if (threads > static_cast<uint32_t>(kMaxBlockThreads)) threads = kMaxBlockThreads;
     const dim3 grid((quads + threads - 1) / threads,
                     (p.height / 2 + p.row_pairs_per_block - 1) / p.row_pairs_per_block, frames);

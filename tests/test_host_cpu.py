@@ -417,6 +417,10 @@ def test_bench_two_ranks_gloo_dry_run():
     assert res["value"] <= px / (5 * 0.002) / 1e9
     assert abs(res["value"] - px / (res["ms_per_step"] * 5e-3) / 1e9) / res["value"] < 1e-3
     assert "cpu_baseline" not in res
+    # the K-step region of the contract is timed and reported; the quoted figure comes from regions stretched to
+    # >= 100 ms: K x m steps, m agreed between the ranks (5 steps x 2 ms -> m = 10)
+    assert res["region_steps"] % res["steps"] == 0 and res["region_steps"] * res["ms_per_step"] >= 99.0
+    assert 9.0 <= res["k_step_region_ms"] <= 60.0
 
 
 def test_bench_two_ranks_gloo_dry_run_batch8():

@@ -1,6 +1,7 @@
 """4K 1:1 decode in the sRGB mode with and without an alpha plane, 32 frames per launch (runs on the GPU box): python tools/bench_alpha11.py"""
 import sys, os, ctypes as C
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import gpu_helpers as gh
 import metalbt709decoder_amd as mb

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One-call evidence run on the GPU box: tests, every bench line, rocprof + PMC summaries.
-# usage (through gpurun, from the repo root): tools/evidence.sh r02
-R=${1:-r02}
+# usage (through gpurun, from the repo root): tools/evidence.sh r03
+R=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/$R; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log
@@ -11,23 +11,33 @@ python bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>/dev/
 python bench.py --workload 8k-half > $O/bench_8k-half.json 2>/dev/null
 for sh in 8 4 2 1; do python bench.py --workload 4k-batch8 --share $sh --no-cpu-baseline --steps 400 > $O/bench_batch8_share$sh.json 2>/dev/null; done
 python bench.py --workload 4k-batch8 --share 1 --streams 1 --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_1stream.json 2>/dev/null
+python bench.py --workload 4k-batch8 --share 1 --streams 2 --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_2streams.json 2>/dev/null
 python bench.py --workload 4k-batch8 --share 1 --graph --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_graph.json 2>/dev/null
+{ tools/ab_batch8.sh; echo "# two frames per step"; SHARE=2 STREAMS="1 2 3 4" tools/ab_batch8.sh; } > $O/batch8_streams.txt 2>&1
+tools/encode_single_shapes.sh "320 512" "1 3" > $O/encode_single_shapes.txt 2>&1
 python tools/bench_encode.py --frames-per-launch 32 > $O/bench_encode.json 2>/dev/null
 python tools/bench_encode.py --frames-per-launch 1 > $O/bench_encode_single.json 2>/dev/null
 tools/bench_paths.sh > $O/bench_paths.txt 2>&1
 python tools/stream_bench.py > $O/stream_bench.txt 2>&1
 { python tools/bench_alpha11.py; python tools/bench_half_alpha.py 7680 4320 8 1; python tools/bench_half_alpha.py 7680 4320 8 0; python tools/bench_half_alpha.py 3840 2160 16 1; } > $O/bench_alpha.txt 2>&1
 tools/profile_gpu.sh 4k > /dev/null 2>&1
+tools/profile_gpu.sh 1080p --workload 1080p > /dev/null 2>&1
+# the sRGB-mode (arithmetic quantiser) and alpha variants of the 1:1 kernel: one kernel trace of tools/bench_alpha11.py holds all five decoders
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof_alpha11/trace" -o trace -- python3 "$OLDPWD/tools/bench_alpha11.py" > "$OLDPWD/gpurun_out/prof_alpha11_trace.log" 2>&1 )
 tools/profile_gpu.sh 8k-half --workload 8k-half > /dev/null 2>&1
 PROFILE_PROG=tools/bench_encode.py tools/profile_gpu.sh encode --frames-per-launch 32 > /dev/null 2>&1
 PROFILE_PROG=tools/bench_scaled.py tools/profile_gpu.sh scaled --path scaled --frames-per-launch 8 > /dev/null 2>&1
 PROFILE_PROG=tools/bench_scaled.py tools/profile_gpu.sh rgba16f --path rgba16f --frames-per-launch 16 > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/prof_4k $R 4k > /dev/null
+python tools/pmc_summary.py gpurun_out/prof_1080p $R 1080p > /dev/null
+cp gpurun_out/prof_alpha11/trace/trace_kernel_stats.csv profiles/${R}_alpha11_kernel_stats.csv 2>/dev/null
 python tools/pmc_summary.py gpurun_out/prof_8k-half $R 8k-half > /dev/null
 python tools/pmc_summary.py gpurun_out/prof_encode $R encode encode_bgra > /dev/null
 python tools/pmc_summary.py gpurun_out/prof_scaled $R scaled decode_nv12_scaled > /dev/null
 python tools/pmc_summary.py gpurun_out/prof_rgba16f $R rgba16f decode_nv12_rgba16f > /dev/null
 mkdir -p $O/profiles; cp profiles/${R}_*_kernel_stats.csv profiles/${R}_*_pmc.json profiles/pmc_traffic.json $O/profiles/
+# gpurun merges at most 64 MiB back: the raw traces and counter dumps have been condensed above, drop them
+rm -rf gpurun_out/prof_* gpurun_out/pmcq_*
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$O/bench_*.json")):
