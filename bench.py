@@ -81,6 +81,8 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=0,
                     help="4k-batch8 only: issue consecutive steps round-robin on this many HIP streams (one stream "
                          "per in-flight frame); 0 = auto (2: measured best for every share, profiles/r02_batch8_streams*.txt)")
+    ap.add_argument("--stream-priorities", default="", metavar="P1,P2,...",
+                    help="4k-batch8: scheduling priority of the 2nd, 3rd, ... stream (0 normal, -1 higher, 1 lower); lab knob")
     ap.add_argument("--no-smooth-leg", action="store_true", help="skip the extra smooth-content measurement (N=1, 4k)")
     ap.add_argument("--decoder-option", action="append", default=[], metavar="ID=VALUE",
                     help="bt709hip_decoder_set_option(ID, VALUE) on the bench decoder (tuning sweeps)")
@@ -187,9 +189,13 @@ class GpuRunner:
         # 888 Gpixel/s; two frames per step 833 / 1077 / 1055 / 972; recorded graphs with 1-4 parallel branches 773 / 818 / 838 / 938.
         nstreams = args.streams or ((3 if g["per_launch"] == 1 else 2) if g["batch8"] and not args.graph else 1)
         self.nstreams = nstreams if g["batch8"] else 1
-        for _ in range(self.nstreams - 1):
+        prios = [int(v) for v in args.stream_priorities.split(",") if v.strip()]
+        for i in range(self.nstreams - 1):
             s, e = C.c_void_p(), C.c_void_p()
-            _capi.check(lib.bt709hip_stream_create(h, C.byref(s)), "stream create")
+            if i < len(prios):
+                _capi.check(lib.bt709hip_stream_create_with_priority(h, prios[i], C.byref(s)), "stream create")
+            else:
+                _capi.check(lib.bt709hip_stream_create(h, C.byref(s)), "stream create")
             _capi.check(lib.bt709hip_event_create(h, C.byref(e)), "event create")
             self.extra_streams.append(s.value)
             self.join_events.append(e)

@@ -165,6 +165,10 @@ int bt709hip_context_set_option(bt709hip_context *ctx, int option, int value);
 /* Streams ~ MTLCommandQueue/-commandBuffer (MetalRenderContext.h:20): one per
  * in-flight frame.  `stream == NULL` anywhere below means the context's default. */
 int bt709hip_stream_create(bt709hip_context *ctx, void **stream);
+/* The same with a scheduling priority (hipStreamCreateWithPriority): 0 = normal, negative = higher, positive = lower; clamped
+ * to the device's range.  (MTLCommandQueue has no twin; a renderer that decodes ahead of what it presents puts the look-ahead
+ * frames on a lower-priority stream.) */
+int bt709hip_stream_create_with_priority(bt709hip_context *ctx, int priority, void **stream);
 int bt709hip_stream_destroy(bt709hip_context *ctx, void *stream);
 int bt709hip_stream_synchronize(bt709hip_context *ctx, void *stream);
 

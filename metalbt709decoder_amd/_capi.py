@@ -76,6 +76,7 @@ SYMBOLS = {
     "bt709hip_context_destroy": (_I, [_P]),
     "bt709hip_context_info": (_I, [_P, C.POINTER(DeviceInfo)]),
     "bt709hip_stream_create": (_I, [_P, c_void_pp]),
+    "bt709hip_stream_create_with_priority": (_I, [_P, _I, c_void_pp]),
     "bt709hip_stream_destroy": (_I, [_P, _P]),
     "bt709hip_stream_synchronize": (_I, [_P, _P]),
     "bt709hip_event_create": (_I, [_P, c_void_pp]),

@@ -412,6 +412,18 @@ int bt709hip_stream_create(bt709hip_context *ctx, void **stream) {
   return BT709HIP_OK;
 }
 
+int bt709hip_stream_create_with_priority(bt709hip_context *ctx, int priority, void **stream) {
+  if (stream == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  int least = 0, greatest = 0;  // numerically: least priority >= greatest priority
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const int p = priority > least ? least : (priority < greatest ? greatest : priority);
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p));
+  *stream = s;
+  return BT709HIP_OK;
+}
+
 int bt709hip_stream_destroy(bt709hip_context *ctx, void *stream) {
   if (stream == nullptr) return BT709HIP_OK;
   if (int rc = bind(ctx)) return rc;
