@@ -479,4 +479,48 @@ class InFlightFramePool {
   int lastStatus_ = BT709HIP_OK;
 };
 
+// ONE process, several GPUs (bt709hip_shard_*): frame i -> lane i mod n, each lane its own context, decoder and in-flight
+// pool on devices[lane]; no collective.  What AAPLRenderer's single queue with MaxBuffersInFlight frames
+// (Renderer/AAPLRenderer.m:34, 874-985) becomes on an 8-GPU node.  Driven by one thread at a time.
+class FrameSharder {
+ public:
+  FrameSharder(const std::vector<int> &devices, int width, int height, MetalBT709Gamma gamma = MetalBT709GammaApple,
+               bool hasAlphaChannel = false, int depth = 3)
+      : width_(width), height_(height) {
+    lastStatus_ = bt709hip_shard_create(devices.data(), static_cast<int>(devices.size()), gamma, hasAlphaChannel ? 1 : 0, width,
+                                        height, depth, &shard_);
+  }
+  ~FrameSharder() { bt709hip_shard_destroy(shard_); }
+  FrameSharder(const FrameSharder &) = delete;
+  FrameSharder &operator=(const FrameSharder &) = delete;
+  bool valid() const { return shard_ != nullptr; }
+  int lastStatus() const { return lastStatus_; }
+  int lanes() const { return bt709hip_shard_lanes(shard_); }
+
+  // copies the planes into the next lane's pinned staging and enqueues upload, decode, download there; the ticket, or -1
+  long long submit(const HostPixelBuffer &frame, const HostPixelBuffer *alpha = nullptr) {
+    bt709hip_frame f{}, a{};
+    f.y = frame.y, f.y_stride = frame.yStride, f.cbcr = frame.cbcr, f.cbcr_stride = frame.cbcrStride;
+    f.width = frame.width, f.height = frame.height, f.matrix = frame.matrix, f.transfer = frame.transfer;
+    if (alpha) {
+      a.y = alpha->y, a.y_stride = alpha->yStride, a.width = alpha->width, a.height = alpha->height;
+      a.matrix = alpha->matrix, a.transfer = alpha->transfer;
+    }
+    uint64_t ticket = 0;
+    lastStatus_ = bt709hip_shard_submit(shard_, &f, alpha ? &a : nullptr, &ticket);
+    return lastStatus_ == BT709HIP_OK ? static_cast<long long>(ticket) : -1;
+  }
+  // the frame's pinned BGRA rows (valid for lanes * depth further frames), or nullptr
+  const uint8_t *wait(long long ticket, size_t *stride) {
+    const void *p = nullptr;
+    lastStatus_ = bt709hip_shard_wait(shard_, static_cast<uint64_t>(ticket), &p, stride);
+    return lastStatus_ == BT709HIP_OK ? static_cast<const uint8_t *>(p) : nullptr;
+  }
+
+ private:
+  bt709hip_shard *shard_ = nullptr;
+  int width_, height_;
+  int lastStatus_ = BT709HIP_OK;
+};
+
 }  // namespace bt709

@@ -102,6 +102,36 @@ static int run_host_vectors(MetalBT709Decoder &metalDecoder, int argc, char **ar
         metalDecoder.lastStatus() != BT709HIP_ERR_SIZE_MISMATCH)
       ++failures;
   }
+  // The same vectors through the in-process frame sharder: three lanes, all on device 0, frame i -> lane i mod 3.
+  {
+    FrameSharder sharder({0, 0, 0}, width, height, MetalBT709GammaApple, false, 2);
+    if (!sharder.valid() || sharder.lanes() != 3) ++failures;
+    std::vector<long long> tickets(n, -1);
+    for (int v = 0; v < n && sharder.valid(); ++v) {
+      HostPixelBuffer b;
+      b.y = ys[v].data(), b.yStride = width + 3, b.cbcr = cs[v].data(), b.cbcrStride = width, b.width = width, b.height = height;
+      tickets[v] = sharder.submit(b);
+      if (tickets[v] != v) ++failures;
+      const int done = v - 5;  // lanes * depth = 6 frames stay valid
+      for (int w = (v == n - 1 ? (done < 0 ? 0 : done) : done); w >= 0 && w <= (v == n - 1 ? v : done); ++w) {
+        const int i = 1 + 6 * w;
+        size_t stride = 0;
+        const uint8_t *rows = sharder.wait(tickets[w], &stride);
+        const uint32_t want = 0xFF000000u | (static_cast<uint32_t>(std::atoi(argv[i + 3])) << 16) |
+                              (static_cast<uint32_t>(std::atoi(argv[i + 4])) << 8) | static_cast<uint32_t>(std::atoi(argv[i + 5]));
+        if (rows == nullptr) {
+          ++failures;
+          continue;
+        }
+        for (int row = 0; row < height; ++row)
+          for (int col = 0; col < width; ++col) {
+            uint32_t px;
+            std::memcpy(&px, rows + static_cast<size_t>(row) * stride + 4 * col, 4);
+            if (px != want) ++failures;
+          }
+      }
+    }
+  }
   std::printf("%s: %d host vectors, %d failures\n", failures ? "FAIL" : "ok", n, failures);
   return failures ? 1 : 0;
 }

@@ -352,7 +352,8 @@ int bt709hip_pool_release(bt709hip_pool *pool, int slot);
  *   acquire -> ticket + pinned Y / CbCr (/ alpha) planes of the next frame's slot (waits for that slot's previous frame)
  *   commit  -> upload, decode, download enqueued on the slot's stream of the ticket's lane; returns at once
  *   submit  -> acquire + copy of caller-owned host planes (any pitch; tags validated as -decodeBT709: does) + commit
- *   wait    -> the frame's pinned BGRA rows, valid until lanes * depth further frames have been handed out
+ *   wait    -> the frame's pinned BGRA rows, valid until its slot is handed out again: lanes * depth frames later (sooner if
+ *              frames of its lane were cancelled or failed in between); BT709HIP_ERR_INVALID_ARG once recycled
  *   cancel  -> hands an acquired, uncommitted ticket back
  * Threading: a shard is driven by ONE thread at a time (like a pool); that thread only enqueues, the lanes'
  * streams run concurrently.  Several feeding threads use a shard each (contexts are per shard). */

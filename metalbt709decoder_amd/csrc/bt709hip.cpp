@@ -1156,7 +1156,10 @@ struct bt709hip_shard {
   uint64_t next = 0;       // ticket of the next frame = frames handed out so far
   bool open = false;       // a ticket is acquired and not yet committed
   int open_slot = -1;
-  std::vector<int> slot_of;  // [ticket % (lanes * depth)] -> pool slot the frame went to
+  // [lane * depth + pool slot] -> ticket whose pixels the slot holds (kNoTicket: none).  A slot is found by its ticket, not by
+  // arithmetic: a cancelled or failed frame advances its lane's pool without taking a ticket, so slots and tickets drift apart.
+  std::vector<uint64_t> owner;
+  static constexpr uint64_t kNoTicket = ~0ull;
 };
 
 int bt709hip_shard_destroy(bt709hip_shard *sh) {
@@ -1182,7 +1185,7 @@ int bt709hip_shard_create(const int *device_ordinals, int lanes, int gamma, int 
   if (sh == nullptr) return BT709HIP_ERR_INVALID_ARG;
   sh->width = width, sh->height = height, sh->depth = depth, sh->has_alpha = has_alpha ? 1 : 0;
   sh->lanes.resize(static_cast<size_t>(lanes));
-  sh->slot_of.assign(static_cast<size_t>(lanes) * depth, -1);
+  sh->owner.assign(static_cast<size_t>(lanes) * depth, bt709hip_shard::kNoTicket);
   int rc = BT709HIP_OK;
   for (int i = 0; i < lanes && rc == BT709HIP_OK; ++i) {
     bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(i)];
@@ -1216,9 +1219,11 @@ int bt709hip_shard_acquire(bt709hip_shard *sh, uint64_t *ticket, void **y, size_
   if (sh == nullptr || ticket == nullptr || y == nullptr || cbcr == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (sh->has_alpha && alpha == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (sh->open) return BT709HIP_ERR_INVALID_ARG;  // one frame is being filled: commit or cancel it first
-  bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(sh->next % sh->lanes.size())];  // frame i -> lane i mod n
+  const size_t lane = static_cast<size_t>(sh->next % sh->lanes.size());  // frame i -> lane i mod n
+  bt709hip_shard::Lane &l = sh->lanes[lane];
   int slot = -1;
   if (int rc = bt709hip_pool_acquire(l.pool, &slot, y, y_stride, cbcr, cbcr_stride)) return rc;
+  sh->owner[lane * sh->depth + static_cast<size_t>(slot)] = bt709hip_shard::kNoTicket;  // the slot's previous frame is gone
   if (alpha != nullptr) {
     *alpha = nullptr;
     if (sh->has_alpha) {
@@ -1243,10 +1248,11 @@ int bt709hip_shard_cancel(bt709hip_shard *sh) {
 
 int bt709hip_shard_commit(bt709hip_shard *sh, uint64_t ticket) {
   if (sh == nullptr || !sh->open || ticket != sh->next) return BT709HIP_ERR_INVALID_ARG;
-  bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(ticket % sh->lanes.size())];
+  const size_t lane = static_cast<size_t>(ticket % sh->lanes.size());
+  bt709hip_shard::Lane &l = sh->lanes[lane];
   sh->open = false;  // pool_submit hands the slot back on failure; the ticket is then void and the lane is reused
   if (int rc = bt709hip_pool_submit(l.pool, sh->open_slot)) return rc;
-  sh->slot_of[static_cast<size_t>(ticket % sh->slot_of.size())] = sh->open_slot;
+  sh->owner[lane * sh->depth + static_cast<size_t>(sh->open_slot)] = ticket;
   ++sh->next;
   return BT709HIP_OK;
 }
@@ -1281,13 +1287,14 @@ int bt709hip_shard_submit(bt709hip_shard *sh, const bt709hip_frame *frame, const
 
 int bt709hip_shard_wait(bt709hip_shard *sh, uint64_t ticket, const void **bgra, size_t *stride) {
   if (sh == nullptr || bgra == nullptr) return BT709HIP_ERR_INVALID_ARG;
-  // a frame's rows stay valid until its slot is handed out again: lanes * depth submissions later
-  if (ticket >= sh->next || sh->next - ticket > sh->slot_of.size()) return BT709HIP_ERR_INVALID_ARG;
-  bt709hip_shard::Lane &l = sh->lanes[static_cast<size_t>(ticket % sh->lanes.size())];
-  const int slot = sh->slot_of[static_cast<size_t>(ticket % sh->slot_of.size())];
-  if (slot < 0) return BT709HIP_ERR_INVALID_ARG;
-  if (sh->open && ticket % sh->lanes.size() == sh->next % sh->lanes.size() && slot == sh->open_slot) return BT709HIP_ERR_INVALID_ARG;
-  return bt709hip_pool_wait(l.pool, slot, bgra, stride);
+  // a frame's rows stay valid until its slot is handed out again: lanes * depth frames later, sooner if frames of its lane
+  // were cancelled or failed in between (they consume a slot without a ticket)
+  if (ticket >= sh->next) return BT709HIP_ERR_INVALID_ARG;
+  const size_t lane = static_cast<size_t>(ticket % sh->lanes.size());
+  for (int slot = 0; slot < sh->depth; ++slot)
+    if (sh->owner[lane * sh->depth + static_cast<size_t>(slot)] == ticket)
+      return bt709hip_pool_wait(sh->lanes[lane].pool, slot, bgra, stride);
+  return BT709HIP_ERR_INVALID_ARG;  // never committed, or its slot has been recycled
 }
 
 // ------------------------------------------------------------------ encoder

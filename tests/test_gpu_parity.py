@@ -318,6 +318,24 @@ def test_frame_sharder_four_lanes_on_one_device(gh, oracle):
     assert sh.submit(y, c, transfer=mb.kCVImageBufferTransferFunction_sRGB) is None and sh.lastStatus == _capi.ERR_TRANSFER
     assert sh.submit(y, c) == 64  # a refused frame takes no ticket and no lane
     assert np.array_equal(sh.wait(64), oracle.decode_nv12(0, y, c))
+    # acquire + cancel consumes a slot of the lane without a ticket: frames are found by ticket, and a ticket whose slot
+    # was recycled early by that is reported gone, never served from another frame's pixels
+    lib, t = sh.lib, C.c_uint64()
+    py, pc, ys, cs = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+    assert lib.bt709hip_shard_acquire(sh.handle, C.byref(t), C.byref(py), C.byref(ys), C.byref(pc), C.byref(cs), None, None) == _capi.OK
+    assert t.value == 65 and lib.bt709hip_shard_commit(sh.handle, 64) == _capi.ERR_INVALID_ARG  # not the open ticket
+    assert lib.bt709hip_shard_acquire(sh.handle, C.byref(t), C.byref(py), C.byref(ys), C.byref(pc), C.byref(cs), None, None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_shard_cancel(sh.handle) == _capi.OK and lib.bt709hip_shard_cancel(sh.handle) == _capi.ERR_INVALID_ARG
+    more = [gh.random_nv12(w, h, seed=5000 + i) for i in range(2 * window)]
+    got_tickets = [sh.submit(yy, cc) for yy, cc in more]
+    assert got_tickets == list(range(65, 65 + 2 * window))
+    for k in range(window):  # the newest `window - lanes` frames are certainly still there; older ones are gone or exact
+        j = 2 * window - 1 - k
+        out = sh.wait(got_tickets[j])
+        if k < window - lanes:
+            assert out is not None
+        if out is not None:
+            assert np.array_equal(out, oracle.decode_nv12(0, *more[j])), j
     sh.release()
     # alpha decoder (sRGB forced), two lanes
     a = np.random.default_rng(5).integers(0, 256, (h, w), dtype=np.uint8)
