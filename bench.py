@@ -44,11 +44,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 WORKLOADS = {
     # name: (width, height, half_scale, default ring, frames per launch)
-    # The ring is one evenly spaced slab, so a launch may hold any number of frames (grid.z = frame);
-    # ~1.5 GB of traffic per launch measured best (4K: 32 frames 1 % faster than 64; 1080p: 128 frames
-    # 5 % faster than 32).
-    "4k": (3840, 2160, False, 64, 32),
-    "1080p": (1920, 1080, False, 256, 128),
+    # The ring is one evenly spaced slab, so a launch may hold any number of frames (grid.z = frame).  Rounds 1-2: ~1.5 GB
+    # of traffic per launch measured best with the plain work map (4K: 32 frames; longer launches got slower: 64 / 128 /
+    # 256 frames 0.75 / 0.71 / 0.70).  Round 3: with the XCD-aware work map (each XCD class a contiguous band of the launch's
+    # frames, csrc/bt709_kernels.hip) a launch GAINS with its length -- no tail, no boundary -- so a step is ONE launch over
+    # a ring of 256 distinct 4K frames (11.7 GB in + out; 1080p: 1024 frames): 0.77-0.81 against 0.75-0.77, same allocation.
+    "4k": (3840, 2160, False, 256, 256),
+    "1080p": (1920, 1080, False, 1024, 1024),
     "8k-half": (7680, 4320, True, 16, 16),
     # BASELINE config 5: 8 frames per step over ALL ranks; per_launch is replaced by the rank's share
     "4k-batch8": (3840, 2160, False, 64, 8),
@@ -81,6 +83,8 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=0,
                     help="4k-batch8 only: issue consecutive steps round-robin on this many HIP streams (one stream "
                          "per in-flight frame); 0 = auto (2: measured best for every share, profiles/r02_batch8_streams*.txt)")
+    ap.add_argument("--placement-tries", type=int, default=4,
+                    help="allocate the ring this many times, time the step's launch on each (untimed set-up), keep the fastest, free the rest")
     ap.add_argument("--stream-priorities", default="", metavar="P1,P2,...",
                     help="4k-batch8: scheduling priority of the 2nd, 3rd, ... stream (0 normal, -1 higher, 1 lower); lab knob")
     ap.add_argument("--no-smooth-leg", action="store_true", help="skip the extra smooth-content measurement (N=1, 4k)")
@@ -155,26 +159,19 @@ class GpuRunner:
         ring, W, H, OW, OH = g["ring"], g["W"], g["H"], g["OW"], g["OH"]
         self.in_stride = in_stride = (g["y_bytes"] + g["c_bytes"] + 255) // 256 * 256
         self.out_stride = out_stride = (g["o_bytes"] + 255) // 256 * 256
-        self.d_in, self.d_out = C.c_void_p(), C.c_void_p()
-        _capi.check(lib.bt709hip_malloc(h, in_stride * ring, C.byref(self.d_in)), "malloc in")
-        _capi.check(lib.bt709hip_malloc(h, out_stride * ring, C.byref(self.d_out)), "malloc out")
-        self.host_frames = {}
-        self.fill_ring(args.content)
-        self.frames = (Frame * ring)()
-        self.surfs = (Surface * ring)()
-        for i in range(ring):
-            base = self.d_in.value + i * in_stride
-            self.frames[i] = Frame(base, W, base + g["y_bytes"], W, W, H, 1, TRANSFER_TAG[gamma])
-            self.surfs[i] = Surface(self.d_out.value + i * out_stride, OW * 4, OW, OH)
         self.ev0, self.ev1, self.ev_fork = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _capi.check(lib.bt709hip_event_create(h, C.byref(self.ev0)))
         _capi.check(lib.bt709hip_event_create(h, C.byref(self.ev1)))
         _capi.check(lib.bt709hip_event_create(h, C.byref(self.ev_fork)))
         self.Frame, self.Surface = Frame, Surface
-        self.pos = 0          # 4k-batch8: ring position of the next step
         self.stream = None    # launch stream: the context's default, or a created one when recording a graph
+        self.extra_streams, self.join_events = [], []
+        self.host_frames = {}
+        self.placement = self.place_ring(max(1, args.placement_tries), gamma)
+        self.fill_ring(args.content)
+        self.pos = 0          # 4k-batch8: ring position of the next step
         self.graph = None
-        self.extra_streams, self.join_events, self.turn = [], [], 0
+        self.turn = 0
         if args.graph:
             s = C.c_void_p()
             _capi.check(lib.bt709hip_stream_create(h, C.byref(s)), "stream create")
@@ -207,6 +204,59 @@ class GpuRunner:
         while time.perf_counter() < t_end:
             self.step()
             self.sync()
+
+    def bind_ring(self, d_in, d_out, gamma):
+        g = self.g
+        self.d_in, self.d_out = d_in, d_out
+        self.frames = (self.Frame * g["ring"])()
+        self.surfs = (self.Surface * g["ring"])()
+        for i in range(g["ring"]):
+            base = d_in.value + i * self.in_stride
+            self.frames[i] = self.Frame(base, g["W"], base + g["y_bytes"], g["W"], g["W"], g["H"], 1, TRANSFER_TAG[gamma])
+            self.surfs[i] = self.Surface(d_out.value + i * self.out_stride, g["OW"] * 4, g["OW"], g["OH"])
+
+    def place_ring(self, tries, gamma):
+        """Where a slab lands in HBM decides how fast it streams: the same launch runs at 0.74-0.81 of the roofline on
+        different allocations made by ONE process, each allocation keeping its rate (tools/placement_hunt.py; the same-run
+        copy moves with it: 5.7-6.4 TB/s).  Untimed set-up: allocate the ring `tries` times (all candidates alive, so they
+        land in different places), time the step's own launches on each -- the input is whatever the memory holds, any
+        bytes decode --, keep the fastest, free the rest.  The probe rates are reported in config.placement."""
+        lib, h, g = self.lib, self.h, self.g
+        cands = []
+        for _ in range(tries):
+            d_in, d_out = C.c_void_p(), C.c_void_p()
+            rc = lib.bt709hip_malloc(h, self.in_stride * g["ring"], C.byref(d_in))
+            if rc == 0:
+                rc = lib.bt709hip_malloc(h, self.out_stride * g["ring"], C.byref(d_out))
+            if rc != 0:  # out of memory: hunt among what we have
+                if d_in.value:
+                    lib.bt709hip_free(h, d_in)
+                break
+            cands.append((d_in, d_out))
+        if not cands:
+            raise self._capi.Bt709Error(rc, "ring allocation")
+        rates = []
+        if len(cands) > 1:
+            for d_in, d_out in cands:
+                self.bind_ring(d_in, d_out, gamma)
+                t_end = time.perf_counter() + 0.15
+                while time.perf_counter() < t_end:
+                    self.launch(0, g["per_launch"])
+                    self.sync()
+                reps = max(3, int(3 * 64 / g["per_launch"]))
+                self.mark(0)
+                for _ in range(reps):
+                    self.launch(0, g["per_launch"])
+                self.mark(1)
+                self.sync()
+                rates.append(g["bytes_per_frame"] * g["per_launch"] * reps / (self.event_ms() / 1e3) / 1e9)
+        best = max(range(len(cands)), key=lambda i: rates[i]) if rates else 0
+        for i, (d_in, d_out) in enumerate(cands):
+            if i != best:
+                lib.bt709hip_free(h, d_in)
+                lib.bt709hip_free(h, d_out)
+        self.bind_ring(cands[best][0], cands[best][1], gamma)
+        return {"tries": len(cands), "probe_GBps": [round(r, 1) for r in rates], "chosen": best}
 
     def fill_ring(self, content):
         """Uploads (outside every timed region) the ring's frames: seeded PRNG bytes or smooth planes."""
@@ -492,6 +542,7 @@ def main(argv=None):
             "frames_per_step_per_gpu": g["frames_per_step"],
             "streams": getattr(runner, "nstreams", 1),
             "sharding": "independent frames per GPU, no collective",
+            "placement": getattr(runner, "placement", None),  # ring allocated `tries` times, the fastest-streaming one kept (untimed set-up)
             "device": runner.device,
             "arch": runner.arch,
             "device_props": runner.props,

@@ -35,6 +35,7 @@ OPT_NONTEMPORAL = 1
 OPT_HALF_KERNEL = 2
 OPT_HALF_WORKGROUPS = 3
 OPT_HALF_LDS_KB = 4
+OPT_XCD_BANDS = 5
 CTX_OPT_GRID_MULT = 1
 CTX_OPT_ENCODE_ROW_PAIRS = 2
 CTX_OPT_ENCODE_THREADS = 3

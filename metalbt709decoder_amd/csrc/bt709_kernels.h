@@ -78,6 +78,9 @@ struct DecodeParams {
   uint32_t cursor_tx, cursor_rp, cursor_f;
   // tools/walk_lab.hip only (persistent 1:1 lab kernel): start-up stagger and the CU count
   uint32_t walk_stagger, walk_cus;
+  // XCD-aware work map of the short-lived kernels (filled by the launchers): grid.x = 8 x tiles, x & 7 = the workgroup's
+  // place in the round-robin over the XCDs, which owns frames [(x & 7) * frames_per_band, ...) of the launch
+  uint32_t xcd_bands, frames_per_band;
 };
 
 // Pass 1 into an RGBA16Float target (bt709_rgba16f.hip): the threshold table of transfer_tables.h
@@ -171,8 +174,9 @@ const char *launch_copy_probe(void *dst, const void *src, size_t bytes, hipStrea
 // decode: variant kVariantQuads -> grid = (grid_x tiles, H/2, frames) x block_threads;
 //         variant kVariantBlocks -> grid = (grid_x, frames) x kBlockThreads, grid-strided.
 // quantiser: the decoder's mode is sRGB (arithmetic transfer step, no table); implied by has_alpha
+// xcd_bands: use the XCD-aware work map when the launch allows it (fast path, frames a multiple of 8)
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
-                          uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
+                          int xcd_bands, uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
 // +unconvert: on packed 4:4:4 words (bt709_kernels.hip unconvert_packed444); `tables` supplies table_unit*, unit_magic, alpha_word
 const char *launch_unconvert(const DecodeParams &tables, const void *in, size_t in_stride, void *out, size_t out_stride, uint32_t width,
                              uint32_t height, bool vec, bool quantiser, hipStream_t stream);

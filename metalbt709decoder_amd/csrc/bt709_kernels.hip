@@ -107,7 +107,18 @@ decode_nv12_quads(const DecodeParams p) {
   __builtin_amdgcn_s_setprio(3);
 #endif
 
-  const FramePlanes f = frame_planes(p, blockIdx.z);
+  // XCD-AWARE WORK MAP (p.xcd_bands; launches whose frame count is a multiple of 8).  Workgroups are dealt round-robin
+  // over the 8 XCDs in dispatch order, so with the plain map (tile, row pair, frame) XCD k owns the tile rows = k mod 8 of
+  // ONE address stream -- and an XCD that runs a few percent ahead of another (they sit at different distances from
+  // the HBM stacks) widens the band of rows in flight for the whole launch: measured, the longer a launch, the slower
+  // (64 / 128 / 256 frames per launch: 0.75 / 0.71 / 0.70 of the roofline against 0.77 for 32).  Here grid.x = 8 x tiles, so
+  // x & 7 IS the workgroup's position in the round-robin, and XCD-class b gets a contiguous band of the launch's frames
+  // [b F/8, (b + 1) F/8): eight sequential streams that cannot drift into each other.  Long launches then GAIN (no tail,
+  // no boundary): 256 frames per launch 0.80-0.81.  Speed only: nothing depends on which XCD a workgroup really lands on.
+  const uint32_t tile = p.xcd_bands ? blockIdx.x >> 3 : blockIdx.x;
+  const uint32_t frame = p.xcd_bands == 1 ? (blockIdx.x & 7u) * p.frames_per_band + blockIdx.z
+                       : (p.xcd_bands == 2 ? blockIdx.z * 8u + (blockIdx.x & 7u) : blockIdx.z);
+  const FramePlanes f = frame_planes(p, frame);
   const uint32_t quads = p.width >> 2;
   const uint32_t row_pairs = p.height >> 1;
   // blockDim.y > 1 only for narrow frames: a workgroup then covers blockDim.y consecutive row
@@ -119,7 +130,7 @@ decode_nv12_quads(const DecodeParams p) {
   const uint32_t rp = min(rp_raw, row_pairs - 1);
   // quad u of this lane: consecutive lanes own consecutive quads (a store instruction must fill whole
   // lines: a lane owning ADJACENT quads measured 3x slower, tools/lab_quads_variants.hip)
-  const uint32_t q0 = blockIdx.x * (blockDim.x * UNROLL) + threadIdx.x;
+  const uint32_t q0 = tile * (blockDim.x * UNROLL) + threadIdx.x;
 
   const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
   const uint8_t *y1 = y0 + p.y_stride;
@@ -316,15 +327,22 @@ const char *launch_unconvert(const DecodeParams &t, const void *in, size_t in_st
 // ---------------------------------------------------------------------------
 // host-callable launchers (no HIP types in the signature beyond hipStream_t)
 // ---------------------------------------------------------------------------
-const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
-                          uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
+const char *launch_decode(const DecodeParams &p_in, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
+                          int xcd_bands, uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
   const bool quant = quantiser || has_alpha;  // the sRGB mode: arithmetic, no table
-  const size_t lds = quant ? 0 : p.table_unit_bytes;
+  const size_t lds = quant ? 0 : p_in.table_unit_bytes;
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
     const uint32_t by = quads_rows_per_block(block_threads, grid_x);
-    const dim3 grid(grid_x, (p.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
+    dim3 grid(grid_x, (p_in.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
     const dim3 block(block_threads, by, 1);
+    DecodeParams banded = p_in;
+    if (xcd_bands && frames >= 8 && frames % 8 == 0) {  // see the kernel: 8 contiguous bands of frames, one per XCD class
+      banded.xcd_bands = static_cast<uint32_t>(xcd_bands);
+      banded.frames_per_band = static_cast<uint32_t>(frames) / 8u;
+      grid = dim3(grid_x * 8u, grid.y, banded.frames_per_band);
+    }
+    const DecodeParams &p = banded;
     if (has_alpha) {
       hipLaunchKernelGGL((decode_nv12_quads<true, true, true>), grid, block, lds, stream, p);
       return "decode_nv12_quads<alpha>";
@@ -342,6 +360,7 @@ const char *launch_decode(const DecodeParams &p, int frames, int variant, bool h
     return "decode_nv12_quads";
   }
   // grid_x = workgroups per frame, grid-strided over row pairs
+  const DecodeParams &p = p_in;
   const dim3 grid(grid_x, static_cast<uint32_t>(frames), 1);
   const dim3 block(kBlockThreads, 1, 1);
   if (has_alpha) {

@@ -55,6 +55,7 @@ struct bt709hip_decoder {
   int half_rep = -1;        // BT709HIP_OPT_HALF_KERNEL: persistent conflict-free rescale kernel: -1 = when the launch is large enough, 0 never, 1 always
   int half_workgroups = 0;  // BT709HIP_OPT_HALF_WORKGROUPS: 0 = one per compute unit
   int half_lds_kb = 0;      // BT709HIP_OPT_HALF_LDS_KB: 0 = all 160
+  int xcd_bands = 1;        // BT709HIP_OPT_XCD_BANDS: XCD-aware work map of the batched 1:1 kernels (frames a multiple of 8)
   std::mutex setup_mutex;
   bool ready = false;
   // device copies (transfer_tables.h)
@@ -632,6 +633,7 @@ int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value) {
     case BT709HIP_OPT_HALF_KERNEL: dec->half_rep = clamp_int(value, -1, 1); return BT709HIP_OK;
     case BT709HIP_OPT_HALF_WORKGROUPS: dec->half_workgroups = clamp_int(value, 0, 1 << 20); return BT709HIP_OK;
     case BT709HIP_OPT_HALF_LDS_KB: dec->half_lds_kb = clamp_int(value, 0, 160); return BT709HIP_OK;
+    case BT709HIP_OPT_XCD_BANDS: dec->xcd_bands = clamp_int(value, 0, 2); return BT709HIP_OK;
     default: return BT709HIP_ERR_INVALID_ARG;
   }
 }
@@ -643,6 +645,7 @@ int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *va
     case BT709HIP_OPT_HALF_KERNEL: *value = dec->half_rep; return BT709HIP_OK;
     case BT709HIP_OPT_HALF_WORKGROUPS: *value = dec->half_workgroups; return BT709HIP_OK;
     case BT709HIP_OPT_HALF_LDS_KB: *value = dec->half_lds_kb; return BT709HIP_OK;
+    case BT709HIP_OPT_XCD_BANDS: *value = dec->xcd_bands; return BT709HIP_OK;
     default: return BT709HIP_ERR_INVALID_ARG;
   }
 }
@@ -806,7 +809,7 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
   const uint32_t gx = fast ? quads_tiles(p.width) : grid_x_for(dec->ctx, p.height / 2, count);
   const uint32_t threads = quads_block_threads(p.width);
   tl_kernel_name = launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
-                                 dec->gamma == kGammaSRGB, dec->nontemporal, gx, threads, s);
+                                 dec->gamma == kGammaSRGB, dec->nontemporal, dec->xcd_bands, gx, threads, s);
   return finish_launch(s, wait_until_completed);
 }
 

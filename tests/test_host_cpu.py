@@ -412,8 +412,8 @@ def test_bench_two_ranks_gloo_dry_run():
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
     assert res["repeats"] >= 5 and res["value_min"] <= res["value"] <= res["value_max"]
     assert res["unit"] == "Gpixel/s" and res["roofline"]["bound"] == "hbm"
-    # 2 ranks x 5 steps x 64 x 4K pixels over >= 5 x 2 ms (dry run sleeps 2 ms per step)
-    px = 2 * 5 * 64 * 3840 * 2160
+    # 2 ranks x 5 steps x 256 x 4K pixels over >= 5 x 2 ms (dry run sleeps 2 ms per step)
+    px = 2 * 5 * 256 * 3840 * 2160
     assert res["value"] <= px / (5 * 0.002) / 1e9
     assert abs(res["value"] - px / (res["ms_per_step"] * 5e-3) / 1e9) / res["value"] < 1e-3
     assert "cpu_baseline" not in res
@@ -444,11 +444,13 @@ def test_bench_two_ranks_gloo_dry_run_batch8():
 def test_bench_geometry():
     import bench
     g = bench.geometry("4k", 0, 65535)
-    assert (g["ring"], g["per_launch"], g["launches"]) == (64, 32, 2)
+    assert (g["ring"], g["per_launch"], g["launches"]) == (256, 256, 1)  # one launch over the whole ring (XCD-aware work map)
     g = bench.geometry("1080p", 0, 65535)
-    assert (g["ring"], g["per_launch"], g["launches"]) == (256, 128, 2)
+    assert (g["ring"], g["per_launch"], g["launches"]) == (1024, 1024, 1)
     g = bench.geometry("4k", 0, 65535, 64)
-    assert (g["ring"], g["per_launch"], g["launches"]) == (64, 64, 1)
+    assert (g["ring"], g["per_launch"], g["launches"]) == (256, 64, 4)
+    g = bench.geometry("4k", 64, 65535, 32)
+    assert (g["ring"], g["per_launch"], g["launches"]) == (64, 32, 2)    # rounds 1-2's shape
     assert g["bytes_per_frame"] == 45_619_200
     g = bench.geometry("1080p", 0, 32)
     assert g["bytes_per_frame"] == 11_404_800

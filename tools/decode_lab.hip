@@ -166,7 +166,7 @@ int main(int argc, char **argv) {
     int t = ((per_tile + kQuadsPerLane - 1) / kQuadsPerLane + 63) / 64 * 64;
     if (t > kMaxBlockThreads) continue;
     add("quads<nt> qpl=" + std::to_string(kQuadsPerLane) + " tiles=" + std::to_string(tiles) + " threads=" + std::to_string(t),
-        [&r, s, t, tiles](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, false, true, tiles, t, (r.s2 && (l & 1)) ? r.s2 : s); });
+        [&r, s, t, tiles](int l) { launch_decode(r.params[l], r.batch, kVariantQuads, false, false, true, std::getenv("LAB_XCD_BANDS") ? std::atoi(std::getenv("LAB_XCD_BANDS")) : 0, tiles, t, (r.s2 && (l & 1)) ? r.s2 : s); });
   }
 
   // warm the clocks

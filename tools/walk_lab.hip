@@ -279,7 +279,7 @@ int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const uint32_t cus = uint32_t(props.multiProcessorCount);
-  auto short_lived = [&](int l, uint8_t *out) { launch_decode(params(l, out), batch, kVariantQuads, false, false, true, quads_tiles(W), quads_block_threads(W), s); };
+  auto short_lived = [&](int l, uint8_t *out) { launch_decode(params(l, out), batch, kVariantQuads, false, false, true, 0, quads_tiles(W), quads_block_threads(W), s); };
   auto walk = [&](int l, uint8_t *out) { launch_decode_walk(params(l, out), batch, true, per_cu * cus, lanes, cus, stagger, s); };
   // parity of the walk against the shipped kernel, launch 0
   short_lived(0, d_ref);
