@@ -39,6 +39,7 @@ OPT_XCD_BANDS = 5
 CTX_OPT_GRID_MULT = 1
 CTX_OPT_ENCODE_ROW_PAIRS = 2
 CTX_OPT_ENCODE_THREADS = 3
+CTX_OPT_XCD_BANDS = 4
 
 
 class DeviceInfo(C.Structure):  # bt709hip_device_info

@@ -191,10 +191,13 @@ __device__ __forceinline__ EncodeFrame encode_frame(const EncodeParams &p, uint3
 __global__ void __launch_bounds__(kMaxBlockThreads)
 encode_bgra_nv12(const EncodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const EncodeFrame f = encode_frame(p, blockIdx.z);
+  // XCD-aware work map (p.xcd_bands; launches of a multiple of 8 pictures): grid.x = 8 x tiles, x & 7 = the workgroup's place in
+  // the round-robin over the XCDs, which owns a contiguous band of the launch's pictures (bt709_kernels.hip decode_nv12_quads)
+  const uint32_t tile = p.xcd_bands ? blockIdx.x >> 3 : blockIdx.x;
+  const EncodeFrame f = encode_frame(p, p.xcd_bands ? (blockIdx.x & 7u) * p.frames_per_band + blockIdx.z : blockIdx.z);
   const uint32_t quads = p.width >> 2;
   const uint32_t row_pairs = p.height >> 1;
-  const uint32_t q_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t q_raw = tile * blockDim.x + threadIdx.x;
   const uint32_t q = min(q_raw, quads - 1);
   const uint32_t rp0 = blockIdx.y * p.row_pairs_per_block;
   const uint32_t rp_end = min(rp0 + p.row_pairs_per_block, row_pairs);
@@ -272,7 +275,7 @@ encode_bgra_nv12_blocks(const EncodeParams p) {
   }
 }
 
-const char *launch_encode(const EncodeParams &params, int frames, bool fast, hipStream_t stream) {
+const char *launch_encode(const EncodeParams &params, int frames, bool fast, bool xcd_bands, hipStream_t stream) {
   EncodeParams p = params;
   if (p.row_pairs_per_block == 0) p.row_pairs_per_block = encode_row_pairs_per_block(p.width, p.height, frames);
   const size_t lds = 256 * sizeof(EncodeByteEntry) + p.from_linear_bytes;
@@ -288,8 +291,13 @@ const char *launch_encode(const EncodeParams &params, int frames, bool fast, hip
       if (threads < 64) threads = 64;
     }
     if (threads > static_cast<uint32_t>(kMaxBlockThreads)) threads = kMaxBlockThreads;
-    const dim3 grid((quads + threads - 1) / threads,
-                    (p.height / 2 + p.row_pairs_per_block - 1) / p.row_pairs_per_block, frames);
+    dim3 grid((quads + threads - 1) / threads,
+              (p.height / 2 + p.row_pairs_per_block - 1) / p.row_pairs_per_block, frames);
+    if (xcd_bands && frames >= kXcdBandMinFrames && frames % 8 == 0) {
+      p.xcd_bands = 1;
+      p.frames_per_band = static_cast<uint32_t>(frames) / 8u;
+      grid = dim3(grid.x * 8u, grid.y, p.frames_per_band);
+    }
     hipLaunchKernelGGL(encode_bgra_nv12, grid, dim3(threads), lds, stream, p);
     return "encode_bgra_nv12";
   }

@@ -20,6 +20,10 @@ constexpr int kBlockThreads = 256;     // general-path workgroup: 4 waves of 64
 constexpr int kMaxBlockThreads = BT709_MAX_BLOCK_THREADS;  // fast-path workgroup is sized per frame width, up to 8 waves
 constexpr int kQuadsPerLane = BT709_QUADS_PER_LANE;        // 4x2-pixel quads a fast-path lane owns per row pair
 constexpr int kMaxBatch = 32;          // == BT709HIP_MAX_BATCH: frames in the kernarg table
+// XCD-aware work map (bt709_kernels.hip decode_nv12_quads): used for launches of a multiple of 8 frames from this many on.
+// Measured (round 3, same call, plain vs banded): decode 32 frames 0.756 / 0.741-0.761, 64 0.741 / 0.745-0.760, 128 0.72 / 0.77,
+// 256 0.70 / 0.76-0.81; encoder 32 pictures 0.70 / 0.67, 256 0.69 / 0.73: a band needs ~8 frames to pay.
+constexpr int kXcdBandMinFrames = 64;
 constexpr int kMaxUniformBatch = 65535;  // evenly spaced frames per launch (grid.z limit)
 
 enum KernelVariant : int {
@@ -94,7 +98,7 @@ struct HalfParams {
   uint32_t wide_store;           // 16-byte stores (target 16-byte aligned), else 8-byte
 };
 const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp, int frames, bool has_alpha,
-                                  uint32_t in_align, uint32_t out_align, uint32_t compute_units, hipStream_t stream);
+                                  uint32_t in_align, uint32_t out_align, uint32_t compute_units, bool xcd_bands, hipStream_t stream);
 hipError_t prepare_rgba16f_kernels();  // bt709_rgba16f.hip
 
 // Pass 2 alone (bt709_rescale.hip render_scaled): an intermediate surface -> a BGRA8 sRGB surface of any size.
@@ -136,8 +140,9 @@ struct EncodeParams {
   uint32_t block_threads;        // fast-path workgroup size (one quad per lane); 0 = encode_block_threads(width)
   uint32_t width, height;
   uint32_t bgra_stride, y_stride, cbcr_stride;
+  uint32_t xcd_bands, frames_per_band;  // XCD-aware work map, as in DecodeParams (filled by launch_encode)
 };
-const char *launch_encode(const EncodeParams &p, int frames, bool fast, hipStream_t stream);
+const char *launch_encode(const EncodeParams &p, int frames, bool fast, bool xcd_bands, hipStream_t stream);
 hipError_t prepare_encode_kernels();
 // Encoder fast-path geometry, measured on 4K (tools/encode_shapes.sh sweeps):
 // one quad per lane, equal tiles of <= 320 lanes rounded up to whole waves (3840 -> 3 x 320,

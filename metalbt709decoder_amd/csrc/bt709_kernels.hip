@@ -337,7 +337,7 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
     dim3 grid(grid_x, (p_in.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
     const dim3 block(block_threads, by, 1);
     DecodeParams banded = p_in;
-    if (xcd_bands && frames >= 8 && frames % 8 == 0) {  // see the kernel: 8 contiguous bands of frames, one per XCD class
+    if (xcd_bands && frames >= kXcdBandMinFrames && frames % 8 == 0) {  // see the kernel: 8 contiguous bands of frames, one per XCD class
       banded.xcd_bands = static_cast<uint32_t>(xcd_bands);
       banded.frames_per_band = static_cast<uint32_t>(frames) / 8u;
       grid = dim3(grid_x * 8u, grid.y, banded.frames_per_band);

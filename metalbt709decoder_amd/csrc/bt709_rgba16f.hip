@@ -91,9 +91,11 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
   t.h_below = hp.h_min - 1u;
   t.table_off = lds_address(lds_raw) + 4u - (hp.h_min << 2);
 
-  const FramePlanes f = frame_planes(p, blockIdx.z);
+  // XCD-aware work map (p.xcd_bands, launches of a multiple of 8 frames): see bt709_kernels.hip decode_nv12_quads
+  const uint32_t tile = p.xcd_bands ? blockIdx.x >> 3 : blockIdx.x;
+  const FramePlanes f = frame_planes(p, p.xcd_bands ? (blockIdx.x & 7u) * p.frames_per_band + blockIdx.z : blockIdx.z);
   const uint32_t blocks = p.width >> 1, row_pairs = p.height >> 1;
-  const uint32_t bx = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t bx = tile * blockDim.x + threadIdx.x;
   if (bx >= blocks) return;
   const uint32_t rp0 = blockIdx.y * hp.row_pairs_per_block, rp1 = min(rp0 + hp.row_pairs_per_block, row_pairs);
   const uint32_t opaque = 0x3c00u << 16;  // A = 1.0
@@ -143,9 +145,10 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
   }
 }
 
-const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp_in, int frames, bool has_alpha,
-                                  uint32_t in_align, uint32_t out_align, uint32_t compute_units, hipStream_t stream) {
+const char *launch_decode_rgba16f(const DecodeParams &p_in, const HalfParams &hp_in, int frames, bool has_alpha,
+                                  uint32_t in_align, uint32_t out_align, uint32_t compute_units, bool xcd_bands, hipStream_t stream) {
   HalfParams hp = hp_in;
+  DecodeParams p = p_in;
   const uint32_t blocks = p.width / 2, row_pairs = p.height / 2;
   uint32_t threads = (blocks + 63) / 64 * 64;
   if (threads > static_cast<uint32_t>(kMaxBlockThreads)) threads = kMaxBlockThreads;
@@ -160,7 +163,12 @@ const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp_in
   rpb = rpb < 1 ? 1 : (rpb > 16 ? 16 : rpb);
   hp.row_pairs_per_block = rpb;
   hp.wide_store = out_align >= 16 ? 1 : 0;
-  const dim3 grid(tiles, (row_pairs + rpb - 1) / rpb, static_cast<uint32_t>(frames));
+  dim3 grid(tiles, (row_pairs + rpb - 1) / rpb, static_cast<uint32_t>(frames));
+  if (xcd_bands && frames >= kXcdBandMinFrames && frames % 8 == 0) {
+    p.xcd_bands = 1;
+    p.frames_per_band = static_cast<uint32_t>(frames) / 8u;
+    grid = dim3(tiles * 8u, grid.y, p.frames_per_band);
+  }
   const dim3 block(threads);
   const bool pairs = in_align >= 2;
   const int curve = hp.table_bytes == 0 ? 0 : ((hp.pre_add == 0.0f && hp.pre_scale == 1.0f) ? 1 : 2);

@@ -39,6 +39,7 @@ struct bt709hip_context {
   int grid_mult = 2;    // BT709HIP_CTX_OPT_GRID_MULT
   int grid_blocks = 0;  // workgroups a general-path launch aims for (all frames together)
   int encode_row_pairs = 0, encode_threads = 0;  // BT709HIP_CTX_OPT_ENCODE_*: 0 = sized per launch
+  int xcd_bands = 1;                             // BT709HIP_CTX_OPT_XCD_BANDS: XCD-aware work map of batched encoder launches
   std::mutex encoder_mutex;
   EncoderTables encoders[3][3];  // [input gamma][output gamma], built on first use
   // bt709hip_render_scaled (pass 2 alone): built on first use under encoder_mutex
@@ -364,6 +365,9 @@ int bt709hip_context_set_option(bt709hip_context *ctx, int option, int value) {
       return BT709HIP_OK;
     case BT709HIP_CTX_OPT_ENCODE_THREADS:
       ctx->encode_threads = clamp_int(value, 0, 1024) / 64 * 64;
+      return BT709HIP_OK;
+    case BT709HIP_CTX_OPT_XCD_BANDS:
+      ctx->xcd_bands = value != 0;
       return BT709HIP_OK;
     default:
       return BT709HIP_ERR_INVALID_ARG;
@@ -800,7 +804,7 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
   if (info.format == BT709HIP_FORMAT_RGBA16F) {  // the reference's pre-10.14 intermediate: linear-light halves
     if (int rc = ensure_half_table(dec, stream)) return rc;
     tl_kernel_name = launch_decode_rgba16f(p, dec->half, count, dec->has_alpha != 0, info.in_align, info.out_align,
-                                           static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), s);
+                                           static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), dec->xcd_bands != 0, s);
     return finish_launch(s, wait_until_completed);
   }
   // Fast path: one short-lived workgroup per tile of a row pair, dispatched in address order
@@ -1369,7 +1373,7 @@ int bt709hip_encode_batch(bt709hip_context *ctx, int count, const bt709hip_surfa
   p.bgra_stride = static_cast<uint32_t>(in0.stride);
   p.y_stride = static_cast<uint32_t>(out0.y_stride);
   p.cbcr_stride = static_cast<uint32_t>(out0.cbcr_stride);
-  tl_kernel_name = launch_encode(p, count, fast, s);
+  tl_kernel_name = launch_encode(p, count, fast, ctx->xcd_bands != 0, s);
   HIP_TRY(hipGetLastError());
   if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;

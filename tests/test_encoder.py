@@ -222,6 +222,25 @@ def test_gpu_encoder_batch_matches_single(gh, oracle):
         want = oracle.encode_nv12(p & 0xFFFFFF, w, h, 1, 0)
         got = b.download_planes()
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # 64 pictures (a multiple of 8, at the threshold): the XCD-aware work map; same bytes as the plain order
+    for bands in (1, 0):
+        _capi.check(ctx.lib.bt709hip_context_set_option(ctx.handle, _capi.CTX_OPT_XCD_BANDS, bands))
+        n64 = 64
+        s_in, s_out = DeviceBuffer(ctx, n64 * in_pitch), DeviceBuffer(ctx, n64 * out_pitch)
+        pics64 = [rng.integers(0, 1 << 32, w * h, dtype=np.uint32) for _ in range(n64)]
+        t64, b64 = [], []
+        for i, p in enumerate(pics64):
+            t = mb.BGRATexture(ctx, w, h, w * 4, ptr=s_in.ptr + i * in_pitch)
+            ctx.fillBGRATexture(t, p)
+            t64.append(t)
+            base = s_out.ptr + i * out_pitch
+            b64.append(mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h)))
+        assert mb.BGRAToBT709Converter.convertIntoCoreVideoBuffers(t64, b64, 1, 0)
+        for p, b in zip(pics64, b64):
+            want = oracle.encode_nv12(p & 0xFFFFFF, w, h, 1, 0)
+            got = b.download_planes()
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), bands
+    _capi.check(ctx.lib.bt709hip_context_set_option(ctx.handle, _capi.CTX_OPT_XCD_BANDS, 1))
     # shuffled: not evenly spaced any more -> the table limit applies; mixed sizes are refused
     order = list(range(n))
     order[2], order[5] = order[5], order[2]

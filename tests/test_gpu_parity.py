@@ -347,35 +347,47 @@ def test_frame_sharder_four_lanes_on_one_device(gh, oracle):
     sh.release()
 
 
-@pytest.mark.parametrize("case", [((3840, 8), 8, False), ((7680, 4), 16, False), ((1920, 12), 24, False), ((328, 10), 8, False),
-                                  ((640, 6), 16, True)])
+@pytest.mark.parametrize("case", [((3840, 8), 64, False), ((7680, 4), 72, False), ((1920, 12), 80, False), ((328, 10), 64, False),
+                                  ((640, 6), 64, True)])
 def test_xcd_band_work_map(gh, oracle, case):
-    """Launches of a multiple of 8 frames use the XCD-aware work map (grid.x = 8 x tiles; each XCD class owns a contiguous
-    band of the launch's frames): every frame distinct, one / two tiles per row, stacked row pairs, an alpha decoder;
+    """Launches of a multiple of 8 frames, 64 or more, use the XCD-aware work map (grid.x = 8 x tiles; each XCD class owns a
+    contiguous band of the launch's frames; the frames sit evenly spaced in one slab, as a ring does): every frame distinct, one / two tiles per row, stacked row pairs, an alpha decoder;
     same bytes as the oracle and as the plain map (BT709HIP_OPT_XCD_BANDS = 0), nothing written outside the rows."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
     (w, h), n, with_alpha = case
     ctx = gh.context()
     gamma = mb.MetalBT709GammaSRGB if with_alpha else mb.MetalBT709GammaApple
     frames = [gh.random_nv12(w, h, seed=7000 + 13 * i + w) for i in range(n)]
     alphas = [np.random.default_rng(i).integers(0, 256, (h, w), dtype=np.uint8) for i in range(n)] if with_alpha else None
+    stride = w * 4 + 16
+    in_pitch, a_pitch, out_pitch = (w * h * 3 // 2 + 255) // 256 * 256, (w * h + 255) // 256 * 256, stride * h
+    slab_in, slab_a, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * a_pitch), DeviceBuffer(ctx, n * out_pitch)
+    bufs, abufs, texs = [], [], []
+    for i, (y, c) in enumerate(frames):
+        base = slab_in.ptr + i * in_pitch
+        b = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h))
+        b.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2)
+        b.setAttachment("TransferFunction", gh.TRANSFER_FOR_GAMMA[gamma])
+        b.upload_planes(y, c)
+        bufs.append(b)
+        if with_alpha:
+            ab = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(slab_a.ptr + i * a_pitch, base + w * h))
+            ab.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2)
+            ab.setAttachment("TransferFunction", mb.kCVImageBufferTransferFunction_Linear)
+            ctx._upload(slab_a.ptr + i * a_pitch, w, alphas[i], None)
+            ctx._sync(None)
+            abufs.append(ab)
+        texs.append(mb.BGRATexture(ctx, w, h, stride, ptr=slab_out.ptr + i * out_pitch))
     outs = {}
     for banded in (1, 0):
         dec = gh.make_decoder(gamma, has_alpha=with_alpha, options={_capi.OPT_XCD_BANDS: banded})
-        bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
-        abufs = [gh.make_alpha_buffer(a) for a in alphas] if with_alpha else None
-        stride = w * 4 + 16
-        texs = [ctx.makeBGRATexture((w, h), stride=stride) for _ in range(n)]
-        for t in texs:
-            _capi.check(ctx.lib.bt709hip_memset(ctx.handle, t.ptr, 0xC3, stride * h, None))
-        assert dec.decodeBT709Batch(bufs, texs, alphaPixelBuffers=abufs, waitUntilCompleted=True), dec.lastStatus
-        got = []
-        for t in texs:
-            raw = np.empty((h, stride), np.uint8)
-            _capi.check(ctx.lib.bt709hip_download(ctx.handle, raw.ctypes.data, stride, t.ptr, stride, stride, h, None))
-            ctx._sync(None)
-            assert (raw[:, w * 4:] == 0xC3).all()
-            got.append(raw[:, :w * 4].copy())
-        outs[banded] = got
+        _capi.check(ctx.lib.bt709hip_memset(ctx.handle, slab_out.ptr, 0xC3, n * out_pitch, None))
+        assert dec.decodeBT709Batch(bufs, texs, alphaPixelBuffers=abufs or None, waitUntilCompleted=True), dec.lastStatus
+        raw = np.empty((n * h, stride), np.uint8)
+        _capi.check(ctx.lib.bt709hip_download(ctx.handle, raw.ctypes.data, stride, slab_out.ptr, stride, stride, n * h, None))
+        ctx._sync(None)
+        assert (raw[:, w * 4:] == 0xC3).all()
+        outs[banded] = raw[:, :w * 4].reshape(n, h, w * 4).copy()
     for i, (y, c) in enumerate(frames):
         want = oracle.decode_nv12(gamma, y, c, alpha=alphas[i] if with_alpha else None)
         assert np.array_equal(outs[1][i], want), i

@@ -182,6 +182,32 @@ def test_gpu_rgba16f_batch_4k(gh, oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_rgba16f_xcd_band_work_map(gh, oracle):
+    """72 evenly spaced frames in one launch (a multiple of 8, past the threshold): the XCD-aware work map of the
+    RGBA16Float kernel against the plain order and the oracle."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    n, w, h = 72, 128, 8
+    in_pitch, out_pitch = w * h * 3 // 2, w * h * 8
+    slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
+    frames = [_frame(w, h, 500 + i) for i in range(n)]
+    bufs, texs = [], []
+    for i, (y, c) in enumerate(frames):
+        base = slab_in.ptr + i * in_pitch
+        b = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h))
+        mb.BGRAToBT709Converter.setBT709Attributes(b)
+        b.upload_planes(y, c)
+        bufs.append(b)
+        texs.append(mb.BGRATexture(ctx, w, h, w * 8, ptr=slab_out.ptr + i * out_pitch, pixelFormat=mb.MTLPixelFormatRGBA16Float))
+    for bands in (1, 0):
+        dec = gh.make_decoder(mb.MetalBT709GammaApple, options={_capi.OPT_XCD_BANDS: bands})
+        _capi.check(ctx.lib.bt709hip_memset(ctx.handle, slab_out.ptr, 0, n * out_pitch, None))
+        assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True), dec.lastStatus
+        for (y, c), t in zip(frames, texs):
+            assert np.array_equal(ctx.getBGRATexturePixels(t).view(np.uint16), oracle.decode_nv12_rgba16f(0, y, c).view(np.uint16)), bands
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(0, (64, 32), (40, 20)), (1, (30, 18), (64, 40)), (3, (1920, 64), (1280, 43)),
                                   (2, (50, 22), (1, 1)), (0, (48, 24), (24, 12))])
 def test_gpu_two_passes_equal_fused(gh, oracle, case):

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--threads", type=int, default=0, help="bt709hip_context_option ENCODE_THREADS (0 = from the width)")
     ap.add_argument("--row-pairs", type=int, default=0, help="bt709hip_context_option ENCODE_ROW_PAIRS (0 = sized per launch)")
+    ap.add_argument("--xcd-bands", type=int, default=1, help="bt709hip_context_option XCD_BANDS")
     ap.add_argument("--frames-per-launch", type=int, default=1,
                     help="> 1: bt709hip_encode_batch over a ring carved from one allocation")
     ap.add_argument("--library", default=None, help="a variant build of libbt709hip.so (python -m metalbt709decoder_amd.build --variant)")
@@ -45,6 +46,7 @@ def main():
     from metalbt709decoder_amd import _capi
     _capi.check(lib.bt709hip_context_set_option(h, _capi.CTX_OPT_ENCODE_THREADS, args.threads))
     _capi.check(lib.bt709hip_context_set_option(h, _capi.CTX_OPT_ENCODE_ROW_PAIRS, args.row_pairs))
+    _capi.check(lib.bt709hip_context_set_option(h, _capi.CTX_OPT_XCD_BANDS, args.xcd_bands))
     rng = np.random.default_rng(0x709)
     from metalbt709decoder_amd.decoder import DeviceBuffer
     fpl = max(1, args.frames_per_launch)
