@@ -420,6 +420,13 @@ int bt709hip_deinterleave_cbcr(bt709hip_context *ctx, const void *cbcr, size_t c
  * non-temporal loads and stores, one launch: the bandwidth a plain copy reaches on this device, for
  * benchmarks that want to report a kernel against the same box's copy rate (no reference twin). */
 int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_t bytes, void *stream);
+/* Placement-aware allocation for streaming slabs (frame rings, pools).  On MI355X the rate at which a slab streams depends on
+ * where it landed: allocations made one after the other by ONE process stream at 5.7-6.5 TB/s, each keeping its rate (the same
+ * decode launch 0.74-0.81 of the roofline; tools/placement_hunt.py).  Allocates `tries` candidates of `bytes` (all alive until
+ * the choice is made), times the streaming copy above over each (lower half onto upper half), keeps the fastest and frees the
+ * rest.  rates_GBps (optional, `tries` floats) receives the probe rates, *chosen (optional) the index kept.  tries = 1 is
+ * bt709hip_malloc.  No reference twin (unified memory has no placement to choose). */
+int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, void **dptr, float *rates_GBps, int *chosen);
 
 const char *bt709hip_strerror(int status);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none). */

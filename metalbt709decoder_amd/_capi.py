@@ -142,6 +142,7 @@ SYMBOLS = {
     "bt709hip_interleave_cbcr": (_I, [_P, _P, _Z, _P, _Z, _P, _Z, _I, _I, _P, _I]),
     "bt709hip_deinterleave_cbcr": (_I, [_P, _P, _Z, _P, _Z, _P, _Z, _I, _I, _P, _I]),
     "bt709hip_copy_probe": (_I, [_P, _P, _P, _Z, _P]),
+    "bt709hip_malloc_streaming": (_I, [_P, _Z, _I, c_void_pp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bt709hip_strerror": (C.c_char_p, [_I]),
     "bt709hip_last_hip_error": (_I, []),
     "bt709hip_last_hip_error_string": (C.c_char_p, []),

@@ -1449,6 +1449,53 @@ int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_
   return BT709HIP_OK;
 }
 
+int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, void **dptr, float *rates_GBps, int *chosen) {
+  if (dptr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *dptr = nullptr;
+  if (chosen) *chosen = -1;
+  if (bytes == 0 || tries < 1 || tries > 32) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bind(ctx)) return rc;
+  std::vector<void *> cand;
+  for (int i = 0; i < tries; ++i) {  // every candidate stays alive until the choice is made: they land in different places
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      break;  // out of memory: choose among what there is
+    }
+    cand.push_back(p);
+  }
+  if (cand.empty()) return hip_fail(hipErrorOutOfMemory);
+  int best = 0;
+  float best_rate = -1.0f;
+  const size_t half = (bytes / 2) & ~static_cast<size_t>(4095);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t s = ctx->default_stream;
+  if (cand.size() > 1 && half >= (1u << 20) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    for (size_t i = 0; i < cand.size(); ++i) {
+      uint8_t *p = static_cast<uint8_t *>(cand[i]);
+      for (int w = 0; w < 3; ++w) launch_copy_probe(p + half, p, half, s);  // warm (clocks, page tables)
+      (void)hipEventRecord(e0, s);
+      for (int r = 0; r < 6; ++r) launch_copy_probe(p + half, p, half, s);
+      (void)hipEventRecord(e1, s);
+      float ms = 0.0f;
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.0f) ms = 1e9f;
+      const float rate = static_cast<float>(6.0 * 2.0 * static_cast<double>(half) / (ms * 1e-3) / 1e9);
+      if (rates_GBps) rates_GBps[i] = rate;
+      if (rate > best_rate) best_rate = rate, best = static_cast<int>(i);
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  for (size_t i = 0; i < cand.size(); ++i)
+    if (static_cast<int>(i) != best) (void)hipFree(cand[i]);
+  if (rates_GBps)
+    for (int i = static_cast<int>(cand.size()); i < tries; ++i) rates_GBps[i] = 0.0f;
+  (void)hipGetLastError();
+  *dptr = cand[static_cast<size_t>(best)];
+  if (chosen) *chosen = best;
+  return BT709HIP_OK;
+}
+
 const char *bt709hip_strerror(int status) {
   switch (status) {
     case BT709HIP_OK: return "ok";

@@ -424,6 +424,25 @@ def test_evenly_spaced_batch_beyond_table_limit(gh, oracle):
     assert dec.lastStatus == _capi.ERR_UNSUPPORTED
 
 
+def test_malloc_streaming_placement_hunt(gh):
+    """bt709hip_malloc_streaming: several candidates, the fastest-streaming one kept; the block is usable and freeable."""
+    ctx = gh.context()
+    lib, h = ctx.lib, ctx.handle
+    p, rates, chosen = C.c_void_p(), (C.c_float * 3)(), C.c_int(-1)
+    nbytes = 64 << 20
+    assert lib.bt709hip_malloc_streaming(h, nbytes, 3, C.byref(p), rates, C.byref(chosen)) == _capi.OK
+    assert p.value and 0 <= chosen.value < 3 and all(r > 100.0 for r in rates) and rates[chosen.value] == max(rates)
+    _capi.check(lib.bt709hip_memset(h, p, 0x11, nbytes, None))
+    back = np.empty((1, 4096), np.uint8)
+    _capi.check(lib.bt709hip_download(h, back.ctypes.data, 4096, p.value + nbytes - 4096, 4096, 4096, 1, None))
+    ctx._sync(None)
+    assert (back == 0x11).all()
+    _capi.check(lib.bt709hip_free(h, p))
+    assert lib.bt709hip_malloc_streaming(h, 1 << 20, 0, C.byref(p), None, None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_malloc_streaming(h, 4096, 1, C.byref(p), None, None) == _capi.OK and p.value  # one try: plain malloc
+    _capi.check(lib.bt709hip_free(h, p))
+
+
 def test_one_stream_per_in_flight_frame(gh, oracle):
     """North-star shape: each in-flight frame on its own HIP stream, no wait until the end."""
     ctx = gh.context()

@@ -15,6 +15,8 @@ python bench.py --workload 4k-batch8 --share 1 --streams 2 --no-cpu-baseline --s
 python bench.py --workload 4k-batch8 --share 1 --graph --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_graph.json 2>/dev/null
 { tools/ab_batch8.sh; echo "# two frames per step"; SHARE=2 STREAMS="1 2 3 4" tools/ab_batch8.sh; } > $O/batch8_streams.txt 2>&1
 tools/encode_single_shapes.sh "320 512" "1 3" > $O/encode_single_shapes.txt 2>&1
+tools/ab_bands.sh > $O/ab_bands.txt 2>&1
+python tools/placement_hunt.py 6 256 > $O/placement_hunt.txt 2>&1
 python tools/bench_encode.py --frames-per-launch 32 > $O/bench_encode.json 2>/dev/null
 python tools/bench_encode.py --frames-per-launch 1 > $O/bench_encode_single.json 2>/dev/null
 tools/bench_paths.sh > $O/bench_paths.txt 2>&1
