@@ -83,7 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=0,
                     help="4k-batch8 only: issue consecutive steps round-robin on this many HIP streams (one stream "
                          "per in-flight frame); 0 = auto (2: measured best for every share, profiles/r02_batch8_streams*.txt)")
-    ap.add_argument("--placement-tries", type=int, default=4,
+    ap.add_argument("--placement-tries", type=int, default=6,
                     help="allocate the ring this many times, time the step's launch on each (untimed set-up), keep the fastest, free the rest")
     ap.add_argument("--stream-priorities", default="", metavar="P1,P2,...",
                     help="4k-batch8: scheduling priority of the 2nd, 3rd, ... stream (0 normal, -1 higher, 1 lower); lab knob")
