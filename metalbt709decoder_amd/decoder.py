@@ -52,10 +52,19 @@ def _align_up(v, a):
 class DeviceBuffer:
     """hipMalloc'd bytes owned through the context."""
 
-    def __init__(self, ctx, nbytes):
+    def __init__(self, ctx, nbytes, placement_tries=1):
+        """placement_tries > 1: bt709hip_malloc_streaming -- that many candidates, the fastest-streaming one kept
+        (where a slab lands in HBM changes its streaming rate by a few percent on MI355X)."""
         self.ctx, self.nbytes = ctx, int(nbytes)
         p = C.c_void_p()
-        _capi.check(ctx.lib.bt709hip_malloc(ctx.handle, self.nbytes, C.byref(p)), "bt709hip_malloc")
+        self.placement = None
+        if placement_tries > 1:
+            rates, chosen = (C.c_float * placement_tries)(), C.c_int(-1)
+            _capi.check(ctx.lib.bt709hip_malloc_streaming(ctx.handle, self.nbytes, int(placement_tries), C.byref(p), rates,
+                                                          C.byref(chosen)), "bt709hip_malloc_streaming")
+            self.placement = {"probe_GBps": [round(r, 1) for r in rates], "chosen": chosen.value}
+        else:
+            _capi.check(ctx.lib.bt709hip_malloc(ctx.handle, self.nbytes, C.byref(p)), "bt709hip_malloc")
         self.ptr = p.value or 0
 
     def free(self):

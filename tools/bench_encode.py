@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="bt709hip_context_option ENCODE_THREADS (0 = from the width)")
     ap.add_argument("--row-pairs", type=int, default=0, help="bt709hip_context_option ENCODE_ROW_PAIRS (0 = sized per launch)")
     ap.add_argument("--xcd-bands", type=int, default=1, help="bt709hip_context_option XCD_BANDS")
+    ap.add_argument("--placement-tries", type=int, default=1, help="bt709hip_malloc_streaming candidates per slab")
     ap.add_argument("--frames-per-launch", type=int, default=1,
                     help="> 1: bt709hip_encode_batch over a ring carved from one allocation")
     ap.add_argument("--library", default=None, help="a variant build of libbt709hip.so (python -m metalbt709decoder_amd.build --variant)")
@@ -52,7 +53,8 @@ def main():
     fpl = max(1, args.frames_per_launch)
     args.ring = (args.ring + fpl - 1) // fpl * fpl
     in_pitch, out_pitch = W * H * 4, W * H * 3 // 2
-    slab_in, slab_out = DeviceBuffer(ctx, args.ring * in_pitch), DeviceBuffer(ctx, args.ring * out_pitch)
+    slab_in = DeviceBuffer(ctx, args.ring * in_pitch, args.placement_tries)
+    slab_out = DeviceBuffer(ctx, args.ring * out_pitch, args.placement_tries)
     texs, bufs = [], []
     for i in range(args.ring):
         t = mb.BGRATexture(ctx, W, H, W * 4, ptr=slab_in.ptr + i * in_pitch)
@@ -93,7 +95,8 @@ def main():
                       "us_per_frame": round(us, 3), "gpixel_per_s": round(W * H / us / 1e3, 1),
                       "algorithmic_GBps": round(bytes_per_frame / us / 1e3, 1),
                       "frac_of_8TBps": round(bytes_per_frame / us / 1e3 / 8000, 4),
-                      "kernel": lib.bt709hip_last_kernel_name().decode()}))
+                      "kernel": lib.bt709hip_last_kernel_name().decode(),
+                      "placement": [slab_in.placement, slab_out.placement]}))
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ python bench.py --workload 4k-batch8 --share 1 --graph --no-cpu-baseline --steps
 tools/encode_single_shapes.sh "320 512" "1 3" > $O/encode_single_shapes.txt 2>&1
 tools/ab_bands.sh > $O/ab_bands.txt 2>&1
 python tools/placement_hunt.py 6 256 > $O/placement_hunt.txt 2>&1
-python tools/bench_encode.py --frames-per-launch 32 > $O/bench_encode.json 2>/dev/null
+{ python tools/bench_encode.py --ring 256 --frames-per-launch 256 --steps 10 --placement-tries 5; python tools/bench_encode.py --frames-per-launch 32; } > $O/bench_encode.json 2>/dev/null
 python tools/bench_encode.py --frames-per-launch 1 > $O/bench_encode_single.json 2>/dev/null
 tools/bench_paths.sh > $O/bench_paths.txt 2>&1
 python tools/stream_bench.py > $O/stream_bench.txt 2>&1
