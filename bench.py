@@ -216,47 +216,58 @@ class GpuRunner:
             self.surfs[i] = self.Surface(d_out.value + i * self.out_stride, g["OW"] * 4, g["OW"], g["OH"])
 
     def place_ring(self, tries, gamma):
-        """Where a slab lands in HBM decides how fast it streams: the same launch runs at 0.74-0.81 of the roofline on
-        different allocations made by ONE process, each allocation keeping its rate (tools/placement_hunt.py; the same-run
-        copy moves with it: 5.7-6.4 TB/s).  Untimed set-up: allocate the ring `tries` times (all candidates alive, so they
-        land in different places), time the step's own launches on each -- the input is whatever the memory holds, any
-        bytes decode --, keep the fastest, free the rest.  The probe rates are reported in config.placement."""
+        """Where a slab lands in HBM decides how fast it streams: the same launch runs at 0.74-0.82 of the roofline on
+        different allocations made by ONE process, each allocation keeping its rate (tools/placement_hunt.py).  The output
+        slab carries most of it, the input slab about a percent, and the pairing matters (tools/placement_cross.py: 5 x 5
+        slabs of one process, 0.74-0.825).  Untimed set-up: allocate `tries` input and `tries` output slabs (all alive, so
+        they land in different places), time the step's own launches on pairings of them -- the input is whatever the memory
+        holds, any bytes decode --: every output slab under input 0, then every input slab under the best output, then the
+        outputs again under the best input; keep the fastest pairing, free the rest.  Reported in config.placement."""
         lib, h, g = self.lib, self.h, self.g
-        cands = []
-        for _ in range(tries):
-            d_in, d_out = C.c_void_p(), C.c_void_p()
-            rc = lib.bt709hip_malloc(h, self.in_stride * g["ring"], C.byref(d_in))
-            if rc == 0:
-                rc = lib.bt709hip_malloc(h, self.out_stride * g["ring"], C.byref(d_out))
-            if rc != 0:  # out of memory: hunt among what we have
-                if d_in.value:
-                    lib.bt709hip_free(h, d_in)
-                break
-            cands.append((d_in, d_out))
-        if not cands:
-            raise self._capi.Bt709Error(rc, "ring allocation")
-        rates = []
-        if len(cands) > 1:
-            for d_in, d_out in cands:
-                self.bind_ring(d_in, d_out, gamma)
-                t_end = time.perf_counter() + 0.15
-                while time.perf_counter() < t_end:
-                    self.launch(0, g["per_launch"])
-                    self.sync()
-                reps = max(3, int(3 * 64 / g["per_launch"]))
-                self.mark(0)
-                for _ in range(reps):
-                    self.launch(0, g["per_launch"])
-                self.mark(1)
+
+        def slabs(nbytes):
+            got = []
+            for _ in range(tries):
+                d = C.c_void_p()
+                if lib.bt709hip_malloc(h, nbytes, C.byref(d)) != 0:  # out of memory: hunt among what we have
+                    break
+                got.append(d)
+            return got
+        ins, outs = slabs(self.in_stride * g["ring"]), slabs(self.out_stride * g["ring"])
+        if not ins or not outs:
+            raise self._capi.Bt709Error(self._capi.ERR_HIP, "ring allocation")
+        probed = {}
+
+        def probe(i, o):
+            if (i, o) in probed:
+                return probed[(i, o)]
+            self.bind_ring(ins[i], outs[o], gamma)
+            t_end = time.perf_counter() + (0.15 if not probed else 0.04)
+            while time.perf_counter() < t_end:
+                self.launch(0, g["per_launch"])
                 self.sync()
-                rates.append(g["bytes_per_frame"] * g["per_launch"] * reps / (self.event_ms() / 1e3) / 1e9)
-        best = max(range(len(cands)), key=lambda i: rates[i]) if rates else 0
-        for i, (d_in, d_out) in enumerate(cands):
-            if i != best:
-                lib.bt709hip_free(h, d_in)
-                lib.bt709hip_free(h, d_out)
-        self.bind_ring(cands[best][0], cands[best][1], gamma)
-        return {"tries": len(cands), "probe_GBps": [round(r, 1) for r in rates], "chosen": best}
+            reps = max(3, int(3 * 64 / g["per_launch"]))
+            self.mark(0)
+            for _ in range(reps):
+                self.launch(0, g["per_launch"])
+            self.mark(1)
+            self.sync()
+            probed[(i, o)] = g["bytes_per_frame"] * g["per_launch"] * reps / (self.event_ms() / 1e3) / 1e9
+            return probed[(i, o)]
+        bi, bo = 0, 0
+        if len(ins) > 1 or len(outs) > 1:
+            bo = max(range(len(outs)), key=lambda o: probe(0, o))
+            bi = max(range(len(ins)), key=lambda i: probe(i, bo))
+            bo = max(range(len(outs)), key=lambda o: probe(bi, o))
+        for k, d in enumerate(ins):
+            if k != bi:
+                lib.bt709hip_free(h, d)
+        for k, d in enumerate(outs):
+            if k != bo:
+                lib.bt709hip_free(h, d)
+        self.bind_ring(ins[bi], outs[bo], gamma)
+        return {"tries": [len(ins), len(outs)], "chosen": [bi, bo],
+                "probe_GBps": {"%d,%d" % k: round(v, 1) for k, v in sorted(probed.items())}}
 
     def fill_ring(self, content):
         """Uploads (outside every timed region) the ring's frames: seeded PRNG bytes or smooth planes."""

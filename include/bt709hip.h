@@ -423,8 +423,8 @@ int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_
 /* Placement-aware allocation for streaming slabs (frame rings, pools).  On MI355X the rate at which a slab streams depends on
  * where it landed: allocations made one after the other by ONE process stream at 5.7-6.5 TB/s, each keeping its rate (the same
  * decode launch 0.74-0.81 of the roofline; tools/placement_hunt.py).  Allocates `tries` candidates of `bytes` (all alive until
- * the choice is made), times the streaming copy above over each (lower half onto upper half), keeps the fastest and frees the
- * rest.  rates_GBps (optional, `tries` floats) receives the probe rates, *chosen (optional) the index kept.  tries = 1 is
+ * the choice is made), times the streaming copy above (lower half onto upper half) plus a fill of the whole slab over each,
+ * keeps the fastest and frees the rest (the memory comes back zeroed when tries > 1).  rates_GBps (optional, `tries` floats) receives the probe rates, *chosen (optional) the index kept.  tries = 1 is
  * bt709hip_malloc.  No reference twin (unified memory has no placement to choose). */
 int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, void **dptr, float *rates_GBps, int *chosen);
 

@@ -126,7 +126,13 @@ decode_nv12_quads(const DecodeParams p) {
   // waves, so threadIdx.y is the same in every lane of a wave: taking it from the first lane
   // makes the row pointers scalar (SGPR base + per-lane offset addressing, no 64-bit VALU
   // address arithmetic).
-  const uint32_t rp_raw = blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
+#if defined(BT709_LAB_BAND_STAGGER)  // lab: band b starts BT709_LAB_BAND_STAGGER workgroup rows further down each of its frames (and wraps)
+  uint32_t by = blockIdx.y + (p.xcd_bands == 1 ? (blockIdx.x & 7u) * (BT709_LAB_BAND_STAGGER) : 0u);
+  if (by >= gridDim.y) by -= gridDim.y;
+#else
+  const uint32_t by = blockIdx.y;
+#endif
+  const uint32_t rp_raw = by * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
   const uint32_t rp = min(rp_raw, row_pairs - 1);
   // quad u of this lane: consecutive lanes own consecutive quads (a store instruction must fill whole
   // lines: a lane owning ADJACENT quads measured 3x slower, tools/lab_quads_variants.hip)

@@ -1473,13 +1473,22 @@ int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, vo
   if (cand.size() > 1 && half >= (1u << 20) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
     for (size_t i = 0; i < cand.size(); ++i) {
       uint8_t *p = static_cast<uint8_t *>(cand[i]);
-      for (int w = 0; w < 3; ++w) launch_copy_probe(p + half, p, half, s);  // warm (clocks, page tables)
+      // a streaming copy (lower half onto upper half) and a fill of the whole slab per round: the fill separates the
+      // placements more clearly (6.3 against 6.5-6.7 TB/s where the copy shows 5.95 against 6.13, tools/placement_probes.py),
+      // and a frame ring is mostly written
+      for (int w = 0; w < 2; ++w) {  // warm (clocks, page tables)
+        launch_copy_probe(p + half, p, half, s);
+        (void)hipMemsetAsync(p, 0, bytes, s);
+      }
       (void)hipEventRecord(e0, s);
-      for (int r = 0; r < 6; ++r) launch_copy_probe(p + half, p, half, s);
+      for (int r = 0; r < 4; ++r) {
+        launch_copy_probe(p + half, p, half, s);
+        (void)hipMemsetAsync(p, 0, bytes, s);
+      }
       (void)hipEventRecord(e1, s);
       float ms = 0.0f;
       if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.0f) ms = 1e9f;
-      const float rate = static_cast<float>(6.0 * 2.0 * static_cast<double>(half) / (ms * 1e-3) / 1e9);
+      const float rate = static_cast<float>(4.0 * (2.0 * static_cast<double>(half) + static_cast<double>(bytes)) / (ms * 1e-3) / 1e9);
       if (rates_GBps) rates_GBps[i] = rate;
       if (rate > best_rate) best_rate = rate, best = static_cast<int>(i);
     }

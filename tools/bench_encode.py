@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--row-pairs", type=int, default=0, help="bt709hip_context_option ENCODE_ROW_PAIRS (0 = sized per launch)")
     ap.add_argument("--xcd-bands", type=int, default=1, help="bt709hip_context_option XCD_BANDS")
     ap.add_argument("--placement-tries", type=int, default=1, help="bt709hip_malloc_streaming candidates per slab")
+    ap.add_argument("--content", choices=("random", "smooth", "flat"), default="random",
+                    help="random bytes (worst case for the LDS gathers), a smooth gradient, or one colour per picture")
     ap.add_argument("--frames-per-launch", type=int, default=1,
                     help="> 1: bt709hip_encode_batch over a ring carved from one allocation")
     ap.add_argument("--library", default=None, help="a variant build of libbt709hip.so (python -m metalbt709decoder_amd.build --variant)")
@@ -58,7 +60,14 @@ def main():
     texs, bufs = [], []
     for i in range(args.ring):
         t = mb.BGRATexture(ctx, W, H, W * 4, ptr=slab_in.ptr + i * in_pitch)
-        ctx.fillBGRATexture(t, rng.integers(0, 1 << 32, W * H, dtype=np.uint32))
+        if args.content == "random":
+            px = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+        elif args.content == "flat":
+            px = np.full(W * H, int(rng.integers(0, 1 << 32)), dtype=np.uint32)
+        else:
+            yy, xx = np.mgrid[0:H, 0:W].astype(np.uint32)
+            px = ((((xx + i) >> 4) & 255) | ((((yy + 2 * i) >> 3) & 255) << 8) | ((((xx + yy) >> 5) & 255) << 16) | (255 << 24)).astype(np.uint32).ravel()
+        ctx.fillBGRATexture(t, px)
         texs.append(t)
         base = slab_out.ptr + i * out_pitch
         bufs.append(mb.CVPixelBuffer(ctx, W, H, W, W, planes=(base, base + W * H)))
@@ -91,7 +100,7 @@ def main():
     n = args.steps * args.ring
     us = ms.value * 1e3 / n
     bytes_per_frame = W * H * 4 + W * H * 3 // 2
-    print(json.dumps({"workload": "%dx%d BGRA -> NV12 encode (sRGB in, Apple gamma out), %d frame(s) per launch" % (W, H, fpl),
+    print(json.dumps({"workload": "%dx%d BGRA -> NV12 encode (sRGB in, Apple gamma out), %d frame(s) per launch, %s content" % (W, H, fpl, args.content),
                       "us_per_frame": round(us, 3), "gpixel_per_s": round(W * H / us / 1e3, 1),
                       "algorithmic_GBps": round(bytes_per_frame / us / 1e3, 1),
                       "frac_of_8TBps": round(bytes_per_frame / us / 1e3 / 8000, 4),
