@@ -336,7 +336,11 @@ const char *launch_unconvert(const DecodeParams &t, const void *in, size_t in_st
 const char *launch_decode(const DecodeParams &p_in, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
                           int xcd_bands, uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
   const bool quant = quantiser || has_alpha;  // the sRGB mode: arithmetic, no table
+#if defined(BT709_LAB_LDS_KB)  // lab: claim this much LDS per workgroup = cap the workgroups per CU (160 KiB each)
+  const size_t lds = BT709_LAB_LDS_KB * 1024;
+#else
   const size_t lds = quant ? 0 : p_in.table_unit_bytes;
+#endif
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
     const uint32_t by = quads_rows_per_block(block_threads, grid_x);

@@ -5,7 +5,7 @@ by up to 8 % between allocations, so process-against-process runs cannot resolve
 the timed regions alternate between the libraries.
 
     python tools/ab_libs.py [--ring 256] [--per-launch 256] [--rounds 4] [--tries 4] LIB [LIB ...]
-LIB = a path, or "shipped" for the in-tree build."""
+LIB = a path, or "shipped" for the in-tree build; LIB@K=V,K=V sets decoder options for that entry only."""
 import argparse
 import ctypes as C
 import os
@@ -50,16 +50,18 @@ def main():
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()
     W, H, RING = args.width, args.height, args.ring
-    paths = [_capi.library_path() if p == "shipped" else os.path.abspath(p) for p in args.libs]
-    libs = [bind(p) for p in paths]
+    specs = [(p.split("@") + [""])[:2] for p in args.libs]  # LIB[@K=V,K=V]: decoder options of that entry only
+    paths = [_capi.library_path() if p == "shipped" else os.path.abspath(p) for p, _ in specs]
+    loaded = {}
+    libs = [loaded.setdefault(p, None) or loaded.__setitem__(p, bind(p)) or loaded[p] for p in paths]
     ctxs, decs = [], []
-    for lib in libs:
+    for lib, (_, own) in zip(libs, specs):
         h = C.c_void_p()
         ok(lib, lib.bt709hip_context_create(0, C.byref(h)))
         d = C.c_void_p()
         ok(lib, lib.bt709hip_decoder_create(h, 0, 0, C.byref(d)))
         ok(lib, lib.bt709hip_decoder_setup(d))
-        for kv in args.decoder_option:
+        for kv in args.decoder_option + [x for x in own.split(",") if x]:
             k, v = kv.split("=")
             ok(lib, lib.bt709hip_decoder_set_option(d, int(k), int(v)))
         ctxs.append(h)
@@ -134,7 +136,7 @@ def main():
             table[k].append(args.steps * RING * W * H / (ms.value / 1e3) / 1e9)
     for p, r in zip(args.libs, table):
         med = sorted(r)[len(r) // 2]
-        print("%-44s %s  median %.1f Gpixel/s = %.4f" % (os.path.basename(p), " ".join("%.1f" % x for x in r), med, med * 5.5 / 8000))
+        print("%-52s %s  median %.1f Gpixel/s = %.4f" % (p if p.startswith("shipped") else os.path.basename(p), " ".join("%.1f" % x for x in r), med, med * 5.5 / 8000))
 
 
 if __name__ == "__main__":
