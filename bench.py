@@ -167,7 +167,9 @@ class GpuRunner:
         self.stream = None    # launch stream: the context's default, or a created one when recording a graph
         self.extra_streams, self.join_events = [], []
         self.host_frames = {}
-        self.placement = self.place_ring(max(1, args.placement_tries), gamma)
+        # ranks that share a device (functional runs on a smaller box) would hunt over each other's memory: no hunt there
+        shared = int(os.environ.get("WORLD_SIZE", "1")) > ndev
+        self.placement = self.place_ring(1 if shared else max(1, args.placement_tries), gamma)
         self.fill_ring(args.content)
         self.pos = 0          # 4k-batch8: ring position of the next step
         self.graph = None
