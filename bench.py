@@ -222,9 +222,9 @@ class GpuRunner:
         different allocations made by ONE process, each allocation keeping its rate (tools/placement_hunt.py).  The output
         slab carries most of it, the input slab about a percent, and the pairing matters (tools/placement_cross.py: 5 x 5
         slabs of one process, 0.74-0.825).  Untimed set-up: allocate `tries` input and `tries` output slabs (all alive, so
-        they land in different places), time the step's own launches on pairings of them -- the input is whatever the memory
-        holds, any bytes decode --: every output slab under input 0, then every input slab under the best output, then the
-        outputs again under the best input; keep the fastest pairing, free the rest.  Reported in config.placement."""
+        they land in different places), time the step's own launches on the pairings of them (hunt_pairing) -- the input is
+        whatever the memory holds, any bytes decode --, keep the fastest pairing, free the rest.  Reported in
+        config.placement."""
         lib, h, g = self.lib, self.h, self.g
 
         def slabs(nbytes):
@@ -256,11 +256,7 @@ class GpuRunner:
             self.sync()
             probed[(i, o)] = g["bytes_per_frame"] * g["per_launch"] * reps / (self.event_ms() / 1e3) / 1e9
             return probed[(i, o)]
-        bi, bo = 0, 0
-        if len(ins) > 1 or len(outs) > 1:
-            bo = max(range(len(outs)), key=lambda o: probe(0, o))
-            bi = max(range(len(ins)), key=lambda i: probe(i, bo))
-            bo = max(range(len(outs)), key=lambda o: probe(bi, o))
+        bi, bo = hunt_pairing(len(ins), len(outs), probe)
         for k, d in enumerate(ins):
             if k != bi:
                 lib.bt709hip_free(h, d)
@@ -420,6 +416,22 @@ class DryRunner:
 
     def kernel_name(self):
         return "dry-run"
+
+
+def hunt_pairing(n_in, n_out, probe, exhaustive_up_to=36):
+    """Which input slab with which output slab (GpuRunner.place_ring): probe(i, o) -> rate.  The output slab carries most of the
+    placement effect, the input slab a percent, and they interact (profiles/r03_placement_cross.txt: on that 5 x 5 matrix a
+    row / column / row descent stops at 0.8187 where the best pairing is 0.8251), so every pairing is probed while that is
+    cheap (<= exhaustive_up_to probes of ~50 ms); beyond that: every output under input 0, every input under the best output,
+    the outputs again under the best input."""
+    if n_in <= 1 and n_out <= 1:
+        return 0, 0
+    if n_in * n_out <= exhaustive_up_to:
+        return max(((i, o) for i in range(n_in) for o in range(n_out)), key=lambda k: probe(*k))
+    bo = max(range(n_out), key=lambda o: probe(0, o))
+    bi = max(range(n_in), key=lambda i: probe(i, bo))
+    bo = max(range(n_out), key=lambda o: probe(bi, o))
+    return bi, bo
 
 
 def smooth_frame(np, rng, g, i):
