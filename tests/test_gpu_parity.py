@@ -348,15 +348,18 @@ def test_frame_sharder_four_lanes_on_one_device(gh, oracle):
 
 
 @pytest.mark.parametrize("case", [((3840, 8), 64, False), ((7680, 4), 72, False), ((1920, 12), 80, False), ((328, 10), 64, False),
-                                  ((640, 6), 64, True)])
+                                  ((640, 6), 64, True), ((640, 6), 64, False, "sRGB"), ((644, 6), 72, False, "Linear"),
+                                  ((1280, 4), 64, False, "ITU709")])
 def test_xcd_band_work_map(gh, oracle, case):
     """Launches of a multiple of 8 frames, 64 or more, use the XCD-aware work map (grid.x = 8 x tiles; each XCD class owns a
     contiguous band of the launch's frames; the frames sit evenly spaced in one slab, as a ring does): every frame distinct, one / two tiles per row, stacked row pairs, an alpha decoder;
     same bytes as the oracle and as the plain map (BT709HIP_OPT_XCD_BANDS = 0), nothing written outside the rows."""
     from metalbt709decoder_amd.decoder import DeviceBuffer
-    (w, h), n, with_alpha = case
+    (w, h), n, with_alpha = case[:3]
     ctx = gh.context()
     gamma = mb.MetalBT709GammaSRGB if with_alpha else mb.MetalBT709GammaApple
+    if len(case) > 3:  # the other gamma modes (the sRGB mode is the table-free kernel variant)
+        gamma = {"sRGB": mb.MetalBT709GammaSRGB, "Linear": mb.MetalBT709GammaLinear, "ITU709": mb.MetalBT709GammaITU709}[case[3]]
     frames = [gh.random_nv12(w, h, seed=7000 + 13 * i + w) for i in range(n)]
     alphas = [np.random.default_rng(i).integers(0, 256, (h, w), dtype=np.uint8) for i in range(n)] if with_alpha else None
     stride = w * 4 + 16
@@ -379,7 +382,7 @@ def test_xcd_band_work_map(gh, oracle, case):
             abufs.append(ab)
         texs.append(mb.BGRATexture(ctx, w, h, stride, ptr=slab_out.ptr + i * out_pitch))
     outs = {}
-    for banded in (1, 0):
+    for banded in (1, 0, 2):  # 2: the bands interleaved frame by frame (lab form of the map, kept as an option)
         dec = gh.make_decoder(gamma, has_alpha=with_alpha, options={_capi.OPT_XCD_BANDS: banded})
         _capi.check(ctx.lib.bt709hip_memset(ctx.handle, slab_out.ptr, 0xC3, n * out_pitch, None))
         assert dec.decodeBT709Batch(bufs, texs, alphaPixelBuffers=abufs or None, waitUntilCompleted=True), dec.lastStatus
@@ -392,6 +395,7 @@ def test_xcd_band_work_map(gh, oracle, case):
         want = oracle.decode_nv12(gamma, y, c, alpha=alphas[i] if with_alpha else None)
         assert np.array_equal(outs[1][i], want), i
         assert np.array_equal(outs[0][i], want), i
+        assert np.array_equal(outs[2][i], want), i
 
 
 def test_evenly_spaced_batch_beyond_table_limit(gh, oracle):
