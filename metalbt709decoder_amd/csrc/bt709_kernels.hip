@@ -153,9 +153,19 @@ decode_nv12_quads(const DecodeParams p) {
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = min((q0 + u * blockDim.x), quads - 1);
+#if defined(BT709_LAB_LOAD_AUX)  // lab: the loads as raw buffer loads with this cache-policy operand (1 sc0, 2 nt, 16 sc1)
+    {
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(f.y), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(f.cbcr), 0, 0x7fffffff, 0x00020000);
+      ya[u] = __builtin_amdgcn_raw_buffer_load_b32(ry, 4 * q, static_cast<int>(2 * rp * p.y_stride), BT709_LAB_LOAD_AUX);
+      yb[u] = __builtin_amdgcn_raw_buffer_load_b32(ry, 4 * q, static_cast<int>((2 * rp + 1) * p.y_stride), BT709_LAB_LOAD_AUX);
+      cw[u] = __builtin_amdgcn_raw_buffer_load_b32(rc, 4 * q, static_cast<int>(rp * p.cbcr_stride), BT709_LAB_LOAD_AUX);
+    }
+#else
     ya[u] = load32<NT>(y0 + 4 * q);
     yb[u] = load32<NT>(y1 + 4 * q);
     cw[u] = load32<NT>(cc + 4 * q);
+#endif
     if (HAS_ALPHA) {
       aa[u] = *reinterpret_cast<const uint32_t *>(a0 + 4 * q);
       ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
@@ -195,8 +205,14 @@ decode_nv12_quads(const DecodeParams p) {
                            bot);
 #endif
     if (q < quads && rp_raw < row_pairs) {
+#if defined(BT709_LAB_STORE_AUX)  // lab: the stores as raw buffer stores with this cache-policy operand (1 sc0, 2 nt, 16 sc1)
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(f.out, 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(top, ro, 16 * q, static_cast<int>(2 * rp * p.out_stride), BT709_LAB_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(bot, ro, 16 * q, static_cast<int>((2 * rp + 1) * p.out_stride), BT709_LAB_STORE_AUX);
+#else
       store16<NT>(o0 + 16 * q, top);
       store16<NT>(o1 + 16 * q, bot);
+#endif
     }
   }
 }
