@@ -256,9 +256,29 @@ class GpuRunner:
             self.sync()
             return g["bytes_per_frame"] * g["per_launch"] * n / (self.event_ms() / 1e3) / 1e9
 
+        # The output slabs come in two regimes (~0.74 / ~0.80+); a process whose candidates all look alike under input 0 may hold
+        # six slow ones (seen: 4 of 4, 6 of 8 on some boxes), so it allocates `tries` more, up to three times; then the
+        # `tries` fastest stay in the hunt.
+        prescan = []
+        while tries > 1:
+            for o in range(len(prescan), len(outs)):
+                prescan.append(measure(0, o, reps, 0.15 if not prescan else 0.03))
+            if (max(prescan) - min(prescan)) / max(prescan) >= 0.02 or len(outs) >= 3 * tries:
+                break
+            more = slabs(self.out_stride * g["ring"])
+            if not more:
+                break
+            outs += more
+        if len(outs) > tries:
+            keep = sorted(sorted(range(len(outs)), key=lambda o: -prescan[o])[:tries])
+            for o in range(len(outs)):
+                if o not in keep:
+                    lib.bt709hip_free(h, outs[o])
+            outs = [outs[o] for o in keep]
+
         def probe(i, o):
             if (i, o) not in probed:
-                probed[(i, o)] = measure(i, o, reps, 0.15 if not probed else 0.03)
+                probed[(i, o)] = measure(i, o, reps, 0.03)
             return probed[(i, o)]
         bi, bo = hunt_pairing(len(ins), len(outs), probe)
         confirmed = {}
@@ -275,7 +295,8 @@ class GpuRunner:
         self.bind_ring(ins[bi], outs[bo], gamma)
         return {"tries": [len(ins), len(outs)], "chosen": [bi, bo],
                 "probe_GBps": {"%d,%d" % k: round(v, 1) for k, v in sorted(probed.items())},
-                "confirm_GBps": {"%d,%d" % k: round(v, 1) for k, v in sorted(confirmed.items())}}
+                "confirm_GBps": {"%d,%d" % k: round(v, 1) for k, v in sorted(confirmed.items())},
+                "output_prescan_GBps": [round(v, 1) for v in prescan]}
 
     def fill_ring(self, content):
         """Uploads (outside every timed region) the ring's frames: seeded PRNG bytes or smooth planes."""
