@@ -207,6 +207,13 @@ class MetalScaleRenderContext {
                                          waitUntilCompleted ? 1 : 0);
     return lastStatus_ == BT709HIP_OK;
   }
+  // The same pass over `count` intermediates of one geometry, evenly spaced in memory, in ONE launch
+  // (bt709hip_render_scaled_batch; no reference twin)
+  bool renderScaledBatch(MetalRenderContext &mrc, int count, const bt709hip_surface *mtkViews, void *commandBuffer,
+                         const bt709hip_surface *bgraTextures, bool waitUntilCompleted = false) {
+    lastStatus_ = bt709hip_render_scaled_batch(mrc.handle(), count, bgraTextures, mtkViews, commandBuffer, waitUntilCompleted ? 1 : 0);
+    return lastStatus_ == BT709HIP_OK;
+  }
   int lastStatus() const { return lastStatus_; }
 
  private:

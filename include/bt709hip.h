@@ -315,6 +315,13 @@ int bt709hip_decode_scaled_batch(bt709hip_decoder *dec, int count, const bt709hi
  * BT709HIP_ERR_UNSUPPORTED: a surface of 2 GiB or more. */
 int bt709hip_render_scaled(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_surface *out,
                            void *stream, int wait_until_completed);
+/* The same pass over `count` intermediates of one geometry and format in ONE launch (grid.z = surface), for a caller that
+ * rescales a ring of decoded frames: one 4K -> 1440p pass is a 3.7-Mpixel launch, too small to fill the chip.  The surfaces
+ * must be evenly spaced in memory (surface i at surface 0 + i * (surface 1 - surface 0), as in a ring carved from one
+ * allocation; BT709HIP_ERR_UNSUPPORTED otherwise), count <= 65535; differing sizes, strides or formats:
+ * BT709HIP_ERR_SIZE_MISMATCH.  No reference twin (-renderScaled: takes one texture). */
+int bt709hip_render_scaled_batch(bt709hip_context *ctx, int count, const bt709hip_surface *ins, const bt709hip_surface *outs,
+                                 void *stream, int wait_until_completed);
 /* The tables of bt709hip_render_scaled (and of RGBA16F decodes: bt709hip_decoder_prepare_format) are
  * built on first use; call these before bt709hip_graph_begin_capture.  Idempotent. */
 int bt709hip_render_scaled_prepare(bt709hip_context *ctx);

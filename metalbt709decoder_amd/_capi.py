@@ -134,6 +134,7 @@ SYMBOLS = {
     "bt709hip_decode_scaled": (_I, [_P, _FP, _FP, _SP, _P, _I]),
     "bt709hip_decode_scaled_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
     "bt709hip_render_scaled": (_I, [_P, _SP, _SP, _P, _I]),
+    "bt709hip_render_scaled_batch": (_I, [_P, _I, _SP, _SP, _P, _I]),
     "bt709hip_render_scaled_prepare": (_I, [_P]),
     "bt709hip_decoder_prepare_format": (_I, [_P, _I]),
     "bt709hip_encoder_prepare": (_I, [_P, _I, _I]),

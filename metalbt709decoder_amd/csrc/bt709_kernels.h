@@ -115,8 +115,10 @@ struct RenderParams {
   uint32_t table_encode_bytes;
   float encode_scale;  // n_fine of table_encode
   uint32_t encode_offset, encode_shift;
+  int64_t in_step, out_step;  // batched launches: surface i of the launch = surface 0 + i * step (evenly spaced, as in a ring)
 };
-const char *launch_render_scaled(const RenderParams &p, bool in_rgba16f, uint32_t compute_units, hipStream_t stream);
+// grid = (column tiles, strips of `rows` output rows, frames)
+const char *launch_render_scaled(const RenderParams &p, int frames, bool in_rgba16f, uint32_t compute_units, hipStream_t stream);
 
 // BGRA -> NV12 encoder (bt709_encode.hip).  One frame per launch.
 struct EncodeFrame {

@@ -872,8 +872,11 @@ render_scaled(const RenderParams p) {
     rt.ys[1] = min(max(yi + 1, 0), hmax);
     return rt;
   };
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.in), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7fffffff, 0x00020000);
+  // surface blockIdx.z of a batched launch (bt709hip_render_scaled_batch: evenly spaced surfaces)
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t *>(p.in) + static_cast<int64_t>(blockIdx.z) * p.in_step, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout =
+      __builtin_amdgcn_make_buffer_rsrc(p.out + static_cast<int64_t>(blockIdx.z) * p.out_step, 0, 0x7fffffff, 0x00020000);
   struct Fetched {  // the two texels of a source row, untouched
     uint32_t w[IN_RGBA16F ? 4 : 2];
   };
@@ -967,16 +970,16 @@ render_scaled(const RenderParams p) {
   landed(a1);
 }
 
-const char *launch_render_scaled(const RenderParams &p_in, bool in_rgba16f, uint32_t compute_units, hipStream_t stream) {
+const char *launch_render_scaled(const RenderParams &p_in, int frames, bool in_rgba16f, uint32_t compute_units, hipStream_t stream) {
   RenderParams p = p_in;
   const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
   const uint64_t want = 8ull * (compute_units ? compute_units : 256u);
-  uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height / want);
+  uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height * static_cast<uint32_t>(frames) / want);
   rows = rows < 1 ? 1 : (rows > 16 ? 16 : rows);
   p.rows = rows;
   // the kernel forms row offsets in 32 bits
   if (static_cast<uint64_t>(p.height) * p.in_stride >= (1ull << 31) || static_cast<uint64_t>(p.out_height) * p.out_stride >= (1ull << 31)) return nullptr;
-  const dim3 grid(cols, (p.out_height + rows - 1) / rows, 1);
+  const dim3 grid(cols, (p.out_height + rows - 1) / rows, static_cast<uint32_t>(frames));
   const size_t lds = static_cast<size_t>(p.table_encode_bytes) + 1024;
   if (in_rgba16f) hipLaunchKernelGGL(render_scaled<true>, grid, dim3(kBlockThreads), lds, stream, p);
   else hipLaunchKernelGGL(render_scaled<false>, grid, dim3(kBlockThreads), lds, stream, p);

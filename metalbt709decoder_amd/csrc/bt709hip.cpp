@@ -959,8 +959,38 @@ int bt709hip_render_scaled_prepare(bt709hip_context *ctx) {
   return render_tables(ctx, nullptr);
 }
 
+static int render_scaled_launch(bt709hip_context *ctx, int count, const bt709hip_surface *in, const bt709hip_surface *out,
+                                int64_t in_step, int64_t out_step, void *stream, int wait_until_completed);
+
+int bt709hip_render_scaled_batch(bt709hip_context *ctx, int count, const bt709hip_surface *in, const bt709hip_surface *out,
+                                 void *stream, int wait_until_completed) {
+  if (ctx == nullptr || in == nullptr || out == nullptr || count < 0 || count > kMaxUniformBatch) return BT709HIP_ERR_INVALID_ARG;
+  if (count == 0) return BT709HIP_OK;
+  // one geometry, surfaces evenly spaced in memory (a ring carved from one allocation): surface i = surface 0 + i * step
+  int64_t in_step = 0, out_step = 0;
+  if (count > 1) {
+    in_step = static_cast<const uint8_t *>(in[1].bgra) - static_cast<const uint8_t *>(in[0].bgra);
+    out_step = static_cast<const uint8_t *>(out[1].bgra) - static_cast<const uint8_t *>(out[0].bgra);
+  }
+  for (int i = 1; i < count; ++i) {
+    if (in[i].width != in[0].width || in[i].height != in[0].height || in[i].stride != in[0].stride || in[i].format != in[0].format ||
+        in[i].reserved != 0 || out[i].width != out[0].width || out[i].height != out[0].height || out[i].stride != out[0].stride ||
+        out[i].format != out[0].format || out[i].reserved != 0)
+      return BT709HIP_ERR_SIZE_MISMATCH;
+    if (static_cast<const uint8_t *>(in[i].bgra) != static_cast<const uint8_t *>(in[0].bgra) + static_cast<int64_t>(i) * in_step ||
+        static_cast<const uint8_t *>(out[i].bgra) != static_cast<const uint8_t *>(out[0].bgra) + static_cast<int64_t>(i) * out_step)
+      return BT709HIP_ERR_UNSUPPORTED;
+  }
+  return render_scaled_launch(ctx, count, in, out, in_step, out_step, stream, wait_until_completed);
+}
+
 int bt709hip_render_scaled(bt709hip_context *ctx, const bt709hip_surface *in, const bt709hip_surface *out, void *stream,
                            int wait_until_completed) {
+  return render_scaled_launch(ctx, 1, in, out, 0, 0, stream, wait_until_completed);
+}
+
+static int render_scaled_launch(bt709hip_context *ctx, int count, const bt709hip_surface *in, const bt709hip_surface *out,
+                                int64_t in_step, int64_t out_step, void *stream, int wait_until_completed) {
   if (ctx == nullptr || in == nullptr || out == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (in->width < 0 || in->height < 0 || out->width < 0 || out->height < 0 || in->reserved != 0 || out->reserved != 0)
     return BT709HIP_ERR_INVALID_ARG;
@@ -995,7 +1025,9 @@ int bt709hip_render_scaled(bt709hip_context *ctx, const bt709hip_surface *in, co
   p.encode_scale = static_cast<float>(ctx->render_encode_n);
   p.encode_offset = ctx->render_encode_offset;
   p.encode_shift = ctx->render_encode_shift;
-  const char *name = launch_render_scaled(p, in->format == BT709HIP_FORMAT_RGBA16F,
+  p.in_step = in_step;
+  p.out_step = out_step;
+  const char *name = launch_render_scaled(p, count, in->format == BT709HIP_FORMAT_RGBA16F,
                                           static_cast<uint32_t>(ctx->props.multiProcessorCount), s);
   if (name == nullptr) return BT709HIP_ERR_UNSUPPORTED;  // a surface of 2 GiB or more
   tl_kernel_name = name;

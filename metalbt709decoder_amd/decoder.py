@@ -449,6 +449,21 @@ class MetalScaleRenderContext:
             log.error("renderScaled: %s", _capi.strerror(self.lastStatus))
         return self.lastStatus == _capi.OK
 
+    def renderScaledBatch(self, mrc, mtkViews, commandBuffer=None, bgraTextures=None, waitUntilCompleted=False):
+        """The same pass over several intermediates of one geometry in ONE launch (bt709hip_render_scaled_batch; no
+        reference twin): textures and views evenly spaced in memory, as carved from one allocation."""
+        if not mtkViews or not bgraTextures or len(mtkViews) != len(bgraTextures):
+            self.lastStatus = _capi.ERR_INVALID_ARG
+            return False
+        n = len(mtkViews)
+        srcs = (_capi.Surface * n)(*[t.surface() for t in bgraTextures])
+        dsts = (_capi.Surface * n)(*[v.surface() for v in mtkViews])
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        self.lastStatus = mrc.lib.bt709hip_render_scaled_batch(mrc.handle, n, srcs, dsts, stream, int(bool(waitUntilCompleted)))
+        if self.lastStatus != _capi.OK:
+            log.error("renderScaledBatch: %s", _capi.strerror(self.lastStatus))
+        return self.lastStatus == _capi.OK
+
 
 class BGRAToBT709Converter:
     """Buffer helpers of Renderer/BGRAToBT709Converter.{h,m} that the decode tests use."""

@@ -236,3 +236,44 @@ def test_gpu_two_passes_equal_fused(gh, oracle, case):
         else:
             assert np.array_equal(got, oracle.render_scaled(oracle.decode_nv12_rgba16f(gamma, y, c, alpha=a), ow, oh))
     assert not scale.renderScaled(ctx, view, ow + 1, oh, None, None, inter, True) and scale.lastStatus == _capi.ERR_SIZE_MISMATCH
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [mb.MTLPixelFormatBGRA8Unorm_sRGB, mb.MTLPixelFormatRGBA16Float])
+def test_gpu_render_scaled_batch(gh, oracle, fmt):
+    """bt709hip_render_scaled_batch: pass 2 over a ring of intermediates in ONE launch equals one call per surface and the
+    oracle, writes nothing outside its rows; unevenly spaced or mismatched surfaces are refused."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    n, (w, h), (ow, oh) = 5, (96, 40), (61, 27)
+    bpp = 8 if fmt == mb.MTLPixelFormatRGBA16Float else 4
+    in_stride, out_stride = w * bpp + 32, ow * 4 + 16
+    in_pitch, out_pitch = in_stride * h + 64, out_stride * oh
+    slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
+    dec = gh.make_decoder(0)
+    frames = [_frame(w, h, 900 + i) for i in range(n)]
+    inters = [mb.BGRATexture(ctx, w, h, in_stride, ptr=slab_in.ptr + i * in_pitch, pixelFormat=fmt) for i in range(n)]
+    views = [mb.BGRATexture(ctx, ow, oh, out_stride, ptr=slab_out.ptr + i * out_pitch) for i in range(n)]
+    for (y, c), t in zip(frames, inters):
+        assert dec.decodeBT709(gh.make_buffer(y, c, dec.gamma), None, t, None, None, w, h, True), dec.lastStatus
+    scale = mb.MetalScaleRenderContext()
+    assert scale.setupRenderPipelines(ctx)
+    _capi.check(ctx.lib.bt709hip_memset(ctx.handle, slab_out.ptr, 0x5A, n * out_pitch, None))
+    assert scale.renderScaledBatch(ctx, views, None, inters, True), scale.lastStatus
+    raw = np.empty((n * oh, out_stride), np.uint8)
+    _capi.check(ctx.lib.bt709hip_download(ctx.handle, raw.ctypes.data, out_stride, slab_out.ptr, out_stride, out_stride, n * oh, None))
+    ctx._sync(None)
+    assert (raw[:, ow * 4:] == 0x5A).all()
+    got = raw[:, :ow * 4].reshape(n, oh, ow * 4)
+    for i, (y, c) in enumerate(frames):
+        inter = oracle.decode_nv12_rgba16f(0, y, c) if bpp == 8 else oracle.decode_nv12(0, y, c)
+        assert np.array_equal(got[i], oracle.render_scaled(inter, ow, oh)), i
+        single = ctx.makeBGRATexture((ow, oh))
+        assert scale.renderScaled(ctx, single, ow, oh, None, None, inters[i], True), scale.lastStatus
+        assert np.array_equal(ctx.getBGRATexturePixels(single).view(np.uint8).reshape(oh, -1), got[i]), i
+    # not evenly spaced: refused before anything is launched
+    assert not scale.renderScaledBatch(ctx, [views[0], views[2], views[3]], None, [inters[0], inters[1], inters[2]], True)
+    assert scale.lastStatus == _capi.ERR_UNSUPPORTED
+    other = ctx.makeBGRATexture((w + 2, h), pixelFormat=fmt)
+    assert not scale.renderScaledBatch(ctx, views[:2], None, [inters[0], other], True) and scale.lastStatus == _capi.ERR_SIZE_MISMATCH
+    assert not scale.renderScaledBatch(ctx, views[:2], None, inters[:1], True) and scale.lastStatus == _capi.ERR_INVALID_ARG

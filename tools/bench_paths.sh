@@ -10,4 +10,6 @@ $B --path scaled --width 1920 --height 1080 --out-width 1366 --out-height 768 --
 $B --path rgba16f --frames-per-launch 1
 $B --path rgba16f --frames-per-launch 16
 $B --path render8
+$B --path render8 --frames-per-launch 16
 $B --path render16
+$B --path render16 --frames-per-launch 16

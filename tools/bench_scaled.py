@@ -4,7 +4,7 @@
 
     --path scaled     any-ratio fused decode + bilinear rescale (bt709hip_decode_scaled[_batch])
     --path rgba16f    pass 1 into an RGBA16Float target (bt709hip_decode_batch, format RGBA16F)
-    --path render8    pass 2 alone from a BGRA8 sRGB intermediate (bt709hip_render_scaled)
+    --path render8    pass 2 alone from a BGRA8 sRGB intermediate (bt709hip_render_scaled[_batch])
     --path render16   pass 2 alone from an RGBA16Float intermediate
 
     python tools/bench_scaled.py [--path scaled --width 3840 --height 2160 --out-width 2560 --out-height 1440
@@ -48,7 +48,7 @@ def main():
         _capi.load(os.path.abspath(args.library))
     W, H, path = args.width, args.height, args.path
     OW, OH = (W, H) if path == "rgba16f" else (args.out_width, args.out_height)
-    fpl = 1 if path.startswith("render") else max(1, min(args.frames_per_launch, args.ring))
+    fpl = max(1, min(args.frames_per_launch, args.ring))
     ring = args.ring - args.ring % fpl
     ctx = gh.context()
     lib, h = ctx.lib, ctx.handle
@@ -88,8 +88,10 @@ def main():
                 rc = lib.bt709hip_decode_scaled_batch(dec._handle, fpl, fp, None, sp, None, 0)
             elif path == "rgba16f":
                 rc = lib.bt709hip_decode_batch(dec._handle, fpl, fp, None, sp, None, 0)
-            else:
+            elif fpl == 1:
                 rc = lib.bt709hip_render_scaled(h, C.cast(C.byref(inters, i * ssz), C.POINTER(_capi.Surface)), sp, None, 0)
+            else:
+                rc = lib.bt709hip_render_scaled_batch(h, fpl, C.cast(C.byref(inters, i * ssz), C.POINTER(_capi.Surface)), sp, None, 0)
             _capi.check(rc, path)
 
     t_end = time.perf_counter() + 0.4
