@@ -1016,6 +1016,10 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
 const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool has_alpha, bool nontemporal, uint32_t workgroups,
                                    uint32_t lds_budget, hipStream_t stream) {
   DecodeParams p = p_in;
+#if defined(BT709_LAB_HALF_TABLE)  // lab, WRONG OUTPUT: half as many (coarser) decode-side buckets = the LDS footprint of 8-byte entries
+  p.unit_magic = p.unit_magic * 2.0f;
+  p.table_linear_bytes = (p.table_linear_bytes / 2 + 31u) & ~15u;
+#endif
   const uint64_t kRepLdsBytes = (lds_budget < 16384u ? 16384u : (lds_budget > bt709::kRepLdsBytes ? bt709::kRepLdsBytes : lds_budget));
   // copies: as many as fit the CU's LDS, decode side first (12 of the 15 lookups per output pixel)
   const uint64_t enc_bytes = kRepUniformEncode ? p.table_encode_u_bytes : p.table_encode_bytes;
