@@ -153,7 +153,9 @@ decode_nv12_quads(const DecodeParams p) {
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = min((q0 + u * blockDim.x), quads - 1);
-#if defined(BT709_LAB_LOAD_AUX)  // lab: the loads as raw buffer loads with this cache-policy operand (1 sc0, 2 nt, 16 sc1)
+#if defined(BT709_LAB_NO_LOADS)  // lab, with BT709_LAB_NO_ARITH: the launch's stores alone
+    ya[u] = q * 3u, yb[u] = q * 5u, cw[u] = q * 7u + rp;
+#elif defined(BT709_LAB_LOAD_AUX)  // lab: the loads as raw buffer loads with this cache-policy operand (1 sc0, 2 nt, 16 sc1)
     {
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(f.y), 0, 0x7fffffff, 0x00020000);
       const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(f.cbcr), 0, 0x7fffffff, 0x00020000);
@@ -204,7 +206,11 @@ decode_nv12_quads(const DecodeParams p) {
     decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
                            bot);
 #endif
+#if defined(BT709_LAB_NO_STORES)  // lab, with BT709_LAB_NO_ARITH: the launch's loads alone (a store about once in 2^32 quads keeps them alive)
+    if (q < quads && rp_raw < row_pairs && (top.w ^ bot.w) == 0x9e3779b9u) {
+#else
     if (q < quads && rp_raw < row_pairs) {
+#endif
 #if defined(BT709_LAB_STORE_AUX)  // lab: the stores as raw buffer stores with this cache-policy operand (1 sc0, 2 nt, 16 sc1)
       const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(f.out, 0, 0x7fffffff, 0x00020000);
       __builtin_amdgcn_raw_buffer_store_b128(top, ro, 16 * q, static_cast<int>(2 * rp * p.out_stride), BT709_LAB_STORE_AUX);
