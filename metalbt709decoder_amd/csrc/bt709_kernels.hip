@@ -150,6 +150,9 @@ decode_nv12_quads(const DecodeParams p) {
   // s_waitcnt vmcnt(0) at the join, i.e. each wave waited for the write acknowledgement of its
   // first quad's stores before touching its second quad.
   uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
+#if defined(BT709_LAB_READ_WINDOW_MASK)  // lab: loads only in chip-wide time windows (s_memrealtime counts 10 ns ticks, the same on every XCD)
+  while ((static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) & (BT709_LAB_READ_WINDOW_MASK)) >= (BT709_LAB_READ_WINDOW_OPEN)) __builtin_amdgcn_s_sleep(2);
+#endif
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = min((q0 + u * blockDim.x), quads - 1);
@@ -205,6 +208,9 @@ decode_nv12_quads(const DecodeParams p) {
 #else
     decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
                            bot);
+#endif
+#if defined(BT709_LAB_WRITE_WINDOW_MASK)  // lab: stores only outside the read windows
+    while ((static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) & (BT709_LAB_WRITE_WINDOW_MASK)) < (BT709_LAB_WRITE_WINDOW_CLOSED)) __builtin_amdgcn_s_sleep(2);
 #endif
 #if defined(BT709_LAB_NO_STORES)  // lab, with BT709_LAB_NO_ARITH: the launch's loads alone (a store about once in 2^32 quads keeps them alive)
     if (q < quads && rp_raw < row_pairs && (top.w ^ bot.w) == 0x9e3779b9u) {
