@@ -172,8 +172,8 @@ decode_nv12_quads(const DecodeParams p) {
     cw[u] = load32<NT>(cc + 4 * q);
 #endif
     if (HAS_ALPHA) {
-      aa[u] = *reinterpret_cast<const uint32_t *>(a0 + 4 * q);
-      ab[u] = *reinterpret_cast<const uint32_t *>(a0 + p.alpha_stride + 4 * q);
+      aa[u] = load32<NT>(a0 + 4 * q);
+      ab[u] = load32<NT>(a0 + p.alpha_stride + 4 * q);
     }
   }
 #if defined(BT709_LAB_PRIO_LOADS)
@@ -181,6 +181,9 @@ decode_nv12_quads(const DecodeParams p) {
 #endif
 #if defined(BT709_LAB_PRIO_STORES)  // lab: the other way round: a wave that has its data finishes ahead of younger ones
   __builtin_amdgcn_s_setprio(BT709_LAB_PRIO_STORES);
+#endif
+#if defined(BT709_LAB_SLEEP_AFTER_LOADS)  // lab: every wave idles this many x 64 cycles with its loads in flight (a slower kernel drifts less on the plain map)
+  __builtin_amdgcn_s_sleep(BT709_LAB_SLEEP_AFTER_LOADS);
 #endif
 #if !defined(BT709_LAB_NO_TABLE)  // lab, with BT709_LAB_NO_ARITH: without the per-workgroup table staging and its barrier too
   if (!QUANT) {  // the sRGB mode needs no table (decode_quad)

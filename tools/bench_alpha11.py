@@ -1,4 +1,9 @@
-"""4K 1:1 decode in the sRGB mode with and without an alpha plane, 32 frames per launch (runs on the GPU box): python tools/bench_alpha11.py"""
+"""4K 1:1 decode in the sRGB mode with and without an alpha plane and in the other gamma modes, over a ring of RING frames (default 256: the
+alpha planes of a 32-frame ring are 265 MB, about the size of the Infinity Cache -- round 2's and the first round-3 figure for the
+alpha decoder, 0.86, was measured on such a ring with cached alpha loads and was mostly cache hits), PER_LAUNCH frames per launch
+(environment, default = the ring; from 64 on the XCD-aware work map applies), slabs placed by bt709hip_malloc_streaming with TRIES
+candidates (runs on the GPU box):
+    [PER_LAUNCH=32] [ONLY_ALPHA=1] [BANDS=0] python tools/bench_alpha11.py [library|-] [ring=256] [tries=1]"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -7,27 +12,35 @@ import gpu_helpers as gh
 import metalbt709decoder_amd as mb
 from metalbt709decoder_amd import _capi
 from metalbt709decoder_amd.decoder import DeviceBuffer
-W, H, ring = 3840, 2160, 32
-if len(sys.argv) > 1: _capi.load(os.path.abspath(sys.argv[1]))
+W, H = 3840, 2160
+ring = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+tries = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+if len(sys.argv) > 1 and sys.argv[1] != "-": _capi.load(os.path.abspath(sys.argv[1]))
 ctx = gh.context(); lib, h = ctx.lib, ctx.handle
 for alpha, gamma in ((1, mb.MetalBT709GammaSRGB), (0, mb.MetalBT709GammaSRGB), (0, mb.MetalBT709GammaApple), (0, mb.MetalBT709GammaLinear), (0, mb.MetalBT709GammaITU709)):
-    dec = gh.make_decoder(gamma, has_alpha=bool(alpha))
+    if os.environ.get("ONLY_ALPHA") and not alpha: continue
+    dec = gh.make_decoder(gamma, has_alpha=bool(alpha), options={_capi.OPT_XCD_BANDS: int(os.environ.get("BANDS", "1"))})
     in_pitch = W * H * 3 // 2; a_pitch = W * H; out_pitch = W * H * 4
-    si, sa, so = DeviceBuffer(ctx, ring * in_pitch), DeviceBuffer(ctx, ring * a_pitch), DeviceBuffer(ctx, ring * out_pitch)
+    si, sa, so = DeviceBuffer(ctx, ring * in_pitch, tries), DeviceBuffer(ctx, ring * a_pitch if alpha else 256, tries if alpha else 1), DeviceBuffer(ctx, ring * out_pitch, tries)
     frames, alphas, surfs = (_capi.Frame * ring)(), (_capi.Frame * ring)(), (_capi.Surface * ring)()
     y, c = gh.random_nv12(W, H, seed=1); a = np.random.default_rng(2).integers(0, 256, (H, W), dtype=np.uint8)
     for i in range(ring):
         b = si.ptr + i * in_pitch
-        ctx._upload(b, W, y, None); ctx._upload(b + W * H, W, c, None); ctx._upload(sa.ptr + i * a_pitch, W, a, None); ctx._sync(None)
+        ctx._upload(b, W, y, None); ctx._upload(b + W * H, W, c, None); ctx._sync(None)
+        if alpha: ctx._upload(sa.ptr + i * a_pitch, W, a, None); ctx._sync(None)
         buf = mb.CVPixelBuffer(ctx, W, H, W, W, planes=(b, b + W * H))
         buf.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2); buf.setAttachment("TransferFunction", gh.TRANSFER_FOR_GAMMA[dec.gamma])
         frames[i] = buf.frame()
-        ab = mb.CVPixelBuffer(ctx, W, H, W, W, planes=(sa.ptr + i * a_pitch, b + W * H))
+        ab = mb.CVPixelBuffer(ctx, W, H, W, W, planes=(sa.ptr + (i * a_pitch if alpha else 0), b + W * H))
         ab.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2); ab.setAttachment("TransferFunction", mb.kCVImageBufferTransferFunction_Linear)
         alphas[i] = ab.frame()
         surfs[i] = _capi.Surface(so.ptr + i * out_pitch, W * 4, W, H, _capi.FORMAT_BGRA8_SRGB, 0)
+    per = int(os.environ.get("PER_LAUNCH", ring))
+    fsz, ssz = C.sizeof(_capi.Frame), C.sizeof(_capi.Surface)
     def step():
-        rc = lib.bt709hip_decode_batch(dec._handle, ring, frames, alphas if alpha else None, surfs, None, 0); assert rc == 0, rc
+        for i in range(0, ring, per):
+            fp = C.cast(C.byref(frames, i * fsz), C.POINTER(_capi.Frame)); ap = C.cast(C.byref(alphas, i * fsz), C.POINTER(_capi.Frame)); sp = C.cast(C.byref(surfs, i * ssz), C.POINTER(_capi.Surface))
+            rc = lib.bt709hip_decode_batch(dec._handle, per, fp, ap if alpha else None, sp, None, 0); assert rc == 0, rc
     import time
     t_end = time.perf_counter() + 0.4
     while time.perf_counter() < t_end:
@@ -35,10 +48,10 @@ for alpha, gamma in ((1, mb.MetalBT709GammaSRGB), (0, mb.MetalBT709GammaSRGB), (
     ctx._sync(None)
     e0, e1 = C.c_void_p(), C.c_void_p(); lib.bt709hip_event_create(h, C.byref(e0)); lib.bt709hip_event_create(h, C.byref(e1))
     lib.bt709hip_event_record(h, e0, None)
-    n = 20
+    n = max(3, 20 * 32 // ring)
     for _ in range(n): step()
     lib.bt709hip_event_record(h, e1, None); ctx._sync(None)
     ms = C.c_float(); lib.bt709hip_event_elapsed_ms(h, e0, e1, C.byref(ms))
     us = ms.value * 1e3 / (n * ring)
     nbytes = W * H * 3 // 2 + (W * H if alpha else 0) + out_pitch
-    print("4K 1:1 gamma=%d alpha=%d: %.2f us/frame %.1f Gpx/s %.3f of 8TB/s %s" % (gamma, alpha, us, W * H / us / 1e3, nbytes / us / 1e3 / 8000, lib.bt709hip_last_kernel_name().decode()))
+    print("4K 1:1 ring %d x %d per launch gamma=%d alpha=%d: %.2f us/frame %.1f Gpx/s %.3f of 8TB/s %s" % (ring, per, gamma, alpha, us, W * H / us / 1e3, nbytes / us / 1e3 / 8000, lib.bt709hip_last_kernel_name().decode()))
