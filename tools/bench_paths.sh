@@ -5,8 +5,8 @@ cd "${GRAFT_REPO_ROOT:-.}"
 B="python tools/bench_scaled.py"
 $B --path scaled --frames-per-launch 1
 $B --path scaled --frames-per-launch 8
-$B --path scaled --width 7680 --height 4320 --out-width 3840 --out-height 2160 --ring 8 --frames-per-launch 1
-$B --path scaled --width 1920 --height 1080 --out-width 1366 --out-height 768 --ring 32 --frames-per-launch 16
+$B --path scaled --width 7680 --height 4320 --out-width 3840 --out-height 2160 --ring 16 --frames-per-launch 1
+$B --path scaled --width 1920 --height 1080 --out-width 1366 --out-height 768 --ring 128 --frames-per-launch 16
 $B --path rgba16f --frames-per-launch 1
 $B --path rgba16f --frames-per-launch 16
 $B --path render8
