@@ -96,6 +96,9 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+INFINITY_CACHE_BYTES = 256 << 20  # MI355X memory-side cache
+
+
 def geometry(workload, ring_arg, max_batch, per_launch_arg=0, world=1, share=0):
     """Per-GPU plan of one step: ring size, frames per launch, launches, byte counts.
     4k-batch8: a step is ONE launch of this rank's share of the 8 frames (8 / world, or --share);
@@ -118,6 +121,9 @@ def geometry(workload, ring_arg, max_batch, per_launch_arg=0, world=1, share=0):
         "y_bytes": W * H, "c_bytes": W * (H // 2), "o_bytes": OW * OH * 4,
         # algorithmic bytes: 1.5 B read per source pixel + 4 B written per output pixel
         "bytes_per_frame": W * H * 3 // 2 + OW * OH * 4,
+        # the ring's INPUT against the 256 MB memory-side cache: a ring whose input fits it measures the cache, not HBM (two
+        # side benches of this repo did for two rounds); main() refuses such a ring for a bench record
+        "ring_input_over_cache": ring * (W * H * 3 // 2) / float(INFINITY_CACHE_BYTES),
     }
 
 
@@ -522,6 +528,9 @@ def main(argv=None):
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     g = geometry(args.workload, args.ring, 65535, args.frames_per_launch, world, args.share)
+    if g["ring_input_over_cache"] < 2.0 and not args.dry_run:
+        sys.exit("--ring %d: the ring's input (%.0f MB) must be at least twice the 256 MB Infinity Cache, or the run measures the cache"
+                 % (g["ring"], g["ring_input_over_cache"] * 256))
     runner = DryRunner() if args.dry_run else GpuRunner(args, g, rank, local_rank)
 
     def barrier():

@@ -462,6 +462,10 @@ def test_bench_geometry():
         g = bench.geometry("4k-batch8", 0, 65535, 0, world)
         assert (g["per_launch"], g["launches"], g["frames_per_step"], g["ring"]) == (share, 1, share, 64)
     assert bench.geometry("4k-batch8", 0, 65535, 0, 1, 2)["per_launch"] == 2  # --share: one GPU plays a rank of a 4-GPU job
+    # every default ring's INPUT is several times the 256 MB memory-side cache (a ring that fits it measures the cache)
+    for wl in bench.WORKLOADS:
+        assert bench.geometry(wl, 0, 65535)["ring_input_over_cache"] >= 2.9, wl
+    assert bench.geometry("4k", 16, 65535)["ring_input_over_cache"] < 1.0  # 16 x 12.4 MB: refused by main()
 
 
 def test_bench_placement_hunt_search():
