@@ -21,7 +21,7 @@ python tools/placement_hunt.py 6 256 > $O/placement_hunt.txt 2>&1
 python tools/bench_encode.py --frames-per-launch 1 > $O/bench_encode_single.json 2>/dev/null
 tools/bench_paths.sh > $O/bench_paths.txt 2>&1
 python tools/stream_bench.py > $O/stream_bench.txt 2>&1
-{ python tools/bench_alpha11.py; PER_LAUNCH=32 python tools/bench_alpha11.py; python tools/bench_half_alpha.py 7680 4320 8 1; python tools/bench_half_alpha.py 7680 4320 8 0; python tools/bench_half_alpha.py 3840 2160 16 1; } > $O/bench_alpha.txt 2>&1
+{ python tools/bench_alpha11.py - 256 4; PER_LAUNCH=32 python tools/bench_alpha11.py - 256 4; python tools/bench_half_alpha.py 7680 4320 8 1; python tools/bench_half_alpha.py 7680 4320 8 0; python tools/bench_half_alpha.py 3840 2160 16 1; } > $O/bench_alpha.txt 2>&1
 tools/profile_gpu.sh 4k > /dev/null 2>&1
 tools/profile_gpu.sh 1080p --workload 1080p > /dev/null 2>&1
 # the sRGB-mode (arithmetic quantiser) and alpha variants of the 1:1 kernel: one kernel trace of tools/bench_alpha11.py holds all five decoders
