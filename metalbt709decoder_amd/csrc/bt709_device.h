@@ -194,7 +194,28 @@ __device__ __forceinline__ void stage_table(void *lds, const void *src, uint32_t
   u32x4 *d = reinterpret_cast<u32x4 *>(lds);
   const u32x4 *s = reinterpret_cast<const u32x4 *>(src);
   const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
-  for (uint32_t i = tid; i < bytes / 16; i += nthreads) d[i] = s[i];
+  const uint32_t n = bytes / 16;
+  if (n <= nthreads) {  // uniform: the 4 KiB table of the Apple mode, one load and one write per lane (the loop form: its code is what was tuned)
+    for (uint32_t i = tid; i < n; i += nthreads) d[i] = s[i];
+    return;
+  }
+  // Large tables (the LINEAR mode's 4 096 buckets = 33 KiB: five rounds for 512 lanes): all of a lane's loads are issued
+  // before its first write.  As a plain loop every round was its own L2 round trip inside the workgroup's lifetime
+  // (SQ_WAIT_INST_LDS 442 M against 33 M cycles per launch for the 4 KiB table, +28 % wave cycles; round 3).
+  constexpr int kBatch = 5;
+  for (uint32_t base = tid; base < n; base += nthreads * kBatch) {
+    u32x4 v[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const uint32_t i = base + static_cast<uint32_t>(k) * nthreads;
+      if (i < n) v[k] = s[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const uint32_t i = base + static_cast<uint32_t>(k) * nthreads;
+      if (i < n) d[i] = v[k];
+    }
+  }
 }
 
 // Frame bytes are touched exactly once: stream them past the caches (measured +1.3 % on 4K)

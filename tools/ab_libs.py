@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--in-pad", type=int, default=0, help="bytes added to the spacing of the input frames")
     ap.add_argument("--out-pad", type=int, default=0, help="bytes added to the spacing of the output frames")
     ap.add_argument("--out-shift", type=int, default=0, help="bytes the first output frame sits behind the start of its slab")
+    ap.add_argument("--gamma", type=int, default=0, help="MetalBT709Gamma of every decoder: 0 Apple, 1 sRGB, 2 Linear, 3 ITU-709")
     ap.add_argument("--decoder-option", action="append", default=[], metavar="K=V")
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()
@@ -59,7 +60,7 @@ def main():
         h = C.c_void_p()
         ok(lib, lib.bt709hip_context_create(0, C.byref(h)))
         d = C.c_void_p()
-        ok(lib, lib.bt709hip_decoder_create(h, 0, 0, C.byref(d)))
+        ok(lib, lib.bt709hip_decoder_create(h, args.gamma, 0, C.byref(d)))
         ok(lib, lib.bt709hip_decoder_setup(d))
         for kv in args.decoder_option + [x for x in own.split(",") if x]:
             k, v = kv.split("=")
@@ -93,7 +94,7 @@ def main():
     frames, surfs = (Frame * RING)(), (Surface * RING)()
     for i in range(RING):
         b = d_in.value + i * in_stride
-        frames[i] = Frame(b, W, b + yb, W, W, H, 1, 1)
+        frames[i] = Frame(b, W, b + yb, W, W, H, 1, {0: 1, 1: 2, 2: 3, 3: 1}[args.gamma])
         surfs[i] = Surface(d_out.value + i * out_stride, W * 4, W, H)
     per = args.per_launch
 
