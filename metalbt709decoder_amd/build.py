@@ -20,7 +20,7 @@ ASM = os.path.join(HERE, "build", "bt709_kernels.s")  # decode + rescale + encod
 SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_rgba16f.hip", "bt709_encode.hip", "bt709_planes.hip", "bt709hip.cpp",
            "transfer_tables.cpp"]
 KERNEL_SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_rgba16f.hip", "bt709_encode.hip"]
-HEADERS = ["bt709_kernels.h", "bt709_device.h", "bt709_constants.h", "bt709_quantise.h", "transfer_tables.h"]
+HEADERS = ["bt709_kernels.h", "bt709_device.h", "bt709_constants.h", "bt709_quantise.h", "bt709_stage.h", "transfer_tables.h"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: hipcc otherwise pairs scalar f32 multiplies/adds into v_pk_* ops, which run
 # at half rate on gfx950 and need v_mov shuffles to build their operand pairs (measured: 458 VALU

@@ -40,6 +40,7 @@
 #include "bt709_constants.h"
 #include "bt709_kernels.h"
 #include "bt709_quantise.h"
+#include "bt709_stage.h"
 
 namespace bt709 {
 namespace {

@@ -43,6 +43,7 @@
 
 #include "bt709_constants.h"
 #include "bt709_kernels.h"
+#include "bt709_stage.h"
 
 namespace bt709 {
 namespace {
@@ -163,7 +164,7 @@ __device__ __forceinline__ EncodeLds stage_encode_tables(unsigned char *lds_raw,
   // (The first version staged a uniform 33 KiB BT709_from_linear table here -- ten dependent L2
   // round trips per workgroup -- and a version that left it in global memory was bound by the
   // 64-line gathers; the two-resolution table is 6-10 KiB.)
-  for (uint32_t i = threadIdx.x; i < nb + nf; i += blockDim.x) d[i] = i < nb ? sb[i] : sf[i - nb];
+  stage_batched(d, nb + nf, threadIdx.x, blockDim.x, [&](uint32_t i) { return i < nb ? sb[i] : sf[i - nb]; });
   EncodeLds t;
   if (static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)lds_raw)) != 0u)
     __builtin_trap();

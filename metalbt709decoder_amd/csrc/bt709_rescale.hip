@@ -60,7 +60,7 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
   const u32x4 *src = reinterpret_cast<const u32x4 *>(p.table_linear);
   const uint32_t n = (p.table_linear_bytes / 16) << r1;
-  for (uint32_t i = tid; i < n; i += nthreads) d[i] = src[i >> r1];
+  stage_batched(d, n, tid, nthreads, [&](uint32_t i) { return src[i >> r1]; });
   const uint32_t dec_bytes = p.table_linear_bytes << r1;
   u32x2 *d2 = reinterpret_cast<u32x2 *>(lds_raw + dec_bytes);
   const u32x2 *src2 = reinterpret_cast<const u32x2 *>(UNIFORM_ENCODE ? p.table_encode_u : p.table_encode);
@@ -68,13 +68,13 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   if (UNIFORM_ENCODE) {
     // edges move into the domain of the taps' sum: edge * 4 * 2^-40 (a power of two: exact; +inf stays +inf)
     const float to_sum = __uint_as_float(static_cast<uint32_t>(127 + sum_log2 + kLinearScaleLog2) << 23);
-    for (uint32_t i = tid; i < n2; i += nthreads) {
+    stage_batched(d2, n2, tid, nthreads, [&](uint32_t i) {
       u32x2 e = src2[i >> r2];
       e.x = __float_as_uint(__fmul_rn(__uint_as_float(e.x), to_sum));
-      d2[i] = e;
-    }
+      return e;
+    });
   } else {
-    for (uint32_t i = tid; i < n2; i += nthreads) d2[i] = src2[i >> r2];
+    stage_batched(d2, n2, tid, nthreads, [&](uint32_t i) { return src2[i >> r2]; });
   }
 
   const uint32_t base = lds_address(lds_raw);
@@ -831,8 +831,7 @@ render_scaled(const RenderParams p) {
     const u32x4 *e = reinterpret_cast<const u32x4 *>(p.table_encode);
     const u32x4 *l = reinterpret_cast<const u32x4 *>(p.table_lin);
     const uint32_t ne = p.table_encode_bytes / 16;
-    for (uint32_t i = tid; i < ne; i += n) d[i] = e[i];
-    for (uint32_t i = tid; i < 64; i += n) d[ne + i] = l[i];
+    stage_batched(d, ne + 64u, tid, n, [&](uint32_t i) { return i < ne ? e[i] : l[i - ne]; });  // one batch: both tables' loads in flight together
   }
   __syncthreads();
   RescaleLookup r = {};
