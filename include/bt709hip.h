@@ -233,7 +233,7 @@ typedef enum {
   BT709HIP_OPT_HALF_KERNEL = 2,      /* 2:1 rescale: -1 (default) persistent kernel when the launch is large enough, 0 never, 1 always */
   BT709HIP_OPT_HALF_WORKGROUPS = 3,  /* persistent 2:1 kernel: workgroups; 0 (default) = one per compute unit */
   BT709HIP_OPT_HALF_LDS_KB = 4,      /* persistent 2:1 kernel: KiB of LDS a workgroup may fill with table copies; 0 (default) = 160 */
-  BT709HIP_OPT_XCD_BANDS = 5         /* 1 (default): batched 1:1 launches of a multiple of 8 frames give each XCD a contiguous band of the frames; 0: plain (tile, row pair, frame) order */
+  BT709HIP_OPT_XCD_BANDS = 5         /* 1 (default): batched 1:1 launches of 64 frames or more give each XCD a contiguous band of the frames (a count that is not a multiple of 8: that map over the multiple of 8, the plain map over the rest); 0: plain (tile, row pair, frame) order */
 } bt709hip_decoder_option;
 int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value);
 int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *value);

@@ -379,6 +379,19 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
 #else
   const size_t lds = quant ? 0 : p_in.table_unit_bytes;
 #endif
+  if (variant == kVariantQuads && xcd_bands && p_in.uniform && frames > kXcdBandMinFrames && frames % 8 != 0) {
+    // a long launch of a frame count that is not a multiple of 8: the XCD-aware map over the multiple of 8, the plain map over
+    // the (up to 7) frames left, back to back on the stream
+    const int head = frames - frames % 8;
+    launch_decode(p_in, head, variant, has_alpha, quantiser, nontemporal, xcd_bands, grid_x, block_threads, stream);
+    DecodeParams tail = p_in;
+    FramePlanes &f = tail.frames[0];
+    f.y += static_cast<int64_t>(head) * tail.step_y;
+    f.cbcr += static_cast<int64_t>(head) * tail.step_cbcr;
+    if (f.alpha) f.alpha += static_cast<int64_t>(head) * tail.step_alpha;
+    f.out += static_cast<int64_t>(head) * tail.step_out;
+    return launch_decode(tail, frames - head, variant, has_alpha, quantiser, nontemporal, 0, grid_x, block_threads, stream);
+  }
   if (variant == kVariantQuads) {
     // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
     const uint32_t by = quads_rows_per_block(block_threads, grid_x);

@@ -349,9 +349,10 @@ def test_frame_sharder_four_lanes_on_one_device(gh, oracle):
 
 @pytest.mark.parametrize("case", [((3840, 8), 64, False), ((7680, 4), 72, False), ((1920, 12), 80, False), ((328, 10), 64, False),
                                   ((640, 6), 64, True), ((640, 6), 64, False, "sRGB"), ((644, 6), 72, False, "Linear"),
-                                  ((1280, 4), 64, False, "ITU709")])
+                                  ((1280, 4), 64, False, "ITU709"), ((640, 6), 70, False), ((328, 6), 77, True)])
 def test_xcd_band_work_map(gh, oracle, case):
-    """Launches of a multiple of 8 frames, 64 or more, use the XCD-aware work map (grid.x = 8 x tiles; each XCD class owns a
+    """Launches of a multiple of 8 frames, 64 or more, use the XCD-aware work map (a longer launch of any other count: the map over the multiple
+    of 8 and the plain map over the rest, two launches) (grid.x = 8 x tiles; each XCD class owns a
     contiguous band of the launch's frames; the frames sit evenly spaced in one slab, as a ring does): every frame distinct, one / two tiles per row, stacked row pairs, an alpha decoder;
     same bytes as the oracle and as the plain map (BT709HIP_OPT_XCD_BANDS = 0), nothing written outside the rows."""
     from metalbt709decoder_amd.decoder import DeviceBuffer
