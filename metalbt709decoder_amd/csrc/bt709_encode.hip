@@ -277,6 +277,16 @@ encode_bgra_nv12_blocks(const EncodeParams p) {
 }
 
 const char *launch_encode(const EncodeParams &params, int frames, bool fast, bool xcd_bands, hipStream_t stream) {
+  if (fast && xcd_bands && params.uniform && frames > kXcdBandMinFrames && frames % 8 != 0) {
+    // any count of 64 pictures or more: the XCD-aware map over the multiple of 8, the plain map over the rest (launch_decode)
+    const int head = frames - frames % 8;
+    launch_encode(params, head, fast, xcd_bands, stream);
+    EncodeParams tail = params;
+    tail.frames[0].bgra += static_cast<int64_t>(head) * tail.step_bgra;
+    tail.frames[0].y += static_cast<int64_t>(head) * tail.step_y;
+    tail.frames[0].cbcr += static_cast<int64_t>(head) * tail.step_cbcr;
+    return launch_encode(tail, frames - head, fast, false, stream);
+  }
   EncodeParams p = params;
   if (p.row_pairs_per_block == 0) p.row_pairs_per_block = encode_row_pairs_per_block(p.width, p.height, frames);
   const size_t lds = 256 * sizeof(EncodeByteEntry) + p.from_linear_bytes;

@@ -180,6 +180,18 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
 
 const char *launch_decode_rgba16f(const DecodeParams &p_in, const HalfParams &hp_in, int frames, bool has_alpha,
                                   uint32_t in_align, uint32_t out_align, uint32_t compute_units, bool xcd_bands, hipStream_t stream) {
+  if (xcd_bands && p_in.uniform && frames > kXcdBandMinFrames && frames % 8 != 0) {
+    // any count of 64 frames or more: the XCD-aware map over the multiple of 8, the plain map over the rest (launch_decode)
+    const int head = frames - frames % 8;
+    launch_decode_rgba16f(p_in, hp_in, head, has_alpha, in_align, out_align, compute_units, xcd_bands, stream);
+    DecodeParams tail = p_in;
+    FramePlanes &f = tail.frames[0];
+    f.y += static_cast<int64_t>(head) * tail.step_y;
+    f.cbcr += static_cast<int64_t>(head) * tail.step_cbcr;
+    if (f.alpha) f.alpha += static_cast<int64_t>(head) * tail.step_alpha;
+    f.out += static_cast<int64_t>(head) * tail.step_out;
+    return launch_decode_rgba16f(tail, hp_in, frames - head, has_alpha, in_align, out_align, compute_units, false, stream);
+  }
   HalfParams hp = hp_in;
   DecodeParams p = p_in;
   const uint32_t blocks = p.width / 2, row_pairs = p.height / 2;

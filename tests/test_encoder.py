@@ -222,10 +222,9 @@ def test_gpu_encoder_batch_matches_single(gh, oracle):
         want = oracle.encode_nv12(p & 0xFFFFFF, w, h, 1, 0)
         got = b.download_planes()
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-    # 64 pictures (a multiple of 8, at the threshold): the XCD-aware work map; same bytes as the plain order
-    for bands in (1, 0):
+    # 64 pictures (a multiple of 8, at the threshold): the XCD-aware work map; 70: 64 under the map + 6 plain; same bytes as the plain order
+    for bands, n64 in ((1, 64), (0, 64), (1, 70)):
         _capi.check(ctx.lib.bt709hip_context_set_option(ctx.handle, _capi.CTX_OPT_XCD_BANDS, bands))
-        n64 = 64
         s_in, s_out = DeviceBuffer(ctx, n64 * in_pitch), DeviceBuffer(ctx, n64 * out_pitch)
         pics64 = [rng.integers(0, 1 << 32, w * h, dtype=np.uint32) for _ in range(n64)]
         t64, b64 = [], []

@@ -182,12 +182,13 @@ def test_gpu_rgba16f_batch_4k(gh, oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_rgba16f_xcd_band_work_map(gh, oracle):
-    """72 evenly spaced frames in one launch (a multiple of 8, past the threshold): the XCD-aware work map of the
-    RGBA16Float kernel against the plain order and the oracle."""
+@pytest.mark.parametrize("n", [72, 77])
+def test_gpu_rgba16f_xcd_band_work_map(gh, oracle, n):
+    """72 evenly spaced frames in one launch (a multiple of 8, past the threshold), and 77 (72 under the map + 5 plain): the
+    XCD-aware work map of the RGBA16Float kernel against the plain order and the oracle."""
     from metalbt709decoder_amd.decoder import DeviceBuffer
     ctx = gh.context()
-    n, w, h = 72, 128, 8
+    w, h = 128, 8
     in_pitch, out_pitch = w * h * 3 // 2, w * h * 8
     slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
     frames = [_frame(w, h, 500 + i) for i in range(n)]
