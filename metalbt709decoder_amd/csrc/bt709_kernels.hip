@@ -103,11 +103,8 @@ __global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_quads(const DecodeParams p) {
   constexpr int UNROLL = kQuadsPerLane;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-#if defined(BT709_LAB_PRIO_LOADS)  // tools/ab_prio.sh: a new wave's address arithmetic and loads ahead of the resident waves' arithmetic (-5 %)
-  __builtin_amdgcn_s_setprio(3);
-#endif
 
-  // XCD-AWARE WORK MAP (p.xcd_bands; launches whose frame count is a multiple of 8).  Workgroups are dealt round-robin
+  // XCD-AWARE WORK MAP (p.xcd_bands; launches of 64 frames or more, in multiples of 8: launch_decode).  Workgroups are dealt round-robin
   // over the 8 XCDs in dispatch order, so with the plain map (tile, row pair, frame) XCD k owns the tile rows = k mod 8 of
   // ONE address stream -- and an XCD that runs a few percent ahead of another (they sit at different distances from
   // the HBM stacks) widens the band of rows in flight for the whole launch: measured, the longer a launch, the slower
@@ -126,13 +123,7 @@ decode_nv12_quads(const DecodeParams p) {
   // waves, so threadIdx.y is the same in every lane of a wave: taking it from the first lane
   // makes the row pointers scalar (SGPR base + per-lane offset addressing, no 64-bit VALU
   // address arithmetic).
-#if defined(BT709_LAB_BAND_STAGGER)  // lab: band b starts BT709_LAB_BAND_STAGGER workgroup rows further down each of its frames (and wraps)
-  uint32_t by = blockIdx.y + (p.xcd_bands == 1 ? (blockIdx.x & 7u) * (BT709_LAB_BAND_STAGGER) : 0u);
-  if (by >= gridDim.y) by -= gridDim.y;
-#else
-  const uint32_t by = blockIdx.y;
-#endif
-  const uint32_t rp_raw = by * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const uint32_t rp_raw = blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
   const uint32_t rp = min(rp_raw, row_pairs - 1);
   // quad u of this lane: consecutive lanes own consecutive quads (a store instruction must fill whole
   // lines: a lane owning ADJACENT quads measured 3x slower, tools/lab_quads_variants.hip)
@@ -150,22 +141,11 @@ decode_nv12_quads(const DecodeParams p) {
   // s_waitcnt vmcnt(0) at the join, i.e. each wave waited for the write acknowledgement of its
   // first quad's stores before touching its second quad.
   uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
-#if defined(BT709_LAB_READ_WINDOW_MASK)  // lab: loads only in chip-wide time windows (s_memrealtime counts 10 ns ticks, the same on every XCD)
-  while ((static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) & (BT709_LAB_READ_WINDOW_MASK)) >= (BT709_LAB_READ_WINDOW_OPEN)) __builtin_amdgcn_s_sleep(2);
-#endif
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = min((q0 + u * blockDim.x), quads - 1);
 #if defined(BT709_LAB_NO_LOADS)  // lab, with BT709_LAB_NO_ARITH: the launch's stores alone
     ya[u] = q * 3u, yb[u] = q * 5u, cw[u] = q * 7u + rp;
-#elif defined(BT709_LAB_LOAD_AUX)  // lab: the loads as raw buffer loads with this cache-policy operand (1 sc0, 2 nt, 16 sc1)
-    {
-      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(f.y), 0, 0x7fffffff, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(f.cbcr), 0, 0x7fffffff, 0x00020000);
-      ya[u] = __builtin_amdgcn_raw_buffer_load_b32(ry, 4 * q, static_cast<int>(2 * rp * p.y_stride), BT709_LAB_LOAD_AUX);
-      yb[u] = __builtin_amdgcn_raw_buffer_load_b32(ry, 4 * q, static_cast<int>((2 * rp + 1) * p.y_stride), BT709_LAB_LOAD_AUX);
-      cw[u] = __builtin_amdgcn_raw_buffer_load_b32(rc, 4 * q, static_cast<int>(rp * p.cbcr_stride), BT709_LAB_LOAD_AUX);
-    }
 #else
     ya[u] = load32<NT>(y0 + 4 * q);
     yb[u] = load32<NT>(y1 + 4 * q);
@@ -176,15 +156,6 @@ decode_nv12_quads(const DecodeParams p) {
       ab[u] = load32<NT>(a0 + p.alpha_stride + 4 * q);
     }
   }
-#if defined(BT709_LAB_PRIO_LOADS)
-  __builtin_amdgcn_s_setprio(0);
-#endif
-#if defined(BT709_LAB_PRIO_STORES)  // lab: the other way round: a wave that has its data finishes ahead of younger ones
-  __builtin_amdgcn_s_setprio(BT709_LAB_PRIO_STORES);
-#endif
-#if defined(BT709_LAB_SLEEP_AFTER_LOADS)  // lab: every wave idles this many x 64 cycles with its loads in flight (a slower kernel drifts less on the plain map)
-  __builtin_amdgcn_s_sleep(BT709_LAB_SLEEP_AFTER_LOADS);
-#endif
 #if !defined(BT709_LAB_NO_TABLE)  // lab, with BT709_LAB_NO_ARITH: without the per-workgroup table staging and its barrier too
   if (!QUANT) {  // the sRGB mode needs no table (decode_quad)
     stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
@@ -212,22 +183,13 @@ decode_nv12_quads(const DecodeParams p) {
     decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
                            bot);
 #endif
-#if defined(BT709_LAB_WRITE_WINDOW_MASK)  // lab: stores only outside the read windows
-    while ((static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) & (BT709_LAB_WRITE_WINDOW_MASK)) < (BT709_LAB_WRITE_WINDOW_CLOSED)) __builtin_amdgcn_s_sleep(2);
-#endif
 #if defined(BT709_LAB_NO_STORES)  // lab, with BT709_LAB_NO_ARITH: the launch's loads alone (a store about once in 2^32 quads keeps them alive)
     if (q < quads && rp_raw < row_pairs && (top.w ^ bot.w) == 0x9e3779b9u) {
 #else
     if (q < quads && rp_raw < row_pairs) {
 #endif
-#if defined(BT709_LAB_STORE_AUX)  // lab: the stores as raw buffer stores with this cache-policy operand (1 sc0, 2 nt, 16 sc1)
-      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(f.out, 0, 0x7fffffff, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b128(top, ro, 16 * q, static_cast<int>(2 * rp * p.out_stride), BT709_LAB_STORE_AUX);
-      __builtin_amdgcn_raw_buffer_store_b128(bot, ro, 16 * q, static_cast<int>((2 * rp + 1) * p.out_stride), BT709_LAB_STORE_AUX);
-#else
       store16<NT>(o0 + 16 * q, top);
       store16<NT>(o1 + 16 * q, bot);
-#endif
     }
   }
 }
@@ -374,11 +336,7 @@ const char *launch_unconvert(const DecodeParams &t, const void *in, size_t in_st
 const char *launch_decode(const DecodeParams &p_in, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
                           int xcd_bands, uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
   const bool quant = quantiser || has_alpha;  // the sRGB mode: arithmetic, no table
-#if defined(BT709_LAB_LDS_KB)  // lab: claim this much LDS per workgroup = cap the workgroups per CU (160 KiB each)
-  const size_t lds = BT709_LAB_LDS_KB * 1024;
-#else
   const size_t lds = quant ? 0 : p_in.table_unit_bytes;
-#endif
   if (variant == kVariantQuads && xcd_bands && p_in.uniform && frames > kXcdBandMinFrames && frames % 8 != 0) {
     // a long launch of a frame count that is not a multiple of 8: the XCD-aware map over the multiple of 8, the plain map over
     // the (up to 7) frames left, back to back on the stream

@@ -134,24 +134,15 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
     }
     return v;
   };
-#if defined(BT709_LAB_RGBA16F_DEPTH2)  // lab: two row pairs ahead
-  PairIn cur = fetch(rp0), nxt = fetch(min(rp0 + 1, rp1 - 1));
-  for (uint32_t rp = rp0; rp < rp1; ++rp) {
-    const PairIn nxt2 = fetch(min(rp + 2, rp1 - 1));
-#else
   PairIn cur = fetch(rp0);
   for (uint32_t rp = rp0; rp < rp1; ++rp) {
     PairIn nxt = cur;
     if (rp + 1 < rp1) nxt = fetch(rp + 1);  // uniform branch
-#endif
     float yv[4], cb, cr, av[4] = {0.f, 0.f, 0.f, 0.f};
     yv[0] = byte_of(cur.ya, 0), yv[1] = byte_of(cur.ya, 1), yv[2] = byte_of(cur.yb, 0), yv[3] = byte_of(cur.yb, 1);
     cb = byte_of(cur.cc, 0), cr = byte_of(cur.cc, 1);
     if (HAS_ALPHA) av[0] = byte_of(cur.aa, 0), av[1] = byte_of(cur.aa, 1), av[2] = byte_of(cur.ab, 0), av[3] = byte_of(cur.ab, 1);
     cur = nxt;
-#if defined(BT709_LAB_RGBA16F_DEPTH2)
-    nxt = nxt2;
-#endif
     const Chroma c = chroma_terms(cb, cr);
     uint32_t w[8];  // per pixel {R | G << 16, B | A << 16}
 #pragma unroll

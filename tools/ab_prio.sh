@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the BT709_LAB_PRIO_* gates were removed from bt709_kernels.hip at the end of round 3 (both variants lost); check out commit f9775f7 to re-run this.
 # Same-call A/B of s_setprio placements in the short-lived 1:1 kernel (variant libraries built with
 # python -m metalbt709decoder_amd.build --variant tools/bin/libbt709hip_prio_*.so BT709_LAB_PRIO_LOADS | BT709_LAB_PRIO_STORES=n)
 cd "${GRAFT_REPO_ROOT:-.}"
