@@ -825,22 +825,25 @@ template <bool IN_RGBA16F>
 __global__ void __launch_bounds__(kBlockThreads)
 render_scaled(const RenderParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  {  // stage: encode buckets | lin[256]
+  {  // stage: lin[256] | encode buckets.  lin[] sits at LDS address 0 (this kernel has no static LDS, so its dynamic segment
+     // starts there; trapped below if that ever changes): a texel's byte then becomes its table address by ONE SDWA shift.
     const uint32_t tid = threadIdx.x, n = blockDim.x;
     u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
     const u32x4 *e = reinterpret_cast<const u32x4 *>(p.table_encode);
     const u32x4 *l = reinterpret_cast<const u32x4 *>(p.table_lin);
     const uint32_t ne = p.table_encode_bytes / 16;
-    stage_batched(d, ne + 64u, tid, n, [&](uint32_t i) { return i < ne ? e[i] : l[i - ne]; });  // one batch: both tables' loads in flight together
+    stage_batched(d, ne + 64u, tid, n, [&](uint32_t i) { return i < 64u ? l[i] : e[i - 64u]; });  // one batch: both tables' loads in flight together
+    if (lds_address(lds_raw) != 0u) __builtin_trap();
   }
   __syncthreads();
   RescaleLookup r = {};
   r.enc_shift = 3;
-  r.enc_off = lds_address(lds_raw);
+  r.enc_off = 1024u;  // behind lin[256]
   r.split_offset = p.encode_offset;
   r.split_shift = p.encode_shift;
-  const uint32_t lin_off = lds_address(lds_raw + p.table_encode_bytes);
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
+  uint32_t two = 2u;  // SDWA operands cannot be inline constants
+  asm("" : "+v"(two));
 
   const uint32_t oy0 = blockIdx.y * p.rows, oy1 = min(oy0 + p.rows, p.out_height);
   const StripTaps vt = strip_taps(oy0, p.scale_y);  // before any lane leaves
@@ -912,9 +915,14 @@ render_scaled(const RenderParams p) {
         s[3] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(hi >> 16)));
       } else {
         const uint32_t v = f.w[t];
-        s[0] = *reinterpret_cast<LdsFloatPtr>(((v >> 14) & 0x3fcu) + lin_off);  // R: byte 2
-        s[1] = *reinterpret_cast<LdsFloatPtr>(((v >> 6) & 0x3fcu) + lin_off);   // G: byte 1
-        s[2] = *reinterpret_cast<LdsFloatPtr>(((v << 2) & 0x3fcu) + lin_off);   // B: byte 0
+        // lin[byte]: byte select and << 2 in one v_lshlrev_b32_sdwa (the encoder's form, bt709_encode.hip byte_entry)
+        uint32_t ar, ag, ab;
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(ar) : "v"(two), "v"(v));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ag) : "v"(two), "v"(v));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(ab) : "v"(two), "v"(v));
+        s[0] = *reinterpret_cast<LdsFloatPtr>(ar);  // R: byte 2
+        s[1] = *reinterpret_cast<LdsFloatPtr>(ag);  // G: byte 1
+        s[2] = *reinterpret_cast<LdsFloatPtr>(ab);  // B: byte 0
         s[3] = __fmul_rn(byte_of(v, 3), kInv255);                                // byteNorm
       }
     }
