@@ -52,9 +52,52 @@ __global__ void __launch_bounds__(kThreads) phase_lab(const u32x4 *in, u32x4 *ou
   if (acc.x == 0x12345678u && acc.y == 0x9e3779b9u) out[0] = acc;  // keeps everything alive
 }
 
+// Wave-specialised form: a 1024-lane workgroup, waves 0-7 only LOAD (global -> LDS, chunk k + 1), waves 8-15 only STORE (LDS -> global,
+// chunk k), one barrier per step, two 64 KiB LDS buffers: a wave's loads never queue behind stores.
+__global__ void __launch_bounds__(1024) phase_lab_split(const u32x4 *in, u32x4 *out, uint32_t iters, int mode, uint32_t period, uint32_t rd, int banded) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  u32x4 *lds = reinterpret_cast<u32x4 *>(lds_raw);  // [2][kLoads][512]
+  const uint32_t wg = blockIdx.x, nwg = gridDim.x, tid = threadIdx.x;
+  const bool loader = tid < 512;
+  const uint32_t lane = tid & 511u;
+  auto chunk_of = [&](uint32_t it) {
+    return banded ? static_cast<size_t>(wg & 7u) * (static_cast<size_t>(iters) * (nwg >> 3)) + static_cast<size_t>(it) * (nwg >> 3) + (wg >> 3)
+                  : static_cast<size_t>(it) * nwg + wg;
+  };
+  for (uint32_t step = 0; step <= iters; ++step) {
+    if (loader) {
+      if (step < iters) {
+        const u32x4 *src = in + chunk_of(step) * (kLoads * 512) + lane;
+        if (mode == 1)
+          while (static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) % period >= rd) __builtin_amdgcn_s_sleep(1);
+        u32x4 v[kLoads];
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) v[k] = __builtin_nontemporal_load(src + k * 512);
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) lds[((step & 1u) * kLoads + k) * 512 + lane] = v[k];
+      }
+    } else if (step > 0) {
+      u32x4 *dst = out + chunk_of(step - 1) * (kStores * 512) + lane;
+      u32x4 v[kLoads];
+#pragma unroll
+      for (int k = 0; k < kLoads; ++k) v[k] = lds[(((step - 1) & 1u) * kLoads + k) * 512 + lane];
+      if (mode == 1)
+        while (static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) % period < rd) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int k = 0; k < kStores; ++k) {
+        u32x4 w = v[k % kLoads];
+        w.x ^= static_cast<uint32_t>(k);
+        __builtin_nontemporal_store(w, dst + k * 512);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 int main(int argc, char **argv) {
   const int wg_per_cu = argc > 1 ? std::atoi(argv[1]) : 2;
   const int banded = argc > 2 ? std::atoi(argv[2]) : 1;
+  const int split = argc > 3 ? std::atoi(argv[3]) : 0;  // 1: the wave-specialised form (one 1024-lane workgroup = 512 loading + 512 storing lanes)
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const uint32_t nwg = static_cast<uint32_t>(prop.multiProcessorCount * wg_per_cu);
@@ -69,7 +112,8 @@ int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const double bytes = static_cast<double>(iters) * in_per_iter * (kLoads + kStores) / kLoads;
-  std::printf("%s map, %u workgroups x %d lanes, %u iterations, %.2f GB read + %.2f GB written per launch (%.0f %% reads)\n", banded ? "XCD-aware" : "plain", nwg, kThreads, iters,
+  if (split) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_lab_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  std::printf("%s%s map, %u workgroups x %d lanes, %u iterations, %.2f GB read + %.2f GB written per launch (%.0f %% reads)\n", split ? "wave-specialised, " : "", banded ? "XCD-aware" : "plain", nwg, kThreads, iters,
               iters * in_per_iter / 1e9, iters * in_per_iter * double(kStores) / kLoads / 1e9, 100.0 * kLoads / (kLoads + kStores));
   struct Cfg {
     int mode;
@@ -86,10 +130,14 @@ int main(int argc, char **argv) {
     }
   cfgs.push_back({0, 0, 0});
   for (const Cfg &c : cfgs) {
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(phase_lab, dim3(nwg), dim3(kThreads), 0, nullptr, in, out, iters, c.mode, c.period ? c.period : 1u, c.rd, banded);
+    auto launch = [&]() {
+      if (split) hipLaunchKernelGGL(phase_lab_split, dim3(nwg), dim3(1024), 2 * kLoads * 512 * 16, nullptr, in, out, iters, c.mode, c.period ? c.period : 1u, c.rd, banded);
+      else hipLaunchKernelGGL(phase_lab, dim3(nwg), dim3(kThreads), 0, nullptr, in, out, iters, c.mode, c.period ? c.period : 1u, c.rd, banded);
+    };
+    for (int w = 0; w < 2; ++w) launch();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, nullptr));
-    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(phase_lab, dim3(nwg), dim3(kThreads), 0, nullptr, in, out, iters, c.mode, c.period ? c.period : 1u, c.rd, banded);
+    for (int r = 0; r < 3; ++r) launch();
     CK(hipEventRecord(e1, nullptr));
     CK(hipEventSynchronize(e1));
     float ms = 0;
