@@ -473,6 +473,72 @@ def hunt_pairing(n_in, n_out, probe, exhaustive_up_to=36):
     return bi, bo
 
 
+def self_launch(n, argv, timeout_s=None):
+    """`python3 bench.py --gpus N` from ONE plain command (the reference is one process that drives everything,
+    Renderer/AAPLRenderer.m:874-985; its N-GPU counterpart must start from one command too).  Called when WORLD_SIZE is unset
+    and N > 1, BEFORE the product library, torch or any GPU has been touched by this process: it starts N fresh child
+    processes of this same script -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set exactly
+    as torch.distributed.run sets them -- relays rank 0's stdout (the single JSON line) and every rank's stderr, and returns
+    non-zero if any rank fails (the others are then ended by their exact PIDs).  No os.exec*: a child is a child."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   GROUP_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BT709_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        # rank 0 owns this process's stdout (ONE JSON line); the other ranks print nothing there, whatever they do print
+        # is kept apart on stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+
+    def relay():  # rank 0's JSON line(s) to stdout, anything else it prints there to stderr
+        for raw in procs[0].stdout:
+            line = raw.decode("utf-8", "replace")
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+    import threading
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    deadline = None if not timeout_s else time.time() + timeout_s
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with %d; ending the other ranks\n" % (r, code))
+            if rc != 0 or (deadline and time.time() > deadline):
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        for p in procs:  # exact PIDs, never a pattern
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        pump.join(timeout=5)
+    return rc
+
+
 def smooth_frame(np, rng, g, i):
     """Video-like synthetic frame: low-frequency luma/chroma fields plus +-2 noise, video-legal range."""
     W, H = g["W"], g["H"]
@@ -514,11 +580,11 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python3 bench.py --gpus N`: this process becomes the launcher of N ranks and never touches a GPU
+        sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world  # under torch.distributed.run the launcher's world size is authoritative
 
     dist = None
     if world > 1:
@@ -527,7 +593,18 @@ def main(argv=None):
         # torch is imported BEFORE the product library so the process holds one HIP runtime.
         import torch  # noqa: F401
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on the C++ stdout ("[Gloo] Rank 0 is connected to ..."): this process's stdout
+        # carries ONE JSON line and nothing else, so file descriptor 1 points at stderr while the group is formed
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     g = geometry(args.workload, args.ring, 65535, args.frames_per_launch, world, args.share)
     if g["ring_input_over_cache"] < 2.0 and not args.dry_run:
@@ -609,6 +686,8 @@ def main(argv=None):
             "frames_per_step_per_gpu": g["frames_per_step"],
             "streams": getattr(runner, "nstreams", 1),
             "sharding": "independent frames per GPU, no collective",
+            "launcher": ("self (bench.py started its %d ranks)" % world if os.environ.get("BT709_BENCH_SELF_LAUNCHED")
+                         else "torch.distributed.run" if world > 1 else "single process"),
             "placement": getattr(runner, "placement", None),  # ring allocated `tries` times, the fastest-streaming one kept (untimed set-up)
             "device": runner.device,
             "arch": runner.arch,

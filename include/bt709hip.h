@@ -41,7 +41,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout or a signature in this file changes.  Bindings compare
  * it with bt709hip_abi_version() so that a library older than the header is refused, not mis-called. */
-#define BT709HIP_VERSION 300
+#define BT709HIP_VERSION 400
 
 typedef struct bt709hip_context bt709hip_context; /* ~ MetalRenderContext */
 typedef struct bt709hip_decoder bt709hip_decoder; /* ~ MetalBT709Decoder  */
@@ -202,6 +202,9 @@ int bt709hip_graph_destroy(bt709hip_context *ctx, void *graph);
  * (bt709hip_host_alloc).  Pitches are bytes; `row_bytes` x `rows` is copied. */
 int bt709hip_malloc(bt709hip_context *ctx, size_t bytes, void **dptr);
 int bt709hip_free(bt709hip_context *ctx, void *dptr);
+/* Free and total device memory of the context's GPU right now (hipMemGetInfo), for callers that size rings or a placement
+ * hunt (bt709hip_malloc_streaming) against what is left.  Either pointer may be NULL. */
+int bt709hip_mem_info(bt709hip_context *ctx, size_t *free_bytes, size_t *total_bytes);
 int bt709hip_host_alloc(bt709hip_context *ctx, size_t bytes, void **hptr);
 int bt709hip_host_free(bt709hip_context *ctx, void *hptr);
 int bt709hip_memset(bt709hip_context *ctx, void *dptr, int value, size_t bytes, void *stream);
@@ -226,6 +229,8 @@ int bt709hip_decoder_set_context(bt709hip_decoder *dec, bt709hip_context *ctx);
  * (BGRAToBT709Converter.m:187-193). */
 int bt709hip_decoder_set_alpha_fill(bt709hip_decoder *dec, int alpha_byte);
 int bt709hip_decoder_get_gamma(const bt709hip_decoder *dec);
+int bt709hip_decoder_has_alpha(const bt709hip_decoder *dec);           /* 1 / 0, or <0 */
+bt709hip_context *bt709hip_decoder_context(const bt709hip_decoder *dec); /* the render context it was given, or NULL */
 /* Kernel-selection knobs of a decoder (tuning and test hooks; no reference twin).  They may be
  * changed between calls, not during one. */
 typedef enum {
@@ -233,7 +238,8 @@ typedef enum {
   BT709HIP_OPT_HALF_KERNEL = 2,      /* 2:1 rescale: -1 (default) persistent kernel when the launch is large enough, 0 never, 1 always */
   BT709HIP_OPT_HALF_WORKGROUPS = 3,  /* persistent 2:1 kernel: workgroups; 0 (default) = one per compute unit */
   BT709HIP_OPT_HALF_LDS_KB = 4,      /* persistent 2:1 kernel: KiB of LDS a workgroup may fill with table copies; 0 (default) = 160 */
-  BT709HIP_OPT_XCD_BANDS = 5         /* 1 (default): batched 1:1 launches of 64 frames or more give each XCD a contiguous band of the frames (a count that is not a multiple of 8: that map over the multiple of 8, the plain map over the rest); 0: plain (tile, row pair, frame) order */
+  BT709HIP_OPT_XCD_BANDS = 5,        /* 1 (default): batched 1:1 launches of 64 frames or more give each XCD a contiguous band of the frames (a count that is not a multiple of 8: that map over the multiple of 8, the plain map over the rest); 0: plain (tile, row pair, frame) order */
+  BT709HIP_OPT_COALESCE = 6          /* 0 (default) off; n in 2..32: coalescing submit, see bt709hip_decode */
 } bt709hip_decoder_option;
 int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value);
 int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *value);
@@ -251,6 +257,28 @@ int bt709hip_decode(bt709hip_decoder *dec,
                     const bt709hip_surface *out,
                     int render_width, int render_height,
                     void *stream, int wait_until_completed);
+
+/* COALESCING SUBMIT (extension, opt-in: bt709hip_decoder_set_option(dec, BT709HIP_OPT_COALESCE, n), n = 2..32).
+ * The reference's cadence is one -decodeBT709: call per frame (MetalBT709Decoder.h:65-72, AAPLRenderer.m:914-957), each call
+ * encoding into the caller's command buffer; on an MI355X a 4K frame is a ~7.6 us kernel and a launch boundary on one stream
+ * costs ~3.8 us of idle GPU, so that cadence reaches 0.49 of the roofline where one launch over many frames reaches 0.75-0.81.
+ * With the option on, a 1:1 decode of device-resident frames with wait_until_completed == 0 -- bt709hip_decode, or
+ * bt709hip_decode_batch with a count below n -- is VALIDATED at once (its status is the call's status, as before) but only
+ * QUEUED: up to n frames of one geometry and target format per stream gather and go out as ONE bt709hip_decode_batch launch
+ * (evenly spaced frames as a uniform batch, any others through the pointer table).  The queue of a stream is issued
+ *   - when it holds n frames, or a call with another geometry / format / decoder state arrives for that stream,
+ *   - by any bt709hip_* call that takes that stream (stream_synchronize, event_record, stream_wait_event, download, upload,
+ *     memset, graph capture, copy_probe, a decode with wait_until_completed != 0, every other decode / encode / rescale
+ *     entry point) -- so the stream keeps its order for everything issued through this API,
+ *   - by bt709hip_decoder_flush, and when the decoder is destroyed or the option is turned off.
+ * The command-buffer analogy: queued frames are "encoded, not yet committed".  What the caller gives up: work submitted to
+ * the raw hipStream_t behind this API's back (its own kernels, hipStreamSynchronize) is not ordered after queued frames --
+ * call bt709hip_decoder_flush first.  Frame and surface descriptors are copied at the call; the buffers they point to must
+ * stay alive until the stream has passed the launch, as always.  A launch failure at issue time is returned by the call that
+ * issued the queue.  Thread safety: as without the option (several threads may share a decoder; each queue is per stream). */
+int bt709hip_decoder_flush(bt709hip_decoder *dec, void *stream /* NULL = the context's default stream */);
+/* every stream's queue of this decoder */
+int bt709hip_decoder_flush_all(bt709hip_decoder *dec);
 
 /* The same operator over `count` independent frames of one geometry (same
  * width/height/strides/tags) in ONE launch: grid.z = frame.  This is how a stream of
@@ -351,6 +379,43 @@ int bt709hip_pool_wait(bt709hip_pool *pool, int slot, const void **bgra, size_t 
  * hands its slot back by itself: a slot never stays "acquired" behind an error. */
 int bt709hip_pool_release(bt709hip_pool *pool, int slot);
 
+/* --------------------------------------------------------------- frame ring */
+/* Frames that live in DEVICE memory: a ring of `frames` same-sized NV12 inputs carved from one slab and their BGRA8 outputs
+ * from another (frame i at slab + i * spacing: any count goes out as one launch, bt709hip_decode_batch's "evenly spaced"
+ * form) -- what a streaming application keeps resident, and what bench.py times.  The reference's twin is the set of
+ * CVPixelBuffers + the render texture it keeps per in-flight frame (AAPLRenderer.m:34, 530-862); unified memory has no
+ * placement to choose, a discrete HBM device does: where the two slabs land decides how fast the launch streams (the same
+ * 256-frame 4K launch runs at 0.74-0.82 of the HBM roofline on allocations made one after the other by one process, each
+ * keeping its rate).  bt709hip_ring_create therefore allocates up to `tries` candidates per slab (0 = the
+ * default, 6; 1 = first allocation, no probing; rings under 256 MB never probe), times the DECODER'S OWN LAUNCH over the ring
+ * on the pairings (~15 ms each; every output candidate under input 0 first -- twice or three times `tries` of them when they
+ * all look alike -- then every input with the `tries` fastest outputs, then the three best pairings again three times as
+ * long), keeps the fastest pairing and frees the rest.  It always leaves 4 GiB of the device free and hunts among what it
+ * could allocate.  Set-up cost: 1-2 s for a 12 GB ring.  half_scale != 0: outputs are (W/2) x (H/2) and the ring decodes
+ * through bt709hip_decode_half_batch.  A decoder with an alpha channel gets an alpha plane per frame (third plane of the
+ * input slab).  The memory is NOT cleared.  The decoder must outlive the ring. */
+typedef struct bt709hip_ring bt709hip_ring;
+typedef struct {
+  int32_t tries;                     /* candidates per slab asked for (after clamping) */
+  int32_t in_candidates;             /* input slabs allocated */
+  int32_t out_candidates;            /* output slabs allocated (up to 3 x tries) */
+  int32_t chosen_in, chosen_out;     /* allocation-order index of the slabs kept */
+  int32_t probes;                    /* pairings probed */
+  float first_GBps;                  /* probe of the first-allocated pairing (input 0, output 0): what tries = 1 keeps */
+  float chosen_GBps;                 /* the pairing kept, on the longer confirming probe */
+  float best_GBps, worst_GBps;       /* over the pairing probes */
+  float out_prescan_GBps[18];        /* output candidates under input 0, allocation order; 0 = none */
+  int32_t out_kept[18];              /* allocation-order indices of the outputs that went on to the pairing probes; -1 = none */
+} bt709hip_ring_placement;
+int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frames, int half_scale, int tries, bt709hip_ring **out);
+int bt709hip_ring_destroy(bt709hip_ring *ring);
+int bt709hip_ring_frames(const bt709hip_ring *ring);
+/* Descriptors of frame `index` (any of the three pointers may be NULL; alpha is zeroed for an opaque decoder). */
+int bt709hip_ring_frame(const bt709hip_ring *ring, int index, bt709hip_frame *frame, bt709hip_frame *alpha, bt709hip_surface *out);
+int bt709hip_ring_placement_info(const bt709hip_ring *ring, bt709hip_ring_placement *info);
+/* Frames [first, first + count) in ONE launch on `stream`. */
+int bt709hip_ring_decode(bt709hip_ring *ring, int first, int count, void *stream, int wait_until_completed);
+
 /* ------------------------------------------------------------ frame sharder */
 /* ONE process driving SEVERAL GPUs: independent frames shard with no exchange step, frame i (in submission
  * order) goes to lane i mod n.  The reference is one process with one device, one queue and N frames in
@@ -427,12 +492,14 @@ int bt709hip_deinterleave_cbcr(bt709hip_context *ctx, const void *cbcr, size_t c
  * non-temporal loads and stores, one launch: the bandwidth a plain copy reaches on this device, for
  * benchmarks that want to report a kernel against the same box's copy rate (no reference twin). */
 int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_t bytes, void *stream);
-/* Placement-aware allocation for streaming slabs (frame rings, pools).  On MI355X the rate at which a slab streams depends on
- * where it landed: allocations made one after the other by ONE process stream at 5.7-6.5 TB/s, each keeping its rate (the same
- * decode launch 0.74-0.81 of the roofline; tools/placement_hunt.py).  Allocates `tries` candidates of `bytes` (all alive until
- * the choice is made), times the streaming copy above (lower half onto upper half) plus a fill of the whole slab over each,
- * keeps the fastest and frees the rest (the memory comes back zeroed when tries > 1).  rates_GBps (optional, `tries` floats) receives the probe rates, *chosen (optional) the index kept.  tries = 1 is
- * bt709hip_malloc.  No reference twin (unified memory has no placement to choose). */
+/* Placement-aware allocation of ONE streaming slab.  Allocates `tries` candidates of `bytes` (all alive until the choice is
+ * made), times a streaming copy (lower half onto upper half) plus a fill of the whole slab over each, keeps the fastest and
+ * frees the rest; the slab kept has been overwritten by the probe (zero-filled) whenever a probe ran, and is NOT cleared
+ * otherwise (tries = 1, a slab under 2 MiB, a single candidate).  rates_GBps (optional, `tries` floats; always fully
+ * written: 0 where no probe ran) receives the probe rates, *chosen (optional) the index kept.  tries = 1 is bt709hip_malloc.
+ * This is the WEAKER, cheaper probe: it ranks a slab by itself, with a generic kernel.  A frame ring should use
+ * bt709hip_ring_create, which probes with the decoder's own launch and chooses the input x output PAIRING (worth a further
+ * 1-2 %, profiles/r03_placement_cross.txt).  No reference twin (unified memory has no placement to choose). */
 int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, void **dptr, float *rates_GBps, int *chosen);
 
 const char *bt709hip_strerror(int status);

@@ -24,7 +24,7 @@ class Surface(C.Structure):  # bt709hip_surface
                 ("format", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 300  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
+ABI_VERSION = 400  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
 
 # bt709hip_format
 FORMAT_BGRA8_SRGB = 0
@@ -36,10 +36,18 @@ OPT_HALF_KERNEL = 2
 OPT_HALF_WORKGROUPS = 3
 OPT_HALF_LDS_KB = 4
 OPT_XCD_BANDS = 5
+OPT_COALESCE = 6
 CTX_OPT_GRID_MULT = 1
 CTX_OPT_ENCODE_ROW_PAIRS = 2
 CTX_OPT_ENCODE_THREADS = 3
 CTX_OPT_XCD_BANDS = 4
+
+
+class RingPlacement(C.Structure):  # bt709hip_ring_placement
+    _fields_ = [("tries", C.c_int32), ("in_candidates", C.c_int32), ("out_candidates", C.c_int32),
+                ("chosen_in", C.c_int32), ("chosen_out", C.c_int32), ("probes", C.c_int32),
+                ("first_GBps", C.c_float), ("chosen_GBps", C.c_float), ("best_GBps", C.c_float), ("worst_GBps", C.c_float),
+                ("out_prescan_GBps", C.c_float * 18), ("out_kept", C.c_int32 * 18)]
 
 
 class DeviceInfo(C.Structure):  # bt709hip_device_info
@@ -111,6 +119,17 @@ SYMBOLS = {
     "bt709hip_graph_end_capture": (_I, [_P, _P, C.POINTER(C.c_void_p)]),
     "bt709hip_graph_launch": (_I, [_P, _P, _P]),
     "bt709hip_graph_destroy": (_I, [_P, _P]),
+    "bt709hip_mem_info": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "bt709hip_decoder_has_alpha": (_I, [_P]),
+    "bt709hip_decoder_context": (_P, [_P]),
+    "bt709hip_decoder_flush": (_I, [_P, _P]),
+    "bt709hip_decoder_flush_all": (_I, [_P]),
+    "bt709hip_ring_create": (_I, [_P, _I, _I, _I, _I, _I, c_void_pp]),
+    "bt709hip_ring_destroy": (_I, [_P]),
+    "bt709hip_ring_frames": (_I, [_P]),
+    "bt709hip_ring_frame": (_I, [_P, _I, _FP, _FP, _SP]),
+    "bt709hip_ring_placement_info": (_I, [_P, C.POINTER(RingPlacement)]),
+    "bt709hip_ring_decode": (_I, [_P, _I, _I, _P, _I]),
     "bt709hip_malloc": (_I, [_P, _Z, c_void_pp]),
     "bt709hip_free": (_I, [_P, _P]),
     "bt709hip_host_alloc": (_I, [_P, _Z, c_void_pp]),

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbt709hip.so")
 ASM = os.path.join(HERE, "build", "bt709_kernels.s")  # decode + rescale + encode kernels, concatenated
 SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_rgba16f.hip", "bt709_encode.hip", "bt709_planes.hip", "bt709hip.cpp",
-           "transfer_tables.cpp"]
+           "bt709_ring.cpp", "transfer_tables.cpp"]
 KERNEL_SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_rgba16f.hip", "bt709_encode.hip"]
 HEADERS = ["bt709_kernels.h", "bt709_device.h", "bt709_constants.h", "bt709_quantise.h", "bt709_stage.h", "transfer_tables.h"]
 ARCH = "gfx950"
@@ -86,15 +86,17 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_variant(out_path, defines):
-    """A second build of the library with extra -D flags (e.g. BT709_INDEX_RTZ), for same-call A/B
-    runs: bench.py --library <out_path>.  Never replaces the in-tree library."""
+def build_variant(out_path, defines, csrc=CSRC):
+    """A second build of the library with extra -D flags (tile shape and other correct-output tunables, e.g.
+    BT709_QUADS_PER_LANE=1), for same-call A/B runs: bench.py --library <out_path>.  Never replaces the in-tree
+    library.  `csrc`: another source directory -- tools/lab_variants.py compiles a copy of csrc/ with its experiment
+    gates re-inserted (the product sources carry none)."""
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     # items starting with "-" are raw compiler flags (e.g. -fslp-vectorize), the rest -D macros
     extra = [d if d.startswith("-") else "-D" + d for d in defines]
     flags = [f for f in FLAGS if not ("-fslp-vectorize" in extra and f == "-fno-slp-vectorize")]
     cmd = [_hipcc(), "--offload-arch=" + ARCH, *flags, *extra, "-shared",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out_path]
+           *[os.path.join(csrc, s) for s in SOURCES], "-o", out_path]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
@@ -124,7 +126,7 @@ def emit_asm(force=False):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:  # python -m metalbt709decoder_amd.build --variant tools/bin/libbt709hip_rtz.so BT709_INDEX_RTZ
+    if "--variant" in sys.argv:  # python -m metalbt709decoder_amd.build --variant tools/bin/libbt709hip_q1.so BT709_QUADS_PER_LANE=1
         i = sys.argv.index("--variant")
         print("built", build_variant(os.path.abspath(sys.argv[i + 1]), sys.argv[i + 2:]))
         sys.exit(0)

@@ -74,11 +74,7 @@ __device__ __forceinline__ float byte_value(uint8_t b) {
 // instruction instead of two.  This is the only fused multiply-add in the decode kernels (a CPU
 // test counts them: one per converted byte, none anywhere else).
 __device__ __forceinline__ float centre_norm(float v, float off) {
-#if defined(BT709_NO_FMA_CENTRE)  // the two-instruction form, for A/B runs
-  return __fmul_rn(__fadd_rn(v, -off), kInv255);
-#else
   return __builtin_fmaf(v, kInv255, -off * kInv255);
-#endif
 }
 
 // a + b saturated to [0, 1] (BT709.h:444-446 `saturatef`) by the add's own clamp bit
@@ -125,32 +121,10 @@ __device__ __forceinline__ uint32_t quantise_byte(float x) {
   return quantise_enumerated(x);
 }
 
-// t[i] = bits(x[i] + magic) for saturated x: bits(magic) + bucket index (transfer_tables.h).  The
-// default build uses the add as it stands (round to nearest even: bucket q is centred on q / N).
-// -DBT709_INDEX_RTZ builds round 1's floor(x N) form for A/B runs: the adds of a batch sit in one
-// asm statement between two writes of MODE.fp_round's single-precision field (everything else
-// rounds to nearest even); 12 values because an asm statement takes at most 30 operands.
-#if defined(BT709_INDEX_RTZ)
-__device__ __forceinline__ void magic_index12(const float *x, uint32_t *t, float magic) {
-  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-      "v_add_f32 %0, %24, %12\n\tv_add_f32 %1, %24, %13\n\tv_add_f32 %2, %24, %14\n\tv_add_f32 %3, %24, %15\n\t"
-      "v_add_f32 %4, %24, %16\n\tv_add_f32 %5, %24, %17\n\tv_add_f32 %6, %24, %18\n\tv_add_f32 %7, %24, %19\n\t"
-      "v_add_f32 %8, %24, %20\n\tv_add_f32 %9, %24, %21\n\tv_add_f32 %10, %24, %22\n\tv_add_f32 %11, %24, %23\n\t"
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
-        "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11])
-      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
-        "v"(x[10]), "v"(x[11]), "s"(magic));
-}
-
-__device__ __forceinline__ void magic_index4(const float *x, uint32_t *t, float magic) {
-  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-      "v_add_f32 %0, %8, %4\n\tv_add_f32 %1, %8, %5\n\tv_add_f32 %2, %8, %6\n\tv_add_f32 %3, %8, %7\n\t"
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
-      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(magic));
-}
-#else
+// t[i] = bits(x[i] + magic) for saturated x: bits(magic) + bucket index (transfer_tables.h).  The add as it stands
+// (round to nearest even: bucket q is centred on q / N); the host table builder replays it (transfer_tables.cpp
+// bucket_index).  Round 1's floor(x N) form -- the adds between two writes of MODE.fp_round -- is a lab variant
+// (tools/lab_variants.py index_rtz).
 __device__ __forceinline__ void magic_index12(const float *x, uint32_t *t, float magic) {
 #pragma unroll
   for (int i = 0; i < 12; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
@@ -160,7 +134,6 @@ __device__ __forceinline__ void magic_index4(const float *x, uint32_t *t, float 
 #pragma unroll
   for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
 }
-#endif
 
 // Lookup constants of the byte-valued bucket table (TransferBucket, 8 bytes) held at `lds_table`.
 struct UnitLookup {

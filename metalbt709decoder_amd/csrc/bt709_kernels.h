@@ -80,8 +80,6 @@ struct DecodeParams {
   uint32_t rep_dec_log2, rep_enc_log2;
   uint32_t tiles_x, tile_rows;
   uint32_t cursor_tx, cursor_rp, cursor_f;
-  // tools/walk_lab.hip only (persistent 1:1 lab kernel): start-up stagger and the CU count
-  uint32_t walk_stagger, walk_cus;
   // XCD-aware work map of the short-lived kernels (filled by the launchers): grid.x = 8 x tiles, x & 7 = the workgroup's
   // place in the round-robin over the XCDs, which owns frames [(x & 7) * frames_per_band, ...) of the launch
   uint32_t xcd_bands, frames_per_band;

@@ -144,24 +144,18 @@ decode_nv12_quads(const DecodeParams p) {
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = min((q0 + u * blockDim.x), quads - 1);
-#if defined(BT709_LAB_NO_LOADS)  // lab, with BT709_LAB_NO_ARITH: the launch's stores alone
-    ya[u] = q * 3u, yb[u] = q * 5u, cw[u] = q * 7u + rp;
-#else
     ya[u] = load32<NT>(y0 + 4 * q);
     yb[u] = load32<NT>(y1 + 4 * q);
     cw[u] = load32<NT>(cc + 4 * q);
-#endif
     if (HAS_ALPHA) {
       aa[u] = load32<NT>(a0 + 4 * q);
       ab[u] = load32<NT>(a0 + p.alpha_stride + 4 * q);
     }
   }
-#if !defined(BT709_LAB_NO_TABLE)  // lab, with BT709_LAB_NO_ARITH: without the per-workgroup table staging and its barrier too
   if (!QUANT) {  // the sRGB mode needs no table (decode_quad)
     stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
     __syncthreads();
   }
-#endif
   // Pin every loaded dword here: hipcc then waits for all of the tile's loads once, before any
   // store is issued, instead of emitting s_waitcnt vmcnt(0) between the first quad's stores and
   // the second quad's arithmetic (which would wait for the stores' write acknowledgements).
@@ -176,18 +170,9 @@ decode_nv12_quads(const DecodeParams p) {
   for (int u = 0; u < UNROLL; ++u) {
     const uint32_t q = (q0 + u * blockDim.x);
     u32x4 top, bot;
-#if defined(BT709_LAB_NO_ARITH)  // lab, WRONG OUTPUT: the launch's loads and stores with (almost) no arithmetic = the ceiling of its traffic pattern
-    top = u32x4{ya[u], yb[u], cw[u], ya[u] ^ cw[u]};
-    bot = u32x4{yb[u], cw[u], ya[u], yb[u] ^ cw[u]};
-#else
     decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
                            bot);
-#endif
-#if defined(BT709_LAB_NO_STORES)  // lab, with BT709_LAB_NO_ARITH: the launch's loads alone (a store about once in 2^32 quads keeps them alive)
-    if (q < quads && rp_raw < row_pairs && (top.w ^ bot.w) == 0x9e3779b9u) {
-#else
     if (q < quads && rp_raw < row_pairs) {
-#endif
       store16<NT>(o0 + 16 * q, top);
       store16<NT>(o1 + 16 * q, bot);
     }

@@ -22,6 +22,15 @@
 
 #include <cstdint>
 
+// Every `a * b + c` below is TWO roundings, which is what the exhaustive sweeps certified.  build.py compiles with
+// -ffp-contract=off, but hipcc's own default is fp-contract=fast: an integrator's build of csrc/ without that flag would
+// fuse them into one v_fma_f32 and change the rounding.  The header says it itself, for the rest of the including file.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+
 #if defined(__HIPCC__)
 #define BT709_HD __host__ __device__ __forceinline__
 #else

@@ -102,13 +102,9 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
 // s * (quarter_unscale * n) -- the same float as v * n, the factor being a power of two times n -- and the
 // bucket's edge is compared in the sum's own domain (edges pre-divided by quarter_unscale at staging).
 __device__ __forceinline__ uint32_t encode_byte_uniform(const RescaleLookup &r, float s) {
-#if defined(BT709_UNIFORM_INDEX_TWO_STEP)  // round 2's first form: multiply, then add
-  const uint32_t t = __float_as_uint(__fadd_rn(__fmul_rn(s, r.sum_to_xs), 8388608.0f));  // bits(2^23) + round(v n)
-#else
   // ONE fma: bits(2^23) + round(v n + 2^23 as a real number).  An index function only has to be monotone and the
   // same on the host (transfer_tables.cpp uniform_index files the thresholds under it); it is not reference arithmetic.
   const uint32_t t = __float_as_uint(__builtin_fmaf(s, r.sum_to_xs, 8388608.0f));
-#endif
   const u32x2 e = *reinterpret_cast<LdsPairPtr>((t << r.enc_shift) + r.enc_u_off);
   return e.y + (s >= __uint_as_float(e.x) ? 1u : 0u);
 }
@@ -130,15 +126,7 @@ __device__ __forceinline__ uint32_t encode_byte(const RescaleLookup &r, float xs
 constexpr int kLinBatch = BT709_LIN_BATCH;  // 6 or 12 (12: one wait per pixel, 48 VGPRs of buckets in flight)
 __device__ __forceinline__ void linearise12(const RescaleLookup &r, const float *x, float *lin) {
   uint32_t t[12];
-#if defined(BT709_LAB_BOUND_SHARED_INDEX)
-  // tools/ab_half_bounds.sh, WRONG OUTPUT: G and B reuse R's four bucket indices -- what the launch would take if the
-  // index of a block's 12 evaluations cost 4 adds instead of 12 (the ceiling of any "index from the luma term alone" form)
-  magic_index4(x, t, r.magic);
-#pragma unroll
-  for (int i = 4; i < 12; ++i) t[i] = t[i & 3];
-#else
   magic_index12(x, t, r.magic);
-#endif
 #pragma unroll
   for (int h = 0; h < 12 / kLinBatch; ++h) {
     u32x4 e[kLinBatch];  // {edge, lin(base), lin(base + 1), base}: whole vectors keep the read a ds_read_b128
@@ -214,14 +202,6 @@ __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, f
   const float sr = __fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]);
   const float sg = __fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]);
   const float sb = __fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]);
-#if defined(BT709_LAB_BOUND_ONE_ENCODE)
-  // tools/ab_half_bounds.sh, WRONG OUTPUT: one encode-side lookup instead of three (sg, sb still formed and consumed): the
-  // ceiling of any form that folds the three encode lookups of a pixel into one
-  if (UNIFORM_ENCODE) {
-    const uint32_t e = encode_byte_uniform(r, sr);
-    return pack_bgra(e, e + (sg > sr ? 1u : 0u), e + (sb > sr ? 1u : 0u), alpha_word);
-  }
-#endif
   if (UNIFORM_ENCODE) return pack_bgra(encode_byte_uniform(r, sr), encode_byte_uniform(r, sg), encode_byte_uniform(r, sb), alpha_word);
   return pack_bgra(encode_byte(r, __fmul_rn(sr, r.quarter_scale)), encode_byte(r, __fmul_rn(sg, r.quarter_scale)),
                    encode_byte(r, __fmul_rn(sb, r.quarter_scale)), alpha_word);
@@ -330,13 +310,9 @@ decode_nv12_half(const DecodeParams p) {
 // ---------------------------------------------------------------------------
 namespace {
 
-// encode side of the persistent kernel: the uniform non-power-of-two table (index = mul, mul, add) unless
-// built with -DBT709_REP_SPLIT_ENCODE (round 1's two-resolution table: convert, shift, add, min; A/B runs)
-#if defined(BT709_REP_SPLIT_ENCODE)
-constexpr bool kRepUniformEncode = false;
-#else
+// encode side of the persistent kernel: the uniform non-power-of-two table (index = one fma); round 1's two-resolution
+// table (convert, shift, add, min) is what the short-lived kernel uses and a lab variant here (tools/lab_variants.py)
 constexpr bool kRepUniformEncode = true;
-#endif
 // (The luma terms Yn * My from a 256-entry LDS table -- one SDWA shift + ds_read_b32 instead of convert, fma,
 // multiply, 8 fewer VALU instructions per output pixel in a VALU-issue-bound kernel -- measured 3 % SLOWER in the
 // same call, profiles/r02_ab_half_luma_table.txt: at 60 % busy the LDS pipe has no room for four more conflicted
@@ -1023,10 +999,6 @@ const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, boo
 const char *launch_decode_half_rep(const DecodeParams &p_in, int frames, bool has_alpha, bool nontemporal, uint32_t workgroups,
                                    uint32_t lds_budget, hipStream_t stream) {
   DecodeParams p = p_in;
-#if defined(BT709_LAB_HALF_TABLE)  // lab, WRONG OUTPUT: half as many (coarser) decode-side buckets = the LDS footprint of 8-byte entries
-  p.unit_magic = p.unit_magic * 2.0f;
-  p.table_linear_bytes = (p.table_linear_bytes / 2 + 31u) & ~15u;
-#endif
   const uint64_t kRepLdsBytes = (lds_budget < 16384u ? 16384u : (lds_budget > bt709::kRepLdsBytes ? bt709::kRepLdsBytes : lds_budget));
   // copies: as many as fit the CU's LDS, decode side first (12 of the 15 lookups per output pixel)
   const uint64_t enc_bytes = kRepUniformEncode ? p.table_encode_u_bytes : p.table_encode_bytes;

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +47,19 @@ struct bt709hip_context {
   // bt709hip_render_scaled (pass 2 alone): built on first use under encoder_mutex
   void *d_render_encode = nullptr, *d_render_lin = nullptr;
   uint32_t render_encode_bytes = 0, render_encode_n = 0, render_encode_offset = 0, render_encode_shift = 0;
+  // decoders of this context with BT709HIP_OPT_COALESCE on: every entry point that takes a stream issues their queued
+  // frames for that stream first (flush_stream), so the stream keeps its order
+  std::atomic<int> n_coalescing{0};
+  std::mutex coalescing_mutex;
+  std::vector<bt709hip_decoder *> coalescing;
+};
+
+// BT709HIP_OPT_COALESCE: frames validated and queued for one stream, not yet launched (include/bt709hip.h, COALESCING SUBMIT)
+struct PendingQueue {
+  hipStream_t stream = nullptr;
+  bool with_alphas = false;  // the calls passed alpha descriptors
+  std::vector<bt709hip_frame> frames, alphas;
+  std::vector<bt709hip_surface> outs;
 };
 
 struct bt709hip_decoder {
@@ -57,6 +72,9 @@ struct bt709hip_decoder {
   int half_workgroups = 0;  // BT709HIP_OPT_HALF_WORKGROUPS: 0 = one per compute unit
   int half_lds_kb = 0;      // BT709HIP_OPT_HALF_LDS_KB: 0 = all 160
   int xcd_bands = 1;        // BT709HIP_OPT_XCD_BANDS: XCD-aware work map of the batched 1:1 kernels (frames a multiple of 8)
+  int coalesce = 0;         // BT709HIP_OPT_COALESCE: 0 off, else frames gathered per launch (2..32)
+  std::mutex queue_mutex;   // guards queues
+  std::vector<PendingQueue> queues;  // one per stream that has (had) queued frames
   std::mutex setup_mutex;
   bool ready = false;
   // device copies (transfer_tables.h)
@@ -304,6 +322,64 @@ uint32_t grid_x_for(const bt709hip_context *ctx, uint32_t rows, int frames) {
   return rows < per_frame ? rows : per_frame;
 }
 
+int decode_batch_now(bt709hip_decoder *dec, int count, const bt709hip_frame *frames, const bt709hip_frame *alphas,
+                     const bt709hip_surface *outs, void *stream, int wait_until_completed);
+
+// Launches what `q` holds (dec->queue_mutex held).  The queue is emptied first: a failed launch is reported once, to the
+// call that issued it, and never re-issued.
+int issue_queue(bt709hip_decoder *dec, PendingQueue &q) {
+  if (q.frames.empty()) return BT709HIP_OK;
+  std::vector<bt709hip_frame> frames, alphas;
+  std::vector<bt709hip_surface> outs;
+  frames.swap(q.frames);
+  alphas.swap(q.alphas);
+  outs.swap(q.outs);
+  return decode_batch_now(dec, static_cast<int>(frames.size()), frames.data(), q.with_alphas ? alphas.data() : nullptr, outs.data(),
+                          q.stream, 0);
+}
+
+// one decoder: the queue of stream `s`, or every queue (all = true)
+int flush_decoder(bt709hip_decoder *dec, hipStream_t s, bool all) {
+  std::lock_guard<std::mutex> lock(dec->queue_mutex);
+  int rc = BT709HIP_OK;
+  for (PendingQueue &q : dec->queues)
+    if (all || q.stream == s)
+      if (int e = issue_queue(dec, q)) rc = rc ? rc : e;
+  return rc;
+}
+
+// every coalescing decoder of `ctx`: called by each entry point that takes a stream, before it touches the stream
+int flush_stream(bt709hip_context *ctx, hipStream_t s) {
+  if (ctx == nullptr || ctx->n_coalescing.load(std::memory_order_relaxed) == 0) return BT709HIP_OK;
+  std::vector<bt709hip_decoder *> decs;
+  {
+    std::lock_guard<std::mutex> lock(ctx->coalescing_mutex);
+    decs = ctx->coalescing;
+  }
+  int rc = BT709HIP_OK;
+  for (bt709hip_decoder *d : decs)
+    if (int e = flush_decoder(d, s, false)) rc = rc ? rc : e;
+  return rc;
+}
+
+#define FLUSH_STREAM(ctx, stream)                                                        \
+  do {                                                                                   \
+    if ((ctx) != nullptr)                                                                \
+      if (int _rc = flush_stream((ctx), pick((ctx), (stream)))) return _rc;              \
+  } while (0)
+
+void set_coalescing(bt709hip_decoder *dec, int n) {
+  bt709hip_context *ctx = dec->ctx;
+  const bool was = dec->coalesce > 1, now = n > 1;
+  dec->coalesce = n;
+  if (ctx == nullptr || was == now) return;
+  std::lock_guard<std::mutex> lock(ctx->coalescing_mutex);
+  auto it = std::find(ctx->coalescing.begin(), ctx->coalescing.end(), dec);
+  if (now && it == ctx->coalescing.end()) ctx->coalescing.push_back(dec);
+  if (!now && it != ctx->coalescing.end()) ctx->coalescing.erase(it);
+  ctx->n_coalescing.store(static_cast<int>(ctx->coalescing.size()), std::memory_order_relaxed);
+}
+
 }  // namespace
 
 extern "C" {
@@ -432,12 +508,14 @@ int bt709hip_stream_create_with_priority(bt709hip_context *ctx, int priority, vo
 int bt709hip_stream_destroy(bt709hip_context *ctx, void *stream) {
   if (stream == nullptr) return BT709HIP_OK;
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);
   HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
   return BT709HIP_OK;
 }
 
 int bt709hip_stream_synchronize(bt709hip_context *ctx, void *stream) {
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);
   HIP_TRY(hipStreamSynchronize(pick(ctx, stream)));
   return BT709HIP_OK;
 }
@@ -461,6 +539,7 @@ int bt709hip_event_destroy(bt709hip_context *ctx, void *event) {
 int bt709hip_event_record(bt709hip_context *ctx, void *event, void *stream) {
   if (event == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);
   HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), pick(ctx, stream)));
   return BT709HIP_OK;
 }
@@ -475,6 +554,7 @@ int bt709hip_event_synchronize(bt709hip_context *ctx, void *event) {
 int bt709hip_stream_wait_event(bt709hip_context *ctx, void *stream, void *event) {
   if (event == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);  // what this stream queued before the wait runs before it
   HIP_TRY(hipStreamWaitEvent(pick(ctx, stream), static_cast<hipEvent_t>(event), 0));
   return BT709HIP_OK;
 }
@@ -489,6 +569,7 @@ int bt709hip_event_elapsed_ms(bt709hip_context *ctx, void *start, void *stop, fl
 int bt709hip_graph_begin_capture(bt709hip_context *ctx, void *stream) {
   if (stream == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);  // frames queued before the recording are not part of it
   HIP_TRY(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
   return BT709HIP_OK;
 }
@@ -497,6 +578,7 @@ int bt709hip_graph_end_capture(bt709hip_context *ctx, void *stream, void **graph
   if (stream == nullptr || graph == nullptr) return BT709HIP_ERR_INVALID_ARG;
   *graph = nullptr;
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);  // frames queued during the recording are recorded
   hipGraph_t g = nullptr;
   HIP_TRY(hipStreamEndCapture(static_cast<hipStream_t>(stream), &g));
   hipGraphExec_t exec = nullptr;
@@ -510,6 +592,7 @@ int bt709hip_graph_end_capture(bt709hip_context *ctx, void *stream, void **graph
 int bt709hip_graph_launch(bt709hip_context *ctx, void *graph, void *stream) {
   if (graph == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);
   HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(graph), pick(ctx, stream)));
   return BT709HIP_OK;
 }
@@ -537,6 +620,15 @@ int bt709hip_free(bt709hip_context *ctx, void *dptr) {
   return BT709HIP_OK;
 }
 
+int bt709hip_mem_info(bt709hip_context *ctx, size_t *free_bytes, size_t *total_bytes) {
+  if (int rc = bind(ctx)) return rc;
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return BT709HIP_OK;
+}
+
 int bt709hip_host_alloc(bt709hip_context *ctx, size_t bytes, void **hptr) {
   if (hptr == nullptr) return BT709HIP_ERR_INVALID_ARG;
   *hptr = nullptr;
@@ -557,6 +649,7 @@ int bt709hip_memset(bt709hip_context *ctx, void *dptr, int value, size_t bytes, 
   if (int rc = bind(ctx)) return rc;
   if (bytes == 0) return BT709HIP_OK;
   if (dptr == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  FLUSH_STREAM(ctx, stream);
   HIP_TRY(hipMemsetAsync(dptr, value, bytes, pick(ctx, stream)));
   return BT709HIP_OK;
 }
@@ -567,6 +660,7 @@ int bt709hip_upload(bt709hip_context *ctx, void *dst_dev, size_t dst_pitch, cons
   if (row_bytes == 0 || rows == 0) return BT709HIP_OK;
   if (dst_dev == nullptr || src_host == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (dst_pitch < row_bytes || src_pitch < row_bytes) return BT709HIP_ERR_STRIDE;
+  FLUSH_STREAM(ctx, stream);
   HIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_host, src_pitch, row_bytes, rows, hipMemcpyHostToDevice,
                            pick(ctx, stream)));
   return BT709HIP_OK;
@@ -578,6 +672,7 @@ int bt709hip_download(bt709hip_context *ctx, void *dst_host, size_t dst_pitch, c
   if (row_bytes == 0 || rows == 0) return BT709HIP_OK;
   if (dst_host == nullptr || src_dev == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (dst_pitch < row_bytes || src_pitch < row_bytes) return BT709HIP_ERR_STRIDE;
+  FLUSH_STREAM(ctx, stream);
   HIP_TRY(hipMemcpy2DAsync(dst_host, dst_pitch, src_dev, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost,
                            pick(ctx, stream)));
   return BT709HIP_OK;
@@ -601,6 +696,10 @@ int bt709hip_decoder_create(bt709hip_context *ctx, int gamma, int has_alpha, bt7
 
 int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
   if (dec == nullptr) return BT709HIP_OK;
+  if (dec->coalesce > 1) {  // queued frames go out; the context forgets the decoder
+    if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) (void)flush_decoder(dec, nullptr, true);
+    set_coalescing(dec, 0);
+  }
   if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) {
     if (dec->d_table_unit) (void)hipFree(dec->d_table_unit);
     if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
@@ -616,12 +715,16 @@ int bt709hip_decoder_set_context(bt709hip_decoder *dec, bt709hip_context *ctx) {
   if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(dec->setup_mutex);
   if (dec->ready) return dec->ctx == ctx ? BT709HIP_OK : BT709HIP_ERR_INVALID_ARG;
+  const int n = dec->coalesce;
+  set_coalescing(dec, 0);  // registered with the context it belongs to
   dec->ctx = ctx;
+  set_coalescing(dec, n);
   return BT709HIP_OK;
 }
 
 int bt709hip_decoder_set_alpha_fill(bt709hip_decoder *dec, int alpha_byte) {
   if (dec == nullptr || alpha_byte < 0 || alpha_byte > 255) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bt709hip_decoder_flush_all(dec)) return rc;  // queued frames were submitted under the old value
   dec->alpha_fill = static_cast<uint32_t>(alpha_byte);
   return BT709HIP_OK;
 }
@@ -630,14 +733,34 @@ int bt709hip_decoder_get_gamma(const bt709hip_decoder *dec) {
   return dec ? dec->gamma : BT709HIP_ERR_INVALID_ARG;
 }
 
+int bt709hip_decoder_has_alpha(const bt709hip_decoder *dec) { return dec ? dec->has_alpha : BT709HIP_ERR_INVALID_ARG; }
+
+bt709hip_context *bt709hip_decoder_context(const bt709hip_decoder *dec) { return dec ? dec->ctx : nullptr; }
+
+int bt709hip_decoder_flush(bt709hip_decoder *dec, void *stream) {
+  if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (dec->coalesce <= 1 || dec->ctx == nullptr) return BT709HIP_OK;
+  if (int rc = bind(dec->ctx)) return rc;
+  return flush_decoder(dec, pick(dec->ctx, stream), false);
+}
+
+int bt709hip_decoder_flush_all(bt709hip_decoder *dec) {
+  if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (dec->coalesce <= 1 || dec->ctx == nullptr) return BT709HIP_OK;
+  if (int rc = bind(dec->ctx)) return rc;
+  return flush_decoder(dec, nullptr, true);
+}
+
 int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value) {
   if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (int rc = bt709hip_decoder_flush_all(dec)) return rc;  // queued frames were submitted under the old options
   switch (option) {
     case BT709HIP_OPT_NONTEMPORAL: dec->nontemporal = value != 0; return BT709HIP_OK;
     case BT709HIP_OPT_HALF_KERNEL: dec->half_rep = clamp_int(value, -1, 1); return BT709HIP_OK;
     case BT709HIP_OPT_HALF_WORKGROUPS: dec->half_workgroups = clamp_int(value, 0, 1 << 20); return BT709HIP_OK;
     case BT709HIP_OPT_HALF_LDS_KB: dec->half_lds_kb = clamp_int(value, 0, 160); return BT709HIP_OK;
     case BT709HIP_OPT_XCD_BANDS: dec->xcd_bands = clamp_int(value, 0, 2); return BT709HIP_OK;
+    case BT709HIP_OPT_COALESCE: set_coalescing(dec, value <= 1 ? 0 : clamp_int(value, 2, kMaxBatch)); return BT709HIP_OK;
     default: return BT709HIP_ERR_INVALID_ARG;
   }
 }
@@ -650,6 +773,7 @@ int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *va
     case BT709HIP_OPT_HALF_WORKGROUPS: *value = dec->half_workgroups; return BT709HIP_OK;
     case BT709HIP_OPT_HALF_LDS_KB: *value = dec->half_lds_kb; return BT709HIP_OK;
     case BT709HIP_OPT_XCD_BANDS: *value = dec->xcd_bands; return BT709HIP_OK;
+    case BT709HIP_OPT_COALESCE: *value = dec->coalesce; return BT709HIP_OK;
     default: return BT709HIP_ERR_INVALID_ARG;
   }
 }
@@ -793,9 +917,11 @@ int finish_launch(hipStream_t s, int wait_until_completed) {
 
 }  // namespace
 
-int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
-                          const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
-                          int wait_until_completed) {
+namespace {
+
+// the launch itself (no queueing)
+int decode_batch_now(bt709hip_decoder *dec, int count, const bt709hip_frame *frames, const bt709hip_frame *alphas,
+                     const bt709hip_surface *outs, void *stream, int wait_until_completed) {
   DecodeParams p;
   BatchInfo info;
   if (int rc = gather_batch(dec, count, frames, alphas, outs, OutShape::kSame, stream, &p, &info)) return rc;
@@ -817,6 +943,62 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
   return finish_launch(s, wait_until_completed);
 }
 
+bool same_shape(const bt709hip_frame &a, const bt709hip_frame &b) {
+  return a.width == b.width && a.height == b.height && a.y_stride == b.y_stride && a.cbcr_stride == b.cbcr_stride;
+}
+
+// BT709HIP_OPT_COALESCE (include/bt709hip.h, COALESCING SUBMIT): validate now, launch later.
+int coalescing_submit(bt709hip_decoder *dec, int count, const bt709hip_frame *frames, const bt709hip_frame *alphas,
+                      const bt709hip_surface *outs, void *stream, int wait_until_completed) {
+  if (dec->ctx == nullptr) return decode_batch_now(dec, count, frames, alphas, outs, stream, wait_until_completed);
+  hipStream_t s = pick(dec->ctx, stream);
+  std::lock_guard<std::mutex> lock(dec->queue_mutex);
+  PendingQueue *q = nullptr;
+  for (PendingQueue &c : dec->queues)
+    if (c.stream == s) q = &c;
+  const bool eligible = wait_until_completed == 0 && count >= 1 && count < dec->coalesce && frames != nullptr && outs != nullptr;
+  if (!eligible) {  // in stream order: what is queued goes first
+    if (q != nullptr)
+      if (int rc = issue_queue(dec, *q)) return rc;
+    return decode_batch_now(dec, count, frames, alphas, outs, stream, wait_until_completed);
+  }
+  {  // the call's own status: everything -decodeBT709: checks, now
+    DecodeParams p;
+    BatchInfo info;
+    if (int rc = gather_batch(dec, count, frames, alphas, outs, OutShape::kSame, stream, &p, &info)) return rc;
+    if (p.width == 0) return BT709HIP_OK;  // empty frames: nothing to launch
+  }
+  if (q == nullptr) {
+    dec->queues.emplace_back();
+    q = &dec->queues.back();
+    q->stream = s;
+  }
+  if (!q->frames.empty()) {
+    const bool fits = q->frames.size() + static_cast<size_t>(count) <= static_cast<size_t>(dec->coalesce) &&
+                      same_shape(q->frames[0], frames[0]) && q->frames[0].transfer == frames[0].transfer &&
+                      q->outs[0].stride == outs[0].stride && q->outs[0].format == outs[0].format &&
+                      q->with_alphas == (alphas != nullptr) && (alphas == nullptr || q->alphas[0].y_stride == alphas[0].y_stride);
+    if (!fits)
+      if (int rc = issue_queue(dec, *q)) return rc;
+  }
+  q->with_alphas = alphas != nullptr;
+  q->frames.insert(q->frames.end(), frames, frames + count);
+  if (alphas != nullptr) q->alphas.insert(q->alphas.end(), alphas, alphas + count);
+  q->outs.insert(q->outs.end(), outs, outs + count);
+  tl_kernel_name = "(queued: coalescing submit)";
+  if (q->frames.size() >= static_cast<size_t>(dec->coalesce)) return issue_queue(dec, *q);
+  return BT709HIP_OK;
+}
+
+}  // namespace
+
+int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
+                          const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
+                          int wait_until_completed) {
+  if (dec != nullptr && dec->coalesce > 1) return coalescing_submit(dec, count, frames, alphas, outs, stream, wait_until_completed);
+  return decode_batch_now(dec, count, frames, alphas, outs, stream, wait_until_completed);
+}
+
 int bt709hip_decode(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt709hip_frame *alpha,
                     const bt709hip_surface *out, int render_width, int render_height, void *stream,
                     int wait_until_completed) {
@@ -833,6 +1015,7 @@ int bt709hip_unconvert(bt709hip_decoder *dec, const void *ycbcr_words, size_t in
                        const bt709hip_surface *out, void *stream, int wait_until_completed) {
   if (dec == nullptr || out == nullptr || width < 0 || height < 0) return BT709HIP_ERR_INVALID_ARG;
   if (int rc = ensure_setup(dec, stream)) return rc;
+  FLUSH_STREAM(dec->ctx, stream);
   if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;  // the packed words carry no alpha sample
   if (out->width != width || out->height != height) return BT709HIP_ERR_SIZE_MISMATCH;
   if ((width & 1) || (height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;  // BGRAToBT709Converter.m:69-74
@@ -861,6 +1044,7 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
                                int wait_until_completed) {
   DecodeParams p;
   BatchInfo info;
+  if (dec != nullptr) FLUSH_STREAM(dec->ctx, stream);
   if (int rc = gather_batch(dec, count, frames, alphas, outs, OutShape::kHalf, stream, &p, &info)) return rc;
   if (p.width == 0) return BT709HIP_OK;
   hipStream_t s = pick(dec->ctx, stream);
@@ -894,6 +1078,7 @@ int bt709hip_decode_scaled_batch(bt709hip_decoder *dec, int count, const bt709hi
   DecodeParams p;
   BatchInfo info;
   // the frames are validated like any decode input; the surfaces may have any (common) size
+  if (dec != nullptr) FLUSH_STREAM(dec->ctx, stream);
   if (int rc = gather_batch(dec, count, frames, alphas, outs, OutShape::kAny, stream, &p, &info)) return rc;
   if (p.width == 0) return BT709HIP_OK;
   if (p.out_height > static_cast<uint32_t>(kMaxGridYZ)) return BT709HIP_ERR_UNSUPPORTED;
@@ -1005,6 +1190,7 @@ static int render_scaled_launch(bt709hip_context *ctx, int count, const bt709hip
     return BT709HIP_ERR_STRIDE;
   if (out->height > kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);
   hipStream_t s = pick(ctx, stream);
   if (int rc = render_tables(ctx, s)) return rc;
   RenderParams p;
@@ -1155,6 +1341,7 @@ int bt709hip_pool_submit(bt709hip_pool *pool, int slot) {
   s.acquired = false;
   s.busy = true;
   if (int rc = bt709hip_decode(pool->dec, &f, pool->dec->has_alpha ? &a : nullptr, &o, w, h, s.stream, 0)) return rc;
+  if (int rc = bt709hip_decoder_flush(pool->dec, s.stream)) return rc;  // the raw copy below must follow the decode
   HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, pool->out_bytes, hipMemcpyDeviceToHost, s.stream));
   return BT709HIP_OK;
 }
@@ -1380,6 +1567,7 @@ int bt709hip_encode_batch(bt709hip_context *ctx, int count, const bt709hip_surfa
   if (count > (uniform ? kMaxUniformBatch : kMaxBatch)) return BT709HIP_ERR_UNSUPPORTED;
   if (in0.width == 0 || in0.height == 0) return BT709HIP_OK;
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);
 
   hipStream_t s = pick(ctx, stream);
   EncoderTables &t = ctx->encoders[input_gamma][output_gamma];
@@ -1436,6 +1624,7 @@ static int planes_call(bt709hip_context *ctx, const void *u, size_t u_stride, co
   if (u_stride > 0xffffffffu || v_stride > 0xffffffffu || cbcr_stride > 0xffffffffu) return BT709HIP_ERR_STRIDE;
   if (ch > kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;  // one chroma row per gridDim.y
   if (int rc = bind(ctx)) return rc;
+  FLUSH_STREAM(ctx, stream);
   PlaneParams p;
   std::memset(&p, 0, sizeof p);
   p.u = static_cast<const uint8_t *>(u);
@@ -1476,6 +1665,7 @@ int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_
   if (bytes == 0) return BT709HIP_OK;
   if (dst == nullptr || src == nullptr || (bytes & 15) || !aligned(dst, 16) || !aligned(src, 16))
     return BT709HIP_ERR_INVALID_ARG;
+  FLUSH_STREAM(ctx, stream);
   tl_kernel_name = launch_copy_probe(dst, src, bytes, pick(ctx, stream));
   HIP_TRY(hipGetLastError());
   return BT709HIP_OK;
@@ -1486,6 +1676,8 @@ int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, vo
   *dptr = nullptr;
   if (chosen) *chosen = -1;
   if (bytes == 0 || tries < 1 || tries > 32) return BT709HIP_ERR_INVALID_ARG;
+  if (rates_GBps)
+    for (int i = 0; i < tries; ++i) rates_GBps[i] = 0.0f;  // fully written whatever path is taken below
   if (int rc = bind(ctx)) return rc;
   std::vector<void *> cand;
   for (int i = 0; i < tries; ++i) {  // every candidate stays alive until the choice is made: they land in different places
@@ -1529,8 +1721,6 @@ int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, vo
   if (e1) (void)hipEventDestroy(e1);
   for (size_t i = 0; i < cand.size(); ++i)
     if (static_cast<int>(i) != best) (void)hipFree(cand[i]);
-  if (rates_GBps)
-    for (int i = static_cast<int>(cand.size()); i < tries; ++i) rates_GBps[i] = 0.0f;
   (void)hipGetLastError();
   *dptr = cand[static_cast<size_t>(best)];
   if (chosen) *chosen = best;

@@ -105,14 +105,7 @@ uint32_t to_bits(float f) {
 }  // namespace
 
 uint32_t bucket_index(float x, float magic) {
-#if defined(BT709_INDEX_RTZ)
-  const int mode = std::fegetround();
-  std::fesetround(FE_TOWARDZERO);
-  volatile float s = x + magic;
-  std::fesetround(mode);
-#else
   volatile float s = x + magic;  // binary32 add, round to nearest even (volatile: no excess precision, no folding)
-#endif
   return to_bits(s) - to_bits(magic);
 }
 
@@ -259,12 +252,7 @@ bool build_half_table(int gamma, HalfTable *out) {
 }
 
 uint32_t uniform_index(float v, float n) {
-#if defined(BT709_UNIFORM_INDEX_TWO_STEP)
-  volatile float xs = v * n;            // binary32 product, round to nearest even
-  volatile float t = xs + 8388608.0f;   // floats in [2^23, 2^24) have ulp 1: round(xs)
-#else
   volatile float t = std::fmaf(v, n, 8388608.0f);  // one rounding of v n + 2^23, as the kernel's v_fma_f32
-#endif
   return to_bits(t) - 0x4b000000u;
 }
 

@@ -19,8 +19,8 @@
 // and bucket q is the set of x whose sum lands on M + q / N: buckets are 1/N wide and centred on
 // q / N (q = 0 and q = N are half buckets).  Any monotone index function works as long as the
 // builder below and the kernels use the same one; round-to-nearest needs no MODE register switch
-// (round 1 used floor(x N) through a round-toward-zero add between two s_setreg; -DBT709_INDEX_RTZ
-// builds that form for A/B runs in tools/decode_lab).
+// (round 1 used floor(x N) through a round-toward-zero add between two s_setreg; tools/lab_variants.py index_rtz
+// rebuilds that form for A/B runs).
 #pragma once
 
 #include <cstdint>

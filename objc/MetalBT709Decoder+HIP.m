@@ -10,6 +10,7 @@
 // bodies of Renderer/MetalBT709Decoder.m (it is compiled instead of that file's -setupMetal / -decodeBT709:
 // implementations on a machine whose GPU is an MI355X).  Which reference call sites work unchanged: INTEGRATION.md 2.
 #import "MetalBT709Decoder.h"
+#import "MetalBT709Decoder+HIP.h"   // hipDeferredCompletion, -finishHIPFrames (class extension)
 #import "MetalRenderContext.h"
 #import <CoreVideo/CoreVideo.h>
 #include "bt709hip.h"
@@ -26,6 +27,7 @@ enum { BT709HIPMaxInFlight = 3 };  // MaxBuffersInFlight, AAPLRenderer.m:34
   id<MTLTexture> _pendingTexture[BT709HIPMaxInFlight];   // nil = the slot owes nothing
   int _nextSlot;                   // the slot bt709hip_pool_acquire hands out next (follows every acquire)
 }
+- (BOOL) finishHIPSlot:(int)slot;
 @end
 
 static int32_t BT709HIPMatrixTag(CVPixelBufferRef pb) {

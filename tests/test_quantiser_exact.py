@@ -115,3 +115,34 @@ def test_gpu_scaled_alpha_sweep_of_weights(oracle):
         a[1::2] = 255 - a[1::2]
         got = gh.gpu_decode_scaled(y, c, (ow, oh), mb.MetalBT709GammaSRGB, alpha=a)
         assert np.array_equal(got, oracle.decode_nv12_scaled(1, y, c, ow, oh, alpha=a)), ((w, h), (ow, oh))
+
+
+def test_quantiser_header_forbids_contraction_by_itself(tmp_path):
+    """bt709_quantise.h carries its own `fp contract(off)` pragma: compiled WITHOUT build.py's -ffp-contract=off (hipcc's
+    default is fp-contract=fast; an integrator's own build of csrc/) the quantisers still are a multiply and an add, never one
+    fused multiply-add -- the rounding the sweeps above certified (round 3's advisor finding)."""
+    src = tmp_path / "q.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n#include "bt709_quantise.h"\n'
+                   "__global__ void k(const float *x, uint32_t *o) {\n"
+                   "  o[threadIdx.x] = bt709::quantise_enumerated(x[threadIdx.x]) + bt709::quantise_exact(x[threadIdx.x + 64]) +\n"
+                   "                   bt709::half_alpha_sum_to_byte(x[0], x[1], x[2], x[3]) + (uint32_t)bt709::alpha_norm_of_unit(x[4]);\n}\n")
+    out = tmp_path / "q.s"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only",
+                        "-I", os.path.join(ROOT, "metalbt709decoder_amd", "csrc"), str(src), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    asm = out.read_text()
+    body = asm[asm.index("_Z1kPKfPj:"):asm.index(".Lfunc_end0")]
+    import re
+    assert not re.search(r"\bv_(fma|fmac|mad|pk_fma)_f32", body), "the quantiser was contracted into an fma"
+    assert len(re.findall(r"\bv_mul_f32", body)) >= 4
+    # the host twin, with FMA instructions available and GCC's default -ffp-contract=fast
+    hsrc = tmp_path / "q.cpp"
+    hsrc.write_text('#include "bt709_quantise.h"\nunsigned f(float x, float a, float b, float c, float d) {\n'
+                    "  return bt709::quantise_enumerated(x) + bt709::half_alpha_sum_to_byte(a, b, c, d); }\n")
+    hobj = tmp_path / "q.o"
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-mfma", "-Wall", "-Werror", "-c", "-I",
+                        os.path.join(ROOT, "metalbt709decoder_amd", "csrc"), str(hsrc), "-o", str(hobj)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dis = subprocess.run(["objdump", "-d", str(hobj)], capture_output=True, text=True).stdout
+    assert "vfmadd" not in dis and "vmulss" in dis

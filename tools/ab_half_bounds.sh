@@ -1,7 +1,7 @@
 #!/bin/bash
 # Ceilings for the persistent 2:1 kernel (review item 3 of round 2), same call: stub builds with WRONG output that remove
 # work outright, so that the time they save bounds every exact formulation of the same idea from above.
-#   python -m metalbt709decoder_amd.build --variant tools/bin/libbt709hip_bound_<X>.so BT709_LAB_BOUND_<X>
+#   python tools/lab_variants.py tools/bin/libbt709hip_bound_<X>.so BT709_LAB_BOUND_<X>   (round 4: the gates live in tools/lab_variants.py, not in csrc/)
 # The parity spot check of a stub build fails by construction (bench.py then prints value null and exits 1); the launch time is what is read.
 cd "${GRAFT_REPO_ROOT:-.}"
 half() { python bench.py --workload 8k-half --no-cpu-baseline --steps 40 "$@" 2>/dev/null |

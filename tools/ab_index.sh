@@ -3,7 +3,7 @@
 # vs round 1's round-toward-zero add between two s_setreg (-DBT709_INDEX_RTZ), interleaved.
 #   1:1 kernel: tools/bin/decode_lab_rne vs decode_lab_rtz  (built by: see tools/decode_lab.hip header, +/- -DBT709_INDEX_RTZ)
 #   2:1 kernel: bench.py against the in-tree library vs tools/bin/libbt709hip_rtz.so
-#               (python -m metalbt709decoder_amd.build --variant tools/bin/libbt709hip_rtz.so BT709_INDEX_RTZ)
+#               (python tools/lab_variants.py tools/bin/libbt709hip_rtz.so BT709_INDEX_RTZ)
 cd "${GRAFT_REPO_ROOT:-.}"
 for round in 1 2 3; do
   for v in rne rtz; do echo "== decode_lab $v (round $round)"; tools/bin/decode_lab_$v 0 5 | head -2; done

@@ -1,7 +1,8 @@
 // Decode lab: times the PRODUCTION kernels (csrc/bt709_kernels.hip included verbatim) over a
 // ring of 64 distinct 4K frames, several launch shapes, interleaved rounds (median / min).
-// Build variants of the shipping kernels: -DBT709_INDEX_RTZ (round 1's floor index between two s_setreg),
-// -DBT709_NO_FMA_CENTRE, -DBT709_MAX_BLOCK_THREADS / -DBT709_QUADS_PER_LANE (tile shape).  With
+// Build variants of the shipping kernels: -DBT709_MAX_BLOCK_THREADS / -DBT709_QUADS_PER_LANE (tile shape); with
+// -DBT709_LAB_SRC (after `python tools/lab_variants.py --sources`) also -DBT709_INDEX_RTZ (round 1's floor index between
+// two s_setreg) and -DBT709_NO_FMA_CENTRE: those gates left csrc/ in round 4.  With
 // -DBT709_LAB_VARIANTS the lab copy tools/lab_quads_variants.hip is timed instead, whose own macros
 // (-DBT709_LAB_NO_LDS, _LDS_CHROMA, _ADJACENT, _LDS_PAD) select round 1's rejected variants.
 //
@@ -21,7 +22,11 @@
 #if defined(BT709_LAB_VARIANTS)  // round 1's kernel file with the rejected variants (see its header)
 #include "lab_quads_variants.hip"
 #else
+#if defined(BT709_LAB_SRC)  // python tools/lab_variants.py --sources: the product kernels with the experiment gates re-inserted
+#include "bin/lab_src/bt709_kernels.hip"
+#else
 #include "../metalbt709decoder_amd/csrc/bt709_kernels.hip"
+#endif
 #endif
 #if defined(BT709_LAB_LDS_CHROMA)
 #define LAB_EXTRA_LDS 4096

@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Lab builds of libbt709hip.so: the product sources plus the experiment gates that used to live in csrc/.
+
+    python tools/lab_variants.py <out.so> [MACRO[=VALUE] | -flag ...]
+    python tools/lab_variants.py --list
+    python tools/lab_variants.py --sources      (only writes tools/bin/lab_src/, for tools/decode_lab.hip -DBT709_LAB_SRC)
+
+Until round 4 the shipped translation units carried `#if defined(BT709_LAB_...)` branches (several of them WRONG-OUTPUT stubs
+that delete work to measure a ceiling) one -D away from the product.  They are gone from csrc/: this script copies csrc/ to
+tools/bin/lab_src/, re-inserts the gates below by exact text substitution (it fails loudly when the product text it
+anchors on has changed -- then the experiment has to be re-stated against the new kernel, which is the point), and compiles
+the copy with the requested macros through metalbt709decoder_amd.build's own flags.  The result is for bench.py --library /
+tools/ab_libs.py only; nothing under tools/ is part of the product and a CPU test asserts csrc/ holds none of these macros.
+
+Gates (macro -> what it does; profiles/ file it produced):
+  BT709_LAB_NO_ARITH      1:1 kernel, WRONG OUTPUT: loads and stores with (almost) no arithmetic   r03_ab_ceiling.txt
+  BT709_LAB_NO_LOADS      with NO_ARITH: the launch's stores alone                                  r03_ab_loads_stores_only.txt
+  BT709_LAB_NO_STORES     with NO_ARITH: the launch's loads alone                                   r03_ab_loads_stores_only.txt
+  BT709_LAB_NO_TABLE      with NO_ARITH: no table staging / barrier
+  BT709_NO_FMA_CENTRE     centre_norm as add + multiply instead of one fma (same bytes out)         r02 ab_fma
+  BT709_INDEX_RTZ         bucket index by a round-toward-zero add between two s_setreg (same bytes) r02 ab_index
+  BT709_UNIFORM_INDEX_TWO_STEP   2:1 kernel encode index as multiply, then add (same bytes)
+  BT709_REP_SPLIT_ENCODE  persistent 2:1 kernel with the two-resolution encode table (same bytes)
+  BT709_LAB_BOUND_SHARED_INDEX   2:1 kernel, WRONG OUTPUT: 4 index adds per block instead of 12     r03_half_bounds.txt
+  BT709_LAB_BOUND_ONE_ENCODE     2:1 kernel, WRONG OUTPUT: one encode lookup instead of three       r03_half_bounds.txt
+  BT709_LAB_HALF_TABLE    2:1 kernel, WRONG OUTPUT: half-size decode-side table                     r03_ab_half_table.txt
+"""
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LAB_SRC = os.path.join(ROOT, "tools", "bin", "lab_src")
+
+# (file, product text, lab text).  Every product text must occur exactly once.
+GATES = [
+    ("bt709_kernels.hip",
+     """    ya[u] = load32<NT>(y0 + 4 * q);
+    yb[u] = load32<NT>(y1 + 4 * q);
+    cw[u] = load32<NT>(cc + 4 * q);
+""",
+     """#if defined(BT709_LAB_NO_LOADS)  // with BT709_LAB_NO_ARITH: the launch's stores alone
+    ya[u] = q * 3u, yb[u] = q * 5u, cw[u] = q * 7u + rp;
+#else
+    ya[u] = load32<NT>(y0 + 4 * q);
+    yb[u] = load32<NT>(y1 + 4 * q);
+    cw[u] = load32<NT>(cc + 4 * q);
+#endif
+"""),
+    ("bt709_kernels.hip",
+     """  if (!QUANT) {  // the sRGB mode needs no table (decode_quad)
+    stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the tile's loads are in flight
+    __syncthreads();
+  }
+""",
+     """#if !defined(BT709_LAB_NO_TABLE)  // with BT709_LAB_NO_ARITH: without the per-workgroup table staging and its barrier too
+  if (!QUANT) {
+    stage_table(lds_raw, p.table_unit, p.table_unit_bytes);
+    __syncthreads();
+  }
+#endif
+"""),
+    ("bt709_kernels.hip",
+     """    decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
+                           bot);
+    if (q < quads && rp_raw < row_pairs) {
+""",
+     """#if defined(BT709_LAB_NO_ARITH)  // WRONG OUTPUT: the launch's loads and stores with (almost) no arithmetic
+    top = u32x4{ya[u], yb[u], cw[u], ya[u] ^ cw[u]};
+    bot = u32x4{yb[u], cw[u], ya[u], yb[u] ^ cw[u]};
+#else
+    decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
+                           bot);
+#endif
+#if defined(BT709_LAB_NO_STORES)  // with BT709_LAB_NO_ARITH: the loads alone (a store about once in 2^32 quads keeps them alive)
+    if (q < quads && rp_raw < row_pairs && (top.w ^ bot.w) == 0x9e3779b9u) {
+#else
+    if (q < quads && rp_raw < row_pairs) {
+#endif
+"""),
+    ("bt709_device.h",
+     """  return __builtin_fmaf(v, kInv255, -off * kInv255);
+""",
+     """#if defined(BT709_NO_FMA_CENTRE)  // the two-instruction form
+  return __fmul_rn(__fadd_rn(v, -off), kInv255);
+#else
+  return __builtin_fmaf(v, kInv255, -off * kInv255);
+#endif
+"""),
+    ("bt709_device.h",
+     """__device__ __forceinline__ void magic_index12(const float *x, uint32_t *t, float magic) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
+}
+
+__device__ __forceinline__ void magic_index4(const float *x, uint32_t *t, float magic) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
+}
+""",
+     """#if defined(BT709_INDEX_RTZ)  // round 1: floor(x N); the adds of a batch sit between two writes of MODE.fp_round
+__device__ __forceinline__ void magic_index12(const float *x, uint32_t *t, float magic) {
+  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\\n\\t"
+      "v_add_f32 %0, %24, %12\\n\\tv_add_f32 %1, %24, %13\\n\\tv_add_f32 %2, %24, %14\\n\\tv_add_f32 %3, %24, %15\\n\\t"
+      "v_add_f32 %4, %24, %16\\n\\tv_add_f32 %5, %24, %17\\n\\tv_add_f32 %6, %24, %18\\n\\tv_add_f32 %7, %24, %19\\n\\t"
+      "v_add_f32 %8, %24, %20\\n\\tv_add_f32 %9, %24, %21\\n\\tv_add_f32 %10, %24, %22\\n\\tv_add_f32 %11, %24, %23\\n\\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+        "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
+        "v"(x[10]), "v"(x[11]), "s"(magic));
+}
+
+__device__ __forceinline__ void magic_index4(const float *x, uint32_t *t, float magic) {
+  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\\n\\t"
+      "v_add_f32 %0, %8, %4\\n\\tv_add_f32 %1, %8, %5\\n\\tv_add_f32 %2, %8, %6\\n\\tv_add_f32 %3, %8, %7\\n\\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(magic));
+}
+#else
+__device__ __forceinline__ void magic_index12(const float *x, uint32_t *t, float magic) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
+}
+
+__device__ __forceinline__ void magic_index4(const float *x, uint32_t *t, float magic) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
+}
+#endif
+"""),
+    ("transfer_tables.cpp",
+     """  volatile float s = x + magic;  // binary32 add, round to nearest even (volatile: no excess precision, no folding)
+""",
+     """#if defined(BT709_INDEX_RTZ)
+  const int mode = std::fegetround();
+  std::fesetround(FE_TOWARDZERO);
+  volatile float s = x + magic;
+  std::fesetround(mode);
+#else
+  volatile float s = x + magic;
+#endif
+"""),
+    ("bt709_rescale.hip",
+     """  const uint32_t t = __float_as_uint(__builtin_fmaf(s, r.sum_to_xs, 8388608.0f));
+""",
+     """#if defined(BT709_UNIFORM_INDEX_TWO_STEP)  // round 2's first form: multiply, then add
+  const uint32_t t = __float_as_uint(__fadd_rn(__fmul_rn(s, r.sum_to_xs), 8388608.0f));
+#else
+  const uint32_t t = __float_as_uint(__builtin_fmaf(s, r.sum_to_xs, 8388608.0f));
+#endif
+"""),
+    ("transfer_tables.cpp",
+     """  volatile float t = std::fmaf(v, n, 8388608.0f);  // one rounding of v n + 2^23, as the kernel's v_fma_f32
+""",
+     """#if defined(BT709_UNIFORM_INDEX_TWO_STEP)
+  volatile float xs = v * n;
+  volatile float t = xs + 8388608.0f;
+#else
+  volatile float t = std::fmaf(v, n, 8388608.0f);
+#endif
+"""),
+    ("bt709_rescale.hip",
+     """  magic_index12(x, t, r.magic);
+#pragma unroll
+  for (int h = 0; h < 12 / kLinBatch; ++h) {""",
+     """#if defined(BT709_LAB_BOUND_SHARED_INDEX)
+  // WRONG OUTPUT: G and B reuse R's four bucket indices -- what the launch would take if the index of a block's 12
+  // evaluations cost 4 adds instead of 12 (the ceiling of any "index from the luma term alone" form)
+  magic_index4(x, t, r.magic);
+#pragma unroll
+  for (int i = 4; i < 12; ++i) t[i] = t[i & 3];
+#else
+  magic_index12(x, t, r.magic);
+#endif
+#pragma unroll
+  for (int h = 0; h < 12 / kLinBatch; ++h) {"""),
+    ("bt709_rescale.hip",
+     """  if (UNIFORM_ENCODE) return pack_bgra(encode_byte_uniform(r, sr), encode_byte_uniform(r, sg), encode_byte_uniform(r, sb), alpha_word);
+""",
+     """#if defined(BT709_LAB_BOUND_ONE_ENCODE)
+  // WRONG OUTPUT: one encode-side lookup instead of three (sg, sb still formed and consumed)
+  if (UNIFORM_ENCODE) {
+    const uint32_t e = encode_byte_uniform(r, sr);
+    return pack_bgra(e, e + (sg > sr ? 1u : 0u), e + (sb > sr ? 1u : 0u), alpha_word);
+  }
+#endif
+  if (UNIFORM_ENCODE) return pack_bgra(encode_byte_uniform(r, sr), encode_byte_uniform(r, sg), encode_byte_uniform(r, sb), alpha_word);
+"""),
+    ("bt709_rescale.hip",
+     """constexpr bool kRepUniformEncode = true;
+""",
+     """#if defined(BT709_REP_SPLIT_ENCODE)
+constexpr bool kRepUniformEncode = false;
+#else
+constexpr bool kRepUniformEncode = true;
+#endif
+"""),
+    ("bt709_rescale.hip",
+     """  DecodeParams p = p_in;
+  const uint64_t kRepLdsBytes =""",
+     """  DecodeParams p = p_in;
+#if defined(BT709_LAB_HALF_TABLE)  // WRONG OUTPUT: half as many (coarser) decode-side buckets = the LDS footprint of 8-byte entries
+  p.unit_magic = p.unit_magic * 2.0f;
+  p.table_linear_bytes = (p.table_linear_bytes / 2 + 31u) & ~15u;
+#endif
+  const uint64_t kRepLdsBytes ="""),
+]
+
+MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT709_LAB_NO_TABLE", "BT709_NO_FMA_CENTRE",
+          "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
+          "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE"]
+
+
+def make_lab_sources(dst=LAB_SRC):
+    """csrc/ copied to `dst` with every gate re-inserted; returns dst."""
+    from metalbt709decoder_amd import build as b
+    if os.path.isdir(dst):
+        shutil.rmtree(dst)
+    shutil.copytree(b.CSRC, dst)
+    for name, product, lab in GATES:
+        path = os.path.join(dst, name)
+        text = open(path).read()
+        if text.count(product) != 1:
+            raise SystemExit("tools/lab_variants.py: the product text this gate anchors on occurs %d times in csrc/%s "
+                             "(expected once): re-state the experiment against the current kernel\n---\n%s"
+                             % (text.count(product), name, product))
+        open(path, "w").write(text.replace(product, lab))
+    # the copy sits two levels deeper than csrc/: point its include of the public header at the real one
+    for name in os.listdir(dst):
+        path = os.path.join(dst, name)
+        text = open(path).read()
+        if '"../../include/bt709hip.h"' in text:
+            open(path, "w").write(text.replace('"../../include/bt709hip.h"', '"%s"' % os.path.join(ROOT, "include", "bt709hip.h")))
+    return dst
+
+
+def main(argv):
+    if not argv or argv[0] in ("-h", "--help"):
+        print(__doc__)
+        return 0
+    if argv[0] == "--list":
+        print("\n".join(MACROS))
+        return 0
+    if argv[0] == "--sources":
+        print(make_lab_sources())
+        return 0
+    from metalbt709decoder_amd import build as b
+    out = os.path.abspath(argv[0])
+    src = make_lab_sources()
+    print("built", b.build_variant(out, argv[1:], csrc=src))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -105,9 +105,14 @@ __device__ __forceinline__ void walk_landed(WalkIn &in) {
 
 }  // namespace
 
+// lab-only launch fields (they lived in the product's DecodeParams until round 4)
+struct WalkParams : DecodeParams {
+  uint32_t walk_stagger, walk_cus;  // start-up stagger and the CU count
+};
+
 template <bool NT>
 __global__ void __launch_bounds__(kMaxBlockThreads)
-decode_nv12_quads_walk(const DecodeParams p) {
+decode_nv12_quads_walk(const WalkParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t row_pairs = p.height >> 1, quads = p.width >> 2;
   const uint32_t G = gridDim.x;
@@ -190,7 +195,8 @@ decode_nv12_quads_walk(const DecodeParams p) {
 
 const char *launch_decode_walk(const DecodeParams &p_in, int frames, bool nontemporal, uint32_t workgroups,
                                uint32_t block_threads, uint32_t compute_units, uint32_t stagger, hipStream_t stream) {
-  DecodeParams p = p_in;
+  WalkParams p;
+  static_cast<DecodeParams &>(p) = p_in;
   p.walk_cus = compute_units ? compute_units : 256u;
   p.walk_stagger = stagger;
   const uint32_t quads = p.width / 4, row_pairs = p.height / 2;
