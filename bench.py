@@ -3,32 +3,35 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|8k-half|4k-batch8]
 
-A "step" is one pass of the hot path over one batch of synthetic frames already
-resident in HBM: the whole ring of `--ring` distinct frames (default 64 x 4K =
-0.8 GB in + 2.1 GB out, far beyond the 256 MB Infinity Cache, so the kernel streams
-from and to HBM), issued as ring/32 launches of 32 frames (grid.z = frame; 1080p: 128 per launch).
-For N > 1 the driver starts one process per GPU (torch.distributed.run); every rank
-owns a ring on its own GPU and decodes it with no data-path collective (frames are
-independent); rank 0 prints ONE JSON line with the whole-job Gpixel/s.
+A "step" is one pass of the hot path over one batch of synthetic frames already resident in HBM: the whole ring of
+`--ring` distinct frames (default 256 x 4K = 3.2 GB in + 8.5 GB out, far beyond the 256 MB Infinity Cache, so the kernel
+streams from and to HBM), issued as ONE bt709hip_decode_batch launch (grid.z = frame; the XCD-aware work map).  The ring is
+the product's: bt709hip_ring_create allocates it and hunts for a fast-streaming placement (untimed set-up); the ring this
+process allocated first, without a hunt, is timed too and reported as roofline.first_allocation_frac.
 
---workload 4k-batch8 is BASELINE config 5 as written: a step is 8 x 4K frames in total, frame i
-goes to rank i mod N, so a rank decodes 8/N frames per step in one launch (N = 8: one 4K frame =
-one ~8 us kernel per step, launch-bound) -- strong scaling.  --share M runs a single rank with the
-share of an 8/M-GPU job; --graph replays the K steps from one recorded HIP graph.
+--gpus N > 1: one process per GPU.  Either the driver starts them (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE in
+the environment) or -- a plain `python3 bench.py --gpus N` -- this script starts its own N ranks (self_launch) and relays rank
+0's single JSON line.  Every rank owns a ring on its own GPU and decodes it with no data-path collective (frames are
+independent); torch.distributed (gloo, CPU tensors) carries the barrier and the MAX over ranks only.
 
-Timing: W warmup steps, then the region of EXACTLY K steps -- barrier + stream sync, K steps, stream sync +
-barrier, MAX over ranks -- is timed (`k_step_region_ms`).  With the driver's K = 20 that is ~10 ms of work, so
-the reported figure comes from regions of m * K steps bracketed the same way, m the smallest integer that makes
-a region >= 100 ms (`region_steps`), measured `repeats` times (>= 5); the MEDIAN is reported (min / max beside
-it) and `ms_per_step` is per step.  roofline.achieved comes from HIP events recorded
-on the launch stream around the same steps of the median region; roofline.same_run_copy_GBps is a
-16-byte-per-lane non-temporal copy over the same slabs, timed in the same process (the box's own copy
-ceiling).  cpu_baseline (rank 0, N=1 only) times the reference's own per-pixel
-function (oracle/_ref, kind "reference") or, when that library is absent, the CPU
-oracle (kind "port") on a bounded sample of the same frames over the host cores.
+--workload 4k-batch8 is BASELINE config 5 as written: a step is 8 x 4K frames in total, frame i goes to rank i mod N, so a
+rank decodes 8/N frames per step in one launch (N = 8: one 4K frame = one ~8 us kernel per step, launch-bound) -- strong
+scaling.  --share M runs a single rank with the share of an 8/M-GPU job; --graph replays the K steps from one recorded HIP
+graph; --coalesce n turns on the decoder's coalescing submit (one-frame calls gathered n to a launch).
 
---dry-run replaces the GPU work by a sleep so the multi-process control flow
-(rendezvous, barriers, max over ranks, single JSON line) can be tested on CPU.
+Timing: W warmup steps, then the region of EXACTLY K steps -- barrier + stream sync, K steps, stream sync + barrier, MAX
+over ranks -- is timed (`k_step_region_ms`).  With the driver's K = 20 that is ~36 ms of work, so the reported figure comes
+from regions of m * K steps bracketed the same way, m the smallest integer that makes a region >= 100 ms (`region_steps`),
+measured `repeats` times (>= 5); the MEDIAN is reported (min / max beside it) and `ms_per_step` is per step.
+roofline.achieved comes from HIP events recorded on the launch stream around the same steps of the median region;
+roofline.same_run_copy_GBps is a 16-byte-per-lane non-temporal copy over the same slabs, timed in the same process.  Every
+region that counts is bracketed by two sentinel dispatches outside both clocks, so a rocprofv3 kernel trace of this command
+can be cut down to the timed launches (tools/pmc_summary.py).  cpu_baseline (rank 0, N=1 only) times the reference's own
+per-pixel function (oracle/_ref, kind "reference") or, when that library is absent, the CPU oracle (kind "port") on a
+bounded sample of the same frames over the host cores.
+
+--dry-run replaces the GPU work by a sleep so the multi-process control flow (self-launch or rendezvous, barriers, max over
+ranks, single JSON line) can be tested on CPU.
 """
 import argparse
 import ctypes as C
@@ -84,7 +87,10 @@ def parse_args(argv=None):
                     help="4k-batch8 only: issue consecutive steps round-robin on this many HIP streams (one stream "
                          "per in-flight frame); 0 = auto (2: measured best for every share, profiles/r02_batch8_streams*.txt)")
     ap.add_argument("--placement-tries", type=int, default=6,
-                    help="allocate the ring this many times, time the step's launch on each (untimed set-up), keep the fastest, free the rest")
+                    help="bt709hip_ring_create's `tries`: candidates per slab of the ring, the fastest-streaming pairing kept (untimed "
+                         "set-up); 1 = first allocation only")
+    ap.add_argument("--coalesce", type=int, default=0,
+                    help="BT709HIP_OPT_COALESCE: gather this many one-frame submits into one launch (4k-batch8; 0 = off)")
     ap.add_argument("--stream-priorities", default="", metavar="P1,P2,...",
                     help="4k-batch8: scheduling priority of the 2nd, 3rd, ... stream (0 normal, -1 higher, 1 lower); lab knob")
     ap.add_argument("--no-smooth-leg", action="store_true", help="skip the extra smooth-content measurement (N=1, 4k)")
@@ -134,7 +140,8 @@ class GpuRunner:
         import numpy as np
         import metalbt709decoder_amd as mb
         from metalbt709decoder_amd import _capi
-        from metalbt709decoder_amd._capi import Frame, Surface
+        from metalbt709decoder_amd._capi import Frame, Surface, RingPlacement
+        self.RingPlacement = RingPlacement
         self.np, self._capi, self.g, self.args, self.rank = np, _capi, g, args, rank
         gamma = GAMMAS[args.gamma]
         if args.library:
@@ -160,11 +167,10 @@ class GpuRunner:
             k, v = kv.split("=")
             self.dec.setOption(int(k), int(v))
         assert self.dec.setupMetal(), self.dec.lastStatus
+        if args.coalesce:
+            self.dec.setOption(_capi.OPT_COALESCE, args.coalesce)
 
         lib, h = self.lib, self.h
-        ring, W, H, OW, OH = g["ring"], g["W"], g["H"], g["OW"], g["OH"]
-        self.in_stride = in_stride = (g["y_bytes"] + g["c_bytes"] + 255) // 256 * 256
-        self.out_stride = out_stride = (g["o_bytes"] + 255) // 256 * 256
         self.ev0, self.ev1, self.ev_fork = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _capi.check(lib.bt709hip_event_create(h, C.byref(self.ev0)))
         _capi.check(lib.bt709hip_event_create(h, C.byref(self.ev1)))
@@ -173,10 +179,26 @@ class GpuRunner:
         self.stream = None    # launch stream: the context's default, or a created one when recording a graph
         self.extra_streams, self.join_events = [], []
         self.host_frames = {}
-        # ranks that share a device (functional runs on a smaller box) would hunt over each other's memory: no hunt there
+        self.scratch = C.c_void_p()  # sentinel dispatches (tools/pmc_summary.py finds the timed regions in a kernel trace by them)
+        _capi.check(lib.bt709hip_malloc(h, 128 << 10, C.byref(self.scratch)))
+        # THE RING IS THE PRODUCT'S: bt709hip_ring_create (include/bt709hip.h, csrc/bt709_ring.cpp) allocates the two slabs and,
+        # with tries > 1, hunts for a fast-streaming input x output pairing with the decoder's own launch as the probe --
+        # rounds 2-3 did that inside this file.  Two rings are made: `first` with tries = 1 = this process's FIRST ALLOCATION
+        # (what a caller of plain bt709hip_malloc gets; measured after the headline and reported as
+        # roofline.first_allocation_frac), then the hunted one the headline runs on.  Ranks that share a device (functional
+        # runs on a smaller box) would hunt over each other's memory: one ring, no hunt, there.
         shared = int(os.environ.get("WORLD_SIZE", "1")) > ndev
-        self.placement = self.place_ring(1 if shared else max(1, args.placement_tries), gamma)
+        tries = 1 if shared else max(1, args.placement_tries)
+        self.rings = {}
+        self.rings["first"] = self.make_ring(1)
+        self.use_ring("first")
+        self.sample_frames = sample_frames(g["ring"])
         self.fill_ring(args.content)
+        if tries > 1:
+            self.rings["hunted"] = self.make_ring(tries)
+            self.copy_ring_input("first", "hunted")
+            self.use_ring("hunted")
+        self.placement = self.placement_report()
         self.pos = 0          # 4k-batch8: ring position of the next step
         self.graph = None
         self.turn = 0
@@ -213,98 +235,49 @@ class GpuRunner:
             self.step()
             self.sync()
 
-    def bind_ring(self, d_in, d_out, gamma):
+    def make_ring(self, tries):
         g = self.g
-        self.d_in, self.d_out = d_in, d_out
+        r = C.c_void_p()
+        self._capi.check(self.lib.bt709hip_ring_create(self.dec._handle, g["W"], g["H"], g["ring"], 1 if g["half"] else 0, tries,
+                                                       C.byref(r)), "bt709hip_ring_create")
+        return r
+
+    def use_ring(self, name):
+        """Frame / surface descriptors of ring `name` as the arrays the launches take."""
+        g, ring = self.g, self.rings[name]
+        self.ring_name = name
         self.frames = (self.Frame * g["ring"])()
         self.surfs = (self.Surface * g["ring"])()
         for i in range(g["ring"]):
-            base = d_in.value + i * self.in_stride
-            self.frames[i] = self.Frame(base, g["W"], base + g["y_bytes"], g["W"], g["W"], g["H"], 1, TRANSFER_TAG[gamma])
-            self.surfs[i] = self.Surface(d_out.value + i * self.out_stride, g["OW"] * 4, g["OW"], g["OH"])
+            self._capi.check(self.lib.bt709hip_ring_frame(ring, i, C.byref(self.frames[i]), None, C.byref(self.surfs[i])))
+        self.in_stride = self.frames[1].y - self.frames[0].y if g["ring"] > 1 else g["y_bytes"] + g["c_bytes"]
+        self.out_stride = self.surfs[1].bgra - self.surfs[0].bgra if g["ring"] > 1 else g["o_bytes"]
+        self.d_in, self.d_out = C.c_void_p(self.frames[0].y), C.c_void_p(self.surfs[0].bgra)
 
-    def place_ring(self, tries, gamma):
-        """Where a slab lands in HBM decides how fast it streams: the same launch runs at 0.74-0.82 of the roofline on
-        different allocations made by ONE process, each allocation keeping its rate (tools/placement_hunt.py).  The output
-        slab carries most of it, the input slab about a percent, and the pairing matters (tools/placement_cross.py: 5 x 5
-        slabs of one process, 0.74-0.825).  Untimed set-up: allocate `tries` input and `tries` output slabs (all alive, so
-        they land in different places), time the step's own launches on the pairings of them (hunt_pairing) -- the input is
-        whatever the memory holds, any bytes decode --, keep the fastest pairing, free the rest.  Reported in
-        config.placement."""
-        lib, h, g = self.lib, self.h, self.g
+    def copy_ring_input(self, src, dst):
+        """Device-to-device: the frames uploaded into ring `src` also become ring `dst`'s (same layout)."""
+        f0, f1 = self.Frame(), self.Frame()
+        self._capi.check(self.lib.bt709hip_ring_frame(self.rings[src], 0, C.byref(f0), None, None))
+        self._capi.check(self.lib.bt709hip_ring_frame(self.rings[dst], 0, C.byref(f1), None, None))
+        self._capi.check(self.lib.bt709hip_copy_probe(self.h, f1.y, f0.y, self.in_stride * self.g["ring"], None), "ring copy")
+        self._capi.check(self.lib.bt709hip_stream_synchronize(self.h, None))
 
-        def slabs(nbytes):
-            got = []
-            for _ in range(tries):
-                d = C.c_void_p()
-                if lib.bt709hip_malloc(h, nbytes, C.byref(d)) != 0:  # out of memory: hunt among what we have
-                    break
-                got.append(d)
-            return got
-        ins, outs = slabs(self.in_stride * g["ring"]), slabs(self.out_stride * g["ring"])
-        if not ins or not outs:
-            raise self._capi.Bt709Error(self._capi.ERR_HIP, "ring allocation")
-        probed = {}
-        # a probe = ~15 ms of the step's own launches (3 launches resolved the top candidates to only +-1.5 %: the first
-        # version of this hunt picked a 0.822 probe that then ran at 0.809)
-        reps = max(3, -(-8 * 256 * 3840 * 2160 // (g["per_launch"] * g["W"] * g["H"])))
-
-        def measure(i, o, n, warm_s):
-            self.bind_ring(ins[i], outs[o], gamma)
-            t_end = time.perf_counter() + warm_s
-            while time.perf_counter() < t_end:
-                self.launch(0, g["per_launch"])
-                self.sync()
-            self.mark(0)
-            for _ in range(n):
-                self.launch(0, g["per_launch"])
-            self.mark(1)
-            self.sync()
-            return g["bytes_per_frame"] * g["per_launch"] * n / (self.event_ms() / 1e3) / 1e9
-
-        # The output slabs come in two regimes (~0.74 / ~0.80+); a process whose candidates all look alike under input 0 may hold
-        # six slow ones (seen: 4 of 4, 6 of 8 on some boxes), so it allocates `tries` more, up to three times; then the
-        # `tries` fastest stay in the hunt.
-        prescan = []
-        while tries > 1:
-            for o in range(len(prescan), len(outs)):
-                prescan.append(measure(0, o, reps, 0.15 if not prescan else 0.03))
-            # always twice `tries` outputs (the fast regime itself spreads over 1 %: 6.47-6.60 TB/s between processes), three
-            # times when they still all look alike
-            if len(outs) >= 3 * tries or (len(outs) >= 2 * tries and (max(prescan) - min(prescan)) / max(prescan) >= 0.02):
-                break
-            more = slabs(self.out_stride * g["ring"])
-            if not more:
-                break
-            outs += more
-        if len(outs) > tries:
-            keep = sorted(sorted(range(len(outs)), key=lambda o: -prescan[o])[:tries])
-            for o in range(len(outs)):
-                if o not in keep:
-                    lib.bt709hip_free(h, outs[o])
-            outs = [outs[o] for o in keep]
-
-        def probe(i, o):
-            if (i, o) not in probed:
-                probed[(i, o)] = measure(i, o, reps, 0.03)
-            return probed[(i, o)]
-        bi, bo = hunt_pairing(len(ins), len(outs), probe)
-        confirmed = {}
-        if len(probed) > 3:  # the three best of the scan again, three times as long: the choice is made on these
-            for k in sorted(probed, key=probed.get, reverse=True)[:3]:
-                confirmed[k] = measure(k[0], k[1], 3 * reps, 0.03)
-            bi, bo = max(confirmed, key=confirmed.get)
-        for k, d in enumerate(ins):
-            if k != bi:
-                lib.bt709hip_free(h, d)
-        for k, d in enumerate(outs):
-            if k != bo:
-                lib.bt709hip_free(h, d)
-        self.bind_ring(ins[bi], outs[bo], gamma)
-        return {"tries": [len(ins), len(outs)], "chosen": [bi, bo],
-                "probe_GBps": {"%d,%d" % k: round(v, 1) for k, v in sorted(probed.items())},
-                "confirm_GBps": {"%d,%d" % k: round(v, 1) for k, v in sorted(confirmed.items())},
-                "output_prescan_GBps": [round(v, 1) for v in prescan]}
+    def placement_report(self):
+        """config.placement: what bt709hip_ring_create did for the ring the headline runs on (untimed set-up)."""
+        p = self.RingPlacement()
+        self._capi.check(self.lib.bt709hip_ring_placement_info(self.rings[self.ring_name], C.byref(p)))
+        free_b, total_b = C.c_size_t(), C.c_size_t()
+        self._capi.check(self.lib.bt709hip_mem_info(self.h, C.byref(free_b), C.byref(total_b)))
+        kept = [k for k in p.out_kept if k >= 0]
+        return {"allocator": "bt709hip_ring_create (csrc/bt709_ring.cpp): candidates per slab, the decoder's own launch as the probe",
+                "tries": p.tries, "candidates": [p.in_candidates, p.out_candidates], "chosen": [p.chosen_in, p.chosen_out],
+                "pairings_probed": p.probes,
+                "probe_GBps": {"first_pairing": round(p.first_GBps, 1), "chosen_confirmed": round(p.chosen_GBps, 1),
+                               "best": round(p.best_GBps, 1), "worst": round(p.worst_GBps, 1)},
+                # allocation order; `kept` = the indices (same order) that went on to the pairing probes
+                "output_prescan_GBps": [round(v, 1) for v in p.out_prescan_GBps[:p.out_candidates]], "output_kept": kept,
+                "rings_resident": sorted(self.rings), "device_memory_free_GB": round(free_b.value / 1e9, 1),
+                "device_memory_total_GB": round(total_b.value / 1e9, 1)}
 
     def fill_ring(self, content):
         """Uploads (outside every timed region) the ring's frames: seeded PRNG bytes or smooth planes."""
@@ -324,8 +297,8 @@ class GpuRunner:
             self._capi.check(lib.bt709hip_upload(h, self.d_in.value + i * self.in_stride, buf.shape[1], buf.ctypes.data,
                                                  buf.shape[1], buf.shape[1], 1, None), "upload")
             self._capi.check(lib.bt709hip_stream_synchronize(h, None))
-            if i == 0:
-                self.host_frames[0] = buf.reshape(-1)
+            if i in self.sample_frames:
+                self.host_frames[i] = buf.reshape(-1)
 
     def launch(self, first, n, stream=None):
         stream = stream if stream is not None else self.stream
@@ -412,26 +385,55 @@ class GpuRunner:
         times.sort()
         return 2 * half / (times[len(times) // 2] / 1e3) / 1e9
 
+    def sentinel(self, closing):
+        """A tiny copy dispatch (512 lanes opening, 1024 closing) outside the timed bracket: tools/pmc_summary.py averages only the
+        decode dispatches between an opening and a closing sentinel of a rocprofv3 kernel trace."""
+        self._capi.check(self.lib.bt709hip_copy_probe(self.h, self.scratch.value + (64 << 10), self.scratch.value,
+                                                      (32 << 10) if closing else (4 << 10), self.stream), "sentinel")
+
     def spot_check(self, gamma):
-        """Untimed: 16 output rows at the top, middle and bottom of ring frame 0 against the oracle."""
+        """Untimed parity tripwire over the launch the headline times: 16 output rows at the top, middle and bottom of one frame
+        out of EACH of the 8 XCD bands of the launch (ring frames 0, 37, 70, 103, 136, 169, 202, 255 of 256: the banded map gives
+        band b the frames [b F/8, (b+1) F/8), csrc/bt709_kernels.hip) -- the last rows of the last frame included -- against the
+        oracle.  The ring is decoded once more first, so the bytes compared are the ones the timed launch shape writes."""
         import oracle_lib
         np, g = self.np, self.g
         rows = 16
-        y, c = split_planes(self.host_frames[0], g)
+        self.run_steps(1)
+        if g["batch8"]:  # a step is a share of the ring there: decode every sampled frame's launch
+            for i in self.sample_frames:
+                self.launch(i - i % g["per_launch"], g["per_launch"])
+        self.sync()
         o = oracle_lib.Oracle()
-        for r0 in (0, (g["OH"] // 2) // 4 * 4, g["OH"] - rows):
-            got = np.empty((rows, g["OW"] * 4), np.uint8)
-            self._capi.check(self.lib.bt709hip_download(self.h, got.ctypes.data, got.shape[1],
-                                                        self.surfs[0].bgra + r0 * self.surfs[0].stride,
-                                                        self.surfs[0].stride, got.shape[1], rows, self.stream))
-            self.sync()
-            if g["half"]:
-                want = o.decode_nv12_half(gamma, y[2 * r0:2 * (r0 + rows)], c[r0:r0 + rows])
-            else:
-                want = o.decode_nv12(gamma, y, c, rows=(r0, r0 + rows))[r0:r0 + rows]
-            if not np.array_equal(got, want):
-                return "MISMATCH at output row %d" % r0
+        checked = []
+        for i in self.sample_frames:
+            y, c = split_planes(self.host_frames[i], g)
+            for r0 in (0, (g["OH"] // 2) // 4 * 4, g["OH"] - rows):
+                got = np.empty((rows, g["OW"] * 4), np.uint8)
+                self._capi.check(self.lib.bt709hip_download(self.h, got.ctypes.data, got.shape[1],
+                                                            self.surfs[i].bgra + r0 * self.surfs[i].stride,
+                                                            self.surfs[i].stride, got.shape[1], rows, self.stream))
+                self.sync()
+                if g["half"]:
+                    want = o.decode_nv12_half(gamma, y[2 * r0:2 * (r0 + rows)], c[r0:r0 + rows])
+                else:
+                    want = o.decode_nv12(gamma, y, c, rows=(r0, r0 + rows))[r0:r0 + rows]
+                if not np.array_equal(got, want):
+                    return "MISMATCH in ring frame %d at output row %d" % (i, r0)
+            checked.append(i)
+        self.spot_frames = checked
         return "ok"
+
+
+def sample_frames(ring):
+    """One frame of each eighth of the ring (= each XCD band of a whole-ring launch), first and last frame included."""
+    if ring < 8:
+        return list(range(ring))
+    per = ring // 8
+    picks = {0, ring - 1}
+    for b in range(1, 7):
+        picks.add(b * per + (b + 4) % per)
+    return sorted(picks)
 
 
 class DryRunner:
@@ -456,21 +458,8 @@ class DryRunner:
     def kernel_name(self):
         return "dry-run"
 
-
-def hunt_pairing(n_in, n_out, probe, exhaustive_up_to=36):
-    """Which input slab with which output slab (GpuRunner.place_ring): probe(i, o) -> rate.  The output slab carries most of the
-    placement effect, the input slab a percent, and they interact (profiles/r03_placement_cross.txt: on that 5 x 5 matrix a
-    row / column / row descent stops at 0.8187 where the best pairing is 0.8251), so every pairing is probed while that is
-    cheap (<= exhaustive_up_to probes of ~50 ms); beyond that: every output under input 0, every input under the best output,
-    the outputs again under the best input."""
-    if n_in <= 1 and n_out <= 1:
-        return 0, 0
-    if n_in * n_out <= exhaustive_up_to:
-        return max(((i, o) for i in range(n_in) for o in range(n_out)), key=lambda k: probe(*k))
-    bo = max(range(n_out), key=lambda o: probe(0, o))
-    bi = max(range(n_in), key=lambda i: probe(i, bo))
-    bo = max(range(n_out), key=lambda o: probe(bi, o))
-    return bi, bo
+    def sentinel(self, closing):
+        pass
 
 
 def self_launch(n, argv, timeout_s=None):
@@ -560,9 +549,12 @@ def split_planes(buf, g):
     return y, c
 
 
-def timed_region(runner, steps, barrier):
+def timed_region(runner, steps, barrier, headline=False):
     """One measurement of EXACTLY `steps` steps: barrier + sync, the steps, sync + barrier.
-    Returns (host seconds, HIP-event milliseconds)."""
+    Returns (host seconds, HIP-event milliseconds).  headline: the region counts towards `value`; it is marked for a
+    profiler by two sentinel dispatches OUTSIDE both clocks (before the opening sync, after the closing one)."""
+    if headline:
+        runner.sentinel(False)
     runner.sync()
     barrier()
     t0 = time.perf_counter()
@@ -571,6 +563,9 @@ def timed_region(runner, steps, barrier):
     runner.mark(1)
     runner.sync()
     t1 = time.perf_counter()
+    if headline:
+        runner.sentinel(True)
+        runner.sync()
     barrier()
     return t1 - t0, runner.event_ms()
 
@@ -630,7 +625,7 @@ def main(argv=None):
     # asks for >= 100 ms per timing), so the figure that is reported as `value` comes from regions of m * K steps,
     # m the smallest integer that makes a region >= 100 ms (every rank must agree: MAX over ranks), bracketed the
     # same way; `ms_per_step` = median region / (m * K).
-    first = max_over_ranks(list(timed_region(runner, args.steps, barrier)))
+    first = max_over_ranks(list(timed_region(runner, args.steps, barrier, headline=True)))
     stretch = int(max(1, min(4096, -(-0.100 // max(first[0], 1e-6)))))
     stretch = int(max_over_ranks([float(stretch)])[0])
     region_steps = args.steps * stretch
@@ -640,7 +635,7 @@ def main(argv=None):
         repeats = int(max(5, min(40, -(-0.150 // (first[0] * stretch)))))
         repeats = int(max_over_ranks([float(repeats)])[0])
     while len(samples) < repeats:
-        samples.append(max_over_ranks(list(timed_region(runner, region_steps, barrier))))
+        samples.append(max_over_ranks(list(timed_region(runner, region_steps, barrier, headline=True))))
     samples.sort()
     elapsed, ev_ms = samples[len(samples) // 2]  # the median region (by host time) and ITS event time
     fastest, slowest = samples[0][0], samples[-1][0]
@@ -685,6 +680,7 @@ def main(argv=None):
                            step_text),
             "frames_per_step_per_gpu": g["frames_per_step"],
             "streams": getattr(runner, "nstreams", 1),
+            "coalesce": args.coalesce,
             "sharding": "independent frames per GPU, no collective",
             "launcher": ("self (bench.py started its %d ranks)" % world if os.environ.get("BT709_BENCH_SELF_LAUNCHED")
                          else "torch.distributed.run" if world > 1 else "single process"),
@@ -712,7 +708,9 @@ def main(argv=None):
         # parity tripwire on every run (rank 0 of a multi-GPU job too); a mismatch fails the run
         result["parity_spot_check"] = runner.spot_check(GAMMAS[args.gamma])
         failed = result["parity_spot_check"] != "ok"
+        result["parity_spot_frames"] = getattr(runner, "spot_frames", [])  # one ring frame per XCD band, 48 rows each
         if world == 1:
+            result["roofline"].update(first_allocation_leg(runner, args, g, barrier, region_steps, achieved))
             if args.workload == "4k" and args.content == "random" and not args.no_smooth_leg:
                 result["roofline"]["smooth_content"] = smooth_leg(runner, args, g, barrier, region_steps)
             copy_gbps = runner.copy_ceiling()
@@ -729,6 +727,26 @@ def main(argv=None):
         dist.destroy_process_group()
     if failed:
         sys.exit(1)
+
+
+def first_allocation_leg(runner, args, g, barrier, region_steps, hunted_gbps):
+    """The same launches, the same frames, on the ring this process allocated FIRST (bt709hip_ring_create with tries = 1 = two
+    plain allocations, what bt709hip_malloc gives a caller): regions bracketed like the headline's, median of 5.  Reported
+    beside roofline.frac, which comes from the ring the product's placement hunt chose -- the review's request: both numbers
+    from one process in one line."""
+    if "hunted" not in runner.rings:  # --placement-tries 1, or ranks sharing a device: the headline IS the first allocation
+        return {"first_allocation_frac": round(hunted_gbps / HBM_PEAK_GBPS, 4), "first_allocation_GBps": round(hunted_gbps, 1),
+                "first_allocation_note": "no hunt in this run: the headline ran on the first allocation"}
+    runner.use_ring("first")
+    runner.run_steps(max(3, args.warmup // 2))
+    regions = sorted(timed_region(runner, region_steps, barrier) for _ in range(5))
+    _, ev_ms = regions[len(regions) // 2]
+    avg_launch_s = (ev_ms / 1e3) / (region_steps * g["launches"])
+    gbps = g["bytes_per_frame"] * g["per_launch"] / avg_launch_s / 1e9
+    runner.use_ring("hunted")
+    return {"first_allocation_frac": round(gbps / HBM_PEAK_GBPS, 4), "first_allocation_GBps": round(gbps, 1),
+            "first_allocation_avg_launch_us": round(avg_launch_s * 1e6, 3),
+            "first_allocation_note": "same process, same frames, the ring allocated first with tries = 1 (plain allocations)"}
 
 
 def smooth_leg(runner, args, g, barrier, region_steps):

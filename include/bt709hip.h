@@ -528,6 +528,14 @@ int bt709hip_half_thresholds(int gamma, float *thresholds, int capacity);
 int bt709hip_half_lookup(int gamma, float x, int candidate_offset, int *table_entries);
 /* Name of the kernel the last decode on this thread launched (for profiling). */
 const char *bt709hip_last_kernel_name(void);
+/* Launch shape of the last bt709hip_decode / _decode_batch (1:1, BGRA8 target) this thread issued: grid and block of its
+ * first kernel launch, the number of launches it took (2: the XCD-aware map over a multiple of 8 frames plus the plain map
+ * over the rest) and the work map of the first (bt709hip_decoder_option BT709HIP_OPT_XCD_BANDS value actually used; 0 plain). */
+typedef struct {
+  uint32_t grid[3], block[3];
+  int32_t launches, xcd_bands;
+} bt709hip_launch_info;
+int bt709hip_last_launch_info(bt709hip_launch_info *info);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,10 @@ class RingPlacement(C.Structure):  # bt709hip_ring_placement
                 ("out_prescan_GBps", C.c_float * 18), ("out_kept", C.c_int32 * 18)]
 
 
+class LaunchInfo(C.Structure):  # bt709hip_launch_info
+    _fields_ = [("grid", C.c_uint32 * 3), ("block", C.c_uint32 * 3), ("launches", C.c_int32), ("xcd_bands", C.c_int32)]
+
+
 class DeviceInfo(C.Structure):  # bt709hip_device_info
     _fields_ = [("device_ordinal", C.c_int32), ("compute_units", C.c_int32),
                 ("wavefront_size", C.c_int32), ("lds_bytes_per_block", C.c_int32),
@@ -172,6 +176,7 @@ SYMBOLS = {
     "bt709hip_half_thresholds": (_I, [_I, C.POINTER(C.c_float), _I]),
     "bt709hip_half_lookup": (_I, [_I, C.c_float, _I, C.POINTER(C.c_int)]),
     "bt709hip_last_kernel_name": (C.c_char_p, []),
+    "bt709hip_last_launch_info": (_I, [C.POINTER(LaunchInfo)]),
 }
 
 _lib = None

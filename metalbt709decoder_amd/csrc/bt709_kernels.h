@@ -174,6 +174,14 @@ const char *launch_planes(const PlaneParams &p, bool interleave, hipStream_t str
 // 16-byte-per-lane non-temporal streaming copy (bt709_planes.hip): the same-box copy ceiling benchmarks report.
 const char *launch_copy_probe(void *dst, const void *src, size_t bytes, hipStream_t stream);
 
+// Shape of the kernel launches the last bt709hip_decode[_batch] call of this thread made (tests assert the XCD-aware map
+// through it: bt709hip_last_launch_info): grid and block of its FIRST launch, how many launches it took.
+struct LaunchShape {
+  uint32_t grid[3], block[3];
+  int32_t launches, xcd_bands;
+};
+LaunchShape &last_launch_shape();  // thread-local (bt709_kernels.hip)
+
 // Launchers return the kernel's name (static string) for profiling; launch errors
 // are read by the caller with hipGetLastError().
 // decode: variant kVariantQuads -> grid = (grid_x tiles, H/2, frames) x block_threads;

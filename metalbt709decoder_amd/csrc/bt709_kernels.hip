@@ -318,6 +318,11 @@ const char *launch_unconvert(const DecodeParams &t, const void *in, size_t in_st
 // ---------------------------------------------------------------------------
 // host-callable launchers (no HIP types in the signature beyond hipStream_t)
 // ---------------------------------------------------------------------------
+LaunchShape &last_launch_shape() {
+  static thread_local LaunchShape shape = {};
+  return shape;
+}
+
 const char *launch_decode(const DecodeParams &p_in, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
                           int xcd_bands, uint32_t grid_x, uint32_t block_threads, hipStream_t stream) {
   const bool quant = quantiser || has_alpha;  // the sRGB mode: arithmetic, no table
@@ -347,6 +352,12 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
       grid = dim3(grid_x * 8u, grid.y, banded.frames_per_band);
     }
     const DecodeParams &p = banded;
+    LaunchShape &shape = last_launch_shape();
+    if (shape.launches++ == 0) {
+      shape.grid[0] = grid.x, shape.grid[1] = grid.y, shape.grid[2] = grid.z;
+      shape.block[0] = block.x, shape.block[1] = block.y, shape.block[2] = block.z;
+      shape.xcd_bands = static_cast<int32_t>(banded.xcd_bands);
+    }
     if (has_alpha) {
       hipLaunchKernelGGL((decode_nv12_quads<true, true, true>), grid, block, lds, stream, p);
       return "decode_nv12_quads<alpha>";
@@ -367,6 +378,12 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
   const DecodeParams &p = p_in;
   const dim3 grid(grid_x, static_cast<uint32_t>(frames), 1);
   const dim3 block(kBlockThreads, 1, 1);
+  LaunchShape &shape = last_launch_shape();
+  if (shape.launches++ == 0) {
+    shape.grid[0] = grid.x, shape.grid[1] = grid.y, shape.grid[2] = grid.z;
+    shape.block[0] = block.x, shape.block[1] = block.y, shape.block[2] = block.z;
+    shape.xcd_bands = 0;
+  }
   if (has_alpha) {
     hipLaunchKernelGGL((decode_nv12_blocks<true, true>), grid, block, lds, stream, p);
     return "decode_nv12_blocks<alpha>";

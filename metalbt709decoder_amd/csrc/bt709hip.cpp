@@ -938,6 +938,7 @@ int decode_batch_now(bt709hip_decoder *dec, int count, const bt709hip_frame *fra
   const bool fast = (p.width % 4) == 0 && info.in_align >= 4 && info.out_align >= 16;
   const uint32_t gx = fast ? quads_tiles(p.width) : grid_x_for(dec->ctx, p.height / 2, count);
   const uint32_t threads = quads_block_threads(p.width);
+  last_launch_shape() = LaunchShape{};
   tl_kernel_name = launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
                                  dec->gamma == kGammaSRGB, dec->nontemporal, dec->xcd_bands, gx, threads, s);
   return finish_launch(s, wait_until_completed);
@@ -1748,6 +1749,15 @@ const char *bt709hip_strerror(int status) {
 int bt709hip_last_hip_error(void) { return static_cast<int>(tl_hip_error); }
 const char *bt709hip_last_hip_error_string(void) { return hipGetErrorString(tl_hip_error); }
 const char *bt709hip_last_kernel_name(void) { return tl_kernel_name; }
+
+int bt709hip_last_launch_info(bt709hip_launch_info *info) {
+  if (info == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  const LaunchShape &s = last_launch_shape();
+  for (int i = 0; i < 3; ++i) info->grid[i] = s.grid[i], info->block[i] = s.block[i];
+  info->launches = s.launches;
+  info->xcd_bands = s.xcd_bands;
+  return BT709HIP_OK;
+}
 
 int bt709hip_gamma_thresholds(int gamma, float thresholds[255]) {
   if (thresholds == nullptr) return BT709HIP_ERR_INVALID_ARG;

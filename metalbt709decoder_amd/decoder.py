@@ -49,13 +49,21 @@ def _align_up(v, a):
     return (v + a - 1) // a * a
 
 
+STREAMING_SLAB_BYTES = 256 << 20  # the Infinity Cache: a slab this large streams from HBM, where placement matters
+
+
 class DeviceBuffer:
     """hipMalloc'd bytes owned through the context."""
 
-    def __init__(self, ctx, nbytes, placement_tries=1):
+    def __init__(self, ctx, nbytes, placement_tries=None):
         """placement_tries > 1: bt709hip_malloc_streaming -- that many candidates, the fastest-streaming one kept
-        (where a slab lands in HBM changes its streaming rate by a few percent on MI355X)."""
+        (where a slab lands in HBM changes its streaming rate by up to 10 % on MI355X).  Default (None): 4 for slabs of
+        256 MB or more -- the sizes that stream from HBM; a ring of frames is one such slab -- and 1 (plain bt709hip_malloc)
+        below that; pass 1 to turn the probing off.  A whole frame ring is better made with FrameRing (bt709hip_ring_create
+        probes with the decoder's own launch and chooses the input x output pairing)."""
         self.ctx, self.nbytes = ctx, int(nbytes)
+        if placement_tries is None:
+            placement_tries = 4 if self.nbytes >= STREAMING_SLAB_BYTES else 1
         p = C.c_void_p()
         self.placement = None
         if placement_tries > 1:
@@ -155,6 +163,76 @@ class InFlightFramePool:
         if self.handle:
             self.lib.bt709hip_pool_destroy(self.handle)
             self.handle = None
+
+
+class FrameRing:
+    """`frames` same-sized frames resident in device memory, inputs carved from one slab and outputs from another, placed by
+    bt709hip_ring_create's hunt (include/bt709hip.h "frame ring"): what a streaming application keeps in HBM.  The
+    reference's twin is its per-in-flight-frame CVPixelBuffers + render texture (AAPLRenderer.m:34, 530-862); unified
+    memory has no placement to choose."""
+
+    def __init__(self, decoder, size, frames, halfScale=False, tries=0):
+        self.decoder, (self.width, self.height), self.frames = decoder, size, int(frames)
+        self.ctx = decoder.metalRenderContext
+        self.lib = self.ctx.lib
+        if not decoder.setupMetal():
+            raise RuntimeError("decoder setup failed: %s" % decoder.lastStatus)
+        h = C.c_void_p()
+        _capi.check(self.lib.bt709hip_ring_create(decoder._handle, self.width, self.height, self.frames, int(bool(halfScale)),
+                                                  int(tries), C.byref(h)), "ring create")
+        self.handle = h
+        self.halfScale = bool(halfScale)
+
+    def pixelBuffer(self, i):
+        """CVPixelBuffer view of input frame i (tagged for the decoder's gamma)."""
+        f = Frame()
+        _capi.check(self.lib.bt709hip_ring_frame(self.handle, i, C.byref(f), None, None), "ring frame")
+        b = CVPixelBuffer(self.ctx, f.width, f.height, f.y_stride, f.cbcr_stride, planes=(f.y, f.cbcr))
+        b.setAttachment("YCbCrMatrix", f.matrix)
+        b.setAttachment("TransferFunction", f.transfer)
+        return b
+
+    def alphaPixelBuffer(self, i):
+        a = Frame()
+        _capi.check(self.lib.bt709hip_ring_frame(self.handle, i, None, C.byref(a), None), "ring frame")
+        if not a.y:
+            return None
+        b = CVPixelBuffer(self.ctx, a.width, a.height, a.y_stride, a.y_stride, planes=(a.y, a.y))
+        b.setAttachment("YCbCrMatrix", a.matrix)
+        b.setAttachment("TransferFunction", a.transfer)
+        return b
+
+    def texture(self, i):
+        """BGRATexture view of output frame i."""
+        o = Surface()
+        _capi.check(self.lib.bt709hip_ring_frame(self.handle, i, None, None, C.byref(o)), "ring frame")
+        return BGRATexture(self.ctx, o.width, o.height, o.stride, ptr=o.bgra)
+
+    def placement(self):
+        p = _capi.RingPlacement()
+        _capi.check(self.lib.bt709hip_ring_placement_info(self.handle, C.byref(p)), "ring placement")
+        return p
+
+    def decode(self, first=0, count=None, commandBuffer=None, waitUntilCompleted=False):
+        """Frames [first, first + count) in one launch."""
+        count = self.frames - first if count is None else count
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = self.lib.bt709hip_ring_decode(self.handle, int(first), int(count), stream, int(bool(waitUntilCompleted)))
+        if rc != _capi.OK:
+            self.decoder.lastStatus = rc
+            return False
+        return True
+
+    def release(self):
+        if self.handle:
+            self.lib.bt709hip_ring_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class FrameSharder:
@@ -577,6 +655,18 @@ class MetalBT709Decoder:
         if self._handle:
             _capi.check(self.metalRenderContext.lib.bt709hip_decoder_set_option(self._handle, int(option), int(value)),
                         "decoder set option")
+
+    def flush(self, commandBuffer=None, allStreams=False):
+        """Coalescing submit (setOption(_capi.OPT_COALESCE, n)): issue the frames queued for the command buffer's stream (or
+        for every stream).  A no-op without the option."""
+        lib = self.metalRenderContext.lib
+        if allStreams:
+            rc = lib.bt709hip_decoder_flush_all(self._handle)
+        else:
+            rc = lib.bt709hip_decoder_flush(self._handle, commandBuffer.stream if commandBuffer is not None else None)
+        if rc != _capi.OK:
+            return self._fail(rc, "flush")
+        return True
 
     def _fail(self, rc, what):
         self.lastStatus = rc

@@ -1095,3 +1095,211 @@ def test_cpp_host_mirror_reference_vectors(gh, vectors, tmp_path):
     res = subprocess.run([exe] + args, capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "28 vectors, 0 failures" in res.stdout
+
+
+# ------------------------------------------------------------------ round 4: the launch the headline times, the ring, coalescing
+
+def _tiled_ring(gh, ctx, gamma, n, w, h, tile_w, tile_h, seed, in_gap=0, out_gap=4096):
+    """n frames of w x h at a constant pitch in two slabs (as a ring), frame i = a tiling of its OWN small random tile; a
+    canary gap after every output frame.  Returns (slabs, bufs, texs, tiles, pitches)."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    in_pitch = (w * h * 3 // 2 + in_gap + 255) // 256 * 256
+    out_pitch = (w * h * 4 + out_gap + 255) // 256 * 256
+    slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
+    tiles = [gh.random_nv12(tile_w, tile_h, seed=seed + i) for i in range(n)]
+    bufs, texs = [], []
+    for i, (ty, tc) in enumerate(tiles):
+        base = slab_in.ptr + i * in_pitch
+        b = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h))
+        b.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2)
+        b.setAttachment("TransferFunction", gh.TRANSFER_FOR_GAMMA[gamma])
+        b.upload_planes(np.tile(ty, (h // tile_h, w // tile_w)), np.tile(tc, (h // tile_h, w // tile_w)))
+        bufs.append(b)
+        texs.append(mb.BGRATexture(ctx, w, h, w * 4, ptr=slab_out.ptr + i * out_pitch))
+    return (slab_in, slab_out), bufs, texs, tiles, (in_pitch, out_pitch)
+
+
+def _launch_info(ctx):
+    info = _capi.LaunchInfo()
+    _capi.check(ctx.lib.bt709hip_last_launch_info(C.byref(info)))
+    return info
+
+
+@pytest.mark.parametrize("count", [256, 252])
+def test_config3_256_frame_banded_launch_like_the_bench(gh, oracle, count):
+    """BASELINE config 3 in the EXACT shape bench.py times: 256 evenly spaced 3840x2160 frames in ONE bt709hip_decode_batch
+    (the XCD-aware work map: grid.x = 8 x tiles, grid.z = 32 frames per band, 64-bit frame offsets up to 8.5 GB), every
+    frame a tiling of its own small tile (the tile checked against the oracle), EVERY frame compared, canaries between the
+    output frames untouched.  252 frames: the map over 248 plus the plain map over the last 4 (two launches); the frames
+    beyond the count stay unwritten.  Reference test flow: EmptyiOSTests/MetalBT709DecoderTests.m:189-277."""
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    n, w, h = 256, 3840, 2160
+    (slab_in, slab_out), bufs, texs, tiles, (_, out_pitch) = _tiled_ring(gh, ctx, mb.MetalBT709GammaApple, n, w, h, 256, 8, 30000)
+    _capi.check(ctx.lib.bt709hip_memset(ctx.handle, slab_out.ptr, 0xC3, n * out_pitch, None))
+    assert dec.decodeBT709Batch(bufs[:count], texs[:count], waitUntilCompleted=True), dec.lastStatus
+    assert ctx.lib.bt709hip_last_kernel_name() == b"decode_nv12_quads<nt>"
+    info = _launch_info(ctx)
+    head = count - count % 8
+    assert info.xcd_bands == 1 and info.launches == (1 if count % 8 == 0 else 2)
+    assert list(info.grid) == [8 * 1, h // 2, head // 8] and list(info.block) == [512, 1, 1]  # 3840 wide: one 512-lane tile per row pair
+    frame_bytes = w * h * 4
+    raw = np.empty(out_pitch, np.uint8)
+    for i, (ty, tc) in enumerate(tiles):
+        _capi.check(ctx.lib.bt709hip_download(ctx.handle, raw.ctypes.data, out_pitch, slab_out.ptr + i * out_pitch, out_pitch,
+                                              out_pitch, 1, None))
+        ctx._sync(None)
+        assert (raw[frame_bytes:] == 0xC3).all(), "canary after frame %d" % i
+        got = raw[:frame_bytes].reshape(h, w * 4)
+        if i < count:
+            want = np.tile(oracle.decode_nv12(0, ty, tc), (h // 8, w // 256))
+            assert np.array_equal(got, want), "frame %d" % i
+        else:
+            assert (got == 0xC3).all(), "frame %d beyond the launch was written" % i
+
+
+def test_frame_ring_with_placement_hunt(gh, oracle):
+    """bt709hip_ring_create: 64 x 1080p (0.7 GB: large enough to hunt), two candidates per slab asked for.  The hunt's
+    bookkeeping is consistent, every frame of the ring it kept decodes to the oracle's bytes in one bt709hip_ring_decode
+    launch (XCD-aware map), a sub-range decodes too, and tries = 1 allocates exactly one candidate per slab."""
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    n, w, h = 64, 1920, 1080
+    ring = mb.FrameRing(dec, (w, h), n, tries=2)
+    p = ring.placement()
+    assert p.tries == 2 and 1 <= p.in_candidates <= 2 and 2 <= p.out_candidates <= 6
+    assert 0 <= p.chosen_in < p.in_candidates and 0 <= p.chosen_out < p.out_candidates
+    kept = [k for k in p.out_kept if k >= 0]
+    assert p.chosen_out in kept and len(kept) == min(2, p.out_candidates) and p.probes == p.in_candidates * len(kept)
+    scan = list(p.out_prescan_GBps[:p.out_candidates])
+    assert all(v > 100.0 for v in scan) and p.first_GBps == scan[0]
+    assert p.worst_GBps <= p.best_GBps and p.chosen_GBps > 100.0
+    # the kept outputs are the fastest of the prescan
+    assert sorted(kept) == sorted(sorted(range(len(scan)), key=lambda o: -scan[o])[:len(kept)])
+    tiles = [gh.random_nv12(240, 8, seed=41000 + i) for i in range(n)]
+    for i, (ty, tc) in enumerate(tiles):
+        ring.pixelBuffer(i).upload_planes(np.tile(ty, (h // 8, w // 240)), np.tile(tc, (h // 8, w // 240)))
+    assert ring.decode(waitUntilCompleted=True)
+    info = _launch_info(ctx)
+    assert info.xcd_bands == 1 and info.launches == 1 and list(info.grid) == [8, h // 2 // 2, n // 8]  # 1080p: two row pairs per workgroup
+    for i, (ty, tc) in enumerate(tiles):
+        got = ctx.getBGRATexturePixels(ring.texture(i)).view(np.uint8).reshape(h, w * 4)
+        assert np.array_equal(got, np.tile(oracle.decode_nv12(0, ty, tc), (h // 8, w // 240))), i
+    # a sub-range; argument errors
+    _capi.check(ctx.lib.bt709hip_memset(ctx.handle, ring.texture(0).ptr, 0, n * w * h * 4, None))
+    assert ring.decode(5, 3, waitUntilCompleted=True)
+    for i in (4, 5, 7, 8):
+        got = ctx.getBGRATexturePixels(ring.texture(i)).view(np.uint8).reshape(h, w * 4)
+        ty, tc = tiles[i]
+        assert np.array_equal(got, np.tile(oracle.decode_nv12(0, ty, tc), (h // 8, w // 240))) == (5 <= i < 8)
+    assert not ring.decode(60, 5) and dec.lastStatus == _capi.ERR_INVALID_ARG
+    ring.release()
+    one = mb.FrameRing(dec, (w, h), n, tries=1)
+    q = one.placement()
+    assert (q.tries, q.in_candidates, q.out_candidates, q.probes, q.chosen_in, q.chosen_out) == (1, 1, 1, 0, 0, 0)
+    one.release()
+    # a ring that fits the Infinity Cache never probes; a half-scale ring with an alpha decoder decodes through the 2:1 path
+    adec = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
+    small = mb.FrameRing(adec, (64, 16), 3, halfScale=True, tries=6)
+    assert small.placement().tries == 1
+    fr = [gh.random_nv12(64, 16, seed=900 + i) for i in range(3)]
+    al = [np.random.default_rng(950 + i).integers(0, 256, (16, 64), dtype=np.uint8) for i in range(3)]
+    for i in range(3):
+        small.pixelBuffer(i).upload_planes(*fr[i])
+        ab = small.alphaPixelBuffer(i)
+        ctx._upload(ab.y_ptr, ab.y_stride, al[i], None)
+        ctx._sync(None)
+    assert small.decode(waitUntilCompleted=True)
+    for i in range(3):
+        got = ctx.getBGRATexturePixels(small.texture(i)).view(np.uint8).reshape(8, 32 * 4)
+        assert np.array_equal(got, oracle.decode_nv12_half(1, fr[i][0], fr[i][1], alpha=al[i])), i
+    small.release()
+    # argument errors, no GPU work
+    h_ = C.c_void_p()
+    lib = ctx.lib
+    assert lib.bt709hip_ring_create(dec._handle, 63, 16, 4, 0, 1, C.byref(h_)) == _capi.ERR_ODD_DIMENSIONS
+    assert lib.bt709hip_ring_create(dec._handle, 66, 16, 4, 1, 1, C.byref(h_)) == _capi.ERR_ODD_DIMENSIONS
+    assert lib.bt709hip_ring_create(dec._handle, 64, 16, 0, 0, 1, C.byref(h_)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_ring_create(None, 64, 16, 4, 0, 1, C.byref(h_)) == _capi.ERR_INVALID_ARG
+
+
+def test_coalescing_submit(gh, oracle):
+    """BT709HIP_OPT_COALESCE: one-frame -decodeBT709: calls with waitUntilCompleted = FALSE are validated at once and queued;
+    the queue goes out as ONE batch launch when it is full, when a differing call arrives, and through every stream-taking
+    entry point (a read-back, a synchronize).  Same bytes as the oracle through every route; a failing call reports its own
+    status immediately and disturbs nothing."""
+    ctx = gh.context()
+    lib = ctx.lib
+    dec = gh.make_decoder(mb.MetalBT709GammaApple, options={_capi.OPT_COALESCE: 8})
+    w, h, n = 320, 24, 21
+    frames = [gh.random_nv12(w, h, seed=52000 + i) for i in range(n)]
+    bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]          # separate allocations: the pointer-table batch
+    texs = [ctx.makeBGRATexture((w, h)) for _ in range(n)]
+    cb = ctx.commandQueue.commandBuffer()
+    for t in texs:
+        _capi.check(lib.bt709hip_memset(ctx.handle, t.ptr, 0x5A, w * h * 4, None))
+    ctx._sync(None)
+    queued_names = []
+    for i in range(n):
+        assert dec.decodeBT709(bufs[i], None, texs[i], cb, None, w, h, False), dec.lastStatus
+        queued_names.append(lib.bt709hip_last_kernel_name())
+    # 21 calls, 8 per launch: calls 8 and 16 issued a launch, the last five are still queued
+    assert [i for i, nm in enumerate(queued_names) if nm != b"(queued: coalescing submit)"] == [7, 15]
+    info = _launch_info(ctx)
+    assert info.launches == 1 and info.grid[2] == 8
+    # a call that fails validation: its own status, now; the queue is untouched
+    bad = gh.make_buffer(*frames[0], dec.gamma, tag=False)
+    assert not dec.decodeBT709(bad, None, texs[0], cb, None, w, h, False) and dec.lastStatus == _capi.ERR_MATRIX
+    assert not dec.decodeBT709(bufs[0], None, texs[0], cb, None, w + 2, h, False) and dec.lastStatus == _capi.ERR_SIZE_MISMATCH
+    # read-back of a queued frame's texture: the download flushes the queue first (stream order kept)
+    got = ctx.getBGRATexturePixels(texs[n - 1]).view(np.uint8).reshape(h, w * 4)
+    assert np.array_equal(got, oracle.decode_nv12(0, *frames[n - 1]))
+    assert _launch_info(ctx).grid[2] == 5
+    for i in range(n):
+        got = ctx.getBGRATexturePixels(texs[i]).view(np.uint8).reshape(h, w * 4)
+        assert np.array_equal(got, oracle.decode_nv12(0, *frames[i])), i
+    # a frame of another size flushes what is queued and starts a new queue; explicit flush; waitUntilCompleted = TRUE
+    y2, c2 = gh.random_nv12(128, 16, seed=53000)
+    b2, t2 = gh.make_buffer(y2, c2, dec.gamma), ctx.makeBGRATexture((128, 16))
+    for i in range(3):
+        assert dec.decodeBT709(bufs[i], None, texs[i], cb, None, w, h, False)
+    assert dec.decodeBT709(b2, None, t2, cb, None, 128, 16, False)
+    assert _launch_info(ctx).grid[2] == 3                       # the three queued frames went out
+    assert dec.flush(cb) and _launch_info(ctx).grid[2] == 1     # then the odd one
+    assert dec.decodeBT709(bufs[3], None, texs[3], cb, None, w, h, False)
+    assert dec.decodeBT709(bufs[4], None, texs[4], cb, None, w, h, True)  # waits: queue first, then this frame
+    assert lib.bt709hip_last_kernel_name().startswith(b"decode_nv12_quads")
+    assert np.array_equal(ctx.getBGRATexturePixels(t2).view(np.uint8).reshape(16, 128 * 4), oracle.decode_nv12(0, y2, c2))
+    # evenly spaced frames (a ring) gather into the uniform batch form; a second stream has a queue of its own
+    ring = mb.FrameRing(dec, (w, h), 12, tries=1)
+    for i in range(12):
+        ring.pixelBuffer(i).upload_planes(*frames[i])
+    cb2 = ctx.commandQueue.commandBuffer(new_stream=True)
+    for i in range(12):
+        assert dec.decodeBT709(ring.pixelBuffer(i), None, ring.texture(i), cb if i % 2 == 0 else cb2, None, w, h, False)
+    cb.waitUntilCompleted()
+    cb2.waitUntilCompleted()
+    for i in range(12):
+        got = ctx.getBGRATexturePixels(ring.texture(i)).view(np.uint8).reshape(h, w * 4)
+        assert np.array_equal(got, oracle.decode_nv12(0, *frames[i])), i
+    # turning the option off issues what is queued; afterwards calls launch at once
+    assert dec.decodeBT709(bufs[5], None, texs[5], cb, None, w, h, False)
+    dec.setOption(_capi.OPT_COALESCE, 0)
+    assert _launch_info(ctx).grid[2] == 1
+    assert dec.decodeBT709(bufs[6], None, texs[6], cb, None, w, h, False)
+    assert lib.bt709hip_last_kernel_name().startswith(b"decode_nv12_quads")
+    cb.waitUntilCompleted()
+    cb2.release()
+    ring.release()
+    # the in-flight pool (raw stream copies behind the decode) stays correct with the option on
+    pdec = gh.make_decoder(mb.MetalBT709GammaApple, options={_capi.OPT_COALESCE: 4})
+    pool = mb.InFlightFramePool(pdec, (w, h), 3)
+    slots = []
+    for i in range(3):
+        slot, yv, cv = pool.acquire()
+        yv[:], cv[:] = frames[i]
+        pool.submit(slot)
+        slots.append(slot)
+    for i, slot in enumerate(slots):
+        assert np.array_equal(pool.wait(slot), oracle.decode_nv12(0, *frames[i]))
+    pool.release()

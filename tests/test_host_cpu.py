@@ -555,31 +555,16 @@ def test_bench_geometry():
     assert bench.geometry("4k", 16, 65535)["ring_input_over_cache"] < 1.0  # 16 x 12.4 MB: refused by main()
 
 
-def test_bench_placement_hunt_search():
-    """bench.hunt_pairing on the measured 5 x 5 pairing matrix (profiles/r03_placement_cross.txt): every pairing probed once
-    while that is cheap -> the best pairing; the descent used beyond that stays within its probe budget and is not worse
-    than the best as-allocated pair; no candidates -> (0, 0)."""
+def test_bench_spot_check_samples_every_xcd_band():
+    """bench.py's parity tripwire reads one ring frame out of each eighth of the ring (= each XCD band of a whole-ring launch),
+    first and last frame included (round 3 read ring frame 0 only)."""
     import bench
-    m = [[0.8073, 0.7824, 0.7967, 0.8186, 0.7750],
-         [0.8251, 0.7520, 0.8159, 0.8156, 0.7432],
-         [0.8102, 0.7610, 0.8005, 0.8187, 0.7397],
-         [0.8216, 0.7590, 0.8214, 0.8012, 0.7471],
-         [0.8226, 0.7524, 0.8147, 0.8132, 0.7458]]
-    calls, memo = [], {}
-
-    def probe(i, o):  # GpuRunner.place_ring memoises the same way
-        if (i, o) not in memo:
-            calls.append((i, o))
-            memo[(i, o)] = m[i][o]
-        return memo[(i, o)]
-    assert bench.hunt_pairing(5, 5, probe) == (1, 0) and m[1][0] == max(max(r) for r in m)
-    assert len(calls) == len(set(calls)) == 25
-    calls.clear(), memo.clear()
-    bi, bo = bench.hunt_pairing(5, 5, probe, exhaustive_up_to=0)
-    assert len(calls) == len(set(calls)) <= 2 * 5 + 5 - 2
-    assert m[bi][bo] >= max(m[k][k] for k in range(5))
-    assert bench.hunt_pairing(1, 1, probe) == (0, 0)
-    assert bench.hunt_pairing(1, 5, probe) == (0, 3)
+    assert bench.sample_frames(256) == [0, 37, 70, 103, 136, 169, 202, 255]
+    for ring in (8, 16, 64, 256, 1024):
+        picks = bench.sample_frames(ring)
+        assert len(picks) == 8 and picks[0] == 0 and picks[-1] == ring - 1
+        assert sorted({p * 8 // ring for p in picks}) == list(range(8))
+    assert bench.sample_frames(4) == [0, 1, 2, 3]
 
 
 def build_cpp_selftest(tmpdir):

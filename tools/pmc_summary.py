@@ -24,6 +24,48 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def timed_dispatches(kernel_trace_csv, kernel_filter):
+    """Durations (ns) of the `kernel_filter` dispatches between an opening and a closing sentinel of bench.py, by kernel
+    name; None when the trace holds no sentinel pair.  Sentinels: kernel copy_probe with 512 (opening) or 1024 (closing)
+    work-items in the launch."""
+    rows = list(csv.DictReader(open(kernel_trace_csv)))
+    if not rows or "Grid_Size" not in rows[0] and "Grid_Size_X" not in rows[0]:
+        return None
+
+    def grid(r):
+        if "Grid_Size" in r:
+            return int(r["Grid_Size"])
+        return int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    by_kernel, regions, inside, in_region = collections.defaultdict(list), 0, False, 0
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "copy_probe" in name and grid(r) in (512, 1024):
+            if grid(r) == 512:
+                inside, in_region = True, 0
+            elif inside:
+                inside = False
+                regions += 1 if in_region else 0
+            continue
+        if inside and kernel_filter in name:
+            by_kernel[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            in_region += 1
+    return {"regions": regions, "by_kernel": dict(by_kernel)} if regions else None
+
+
+def write_timed_stats(path, timed):
+    total = sum(sum(v) for v in timed["by_kernel"].values())
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev", "MedianNs", "Scope"])
+        for name, v in sorted(timed["by_kernel"].items(), key=lambda kv: -sum(kv[1])):
+            mean = sum(v) / len(v)
+            sd = (sum((x - mean) ** 2 for x in v) / len(v)) ** 0.5
+            w.writerow([name, len(v), sum(v), "%.3f" % mean, "%.2f" % (100.0 * sum(v) / total), min(v), max(v), "%.3f" % sd,
+                        sorted(v)[len(v) // 2],
+                        "dispatches inside bench.py's %d sentinel-bracketed timed regions only" % timed["regions"]])
+
+
 def main():
     src, rnd, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     kernel_filter = sys.argv[4] if len(sys.argv) > 4 else "decode_nv12"
@@ -31,13 +73,25 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
 
     stats = os.path.join(src, "trace", "trace_kernel_stats.csv")
-    if os.path.exists(stats):
+    kt = os.path.join(src, "trace", "trace_kernel_trace.csv")
+    timed = timed_dispatches(kt, kernel_filter) if os.path.exists(kt) else None
+    if timed:
+        # bench.py brackets every region that counts towards `value` with two sentinel dispatches (copy_probe, 512 lanes
+        # opening / 1024 closing, outside both clocks).  <round>_<tag>_kernel_stats.csv = the rocprofv3 stats columns computed
+        # over the dispatches BETWEEN sentinels only (the set-up's placement probes, warm-up, spot check and side legs run the
+        # same kernel and would otherwise be averaged in: round 3's mean was 2 % above ms_per_step for that reason);
+        # rocprofv3's own all-dispatch summary is kept beside it as ..._kernel_stats_all.csv.
+        if os.path.exists(stats):
+            shutil.copy(stats, os.path.join(out_dir, "%s_%s_kernel_stats_all.csv" % (rnd, tag)))
+        write_timed_stats(os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (rnd, tag)), timed)
+    elif os.path.exists(stats):
         shutil.copy(stats, os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (rnd, tag)))
 
     # durations from the kernel trace of the --stats run
     durs = []
-    kt = os.path.join(src, "trace", "trace_kernel_trace.csv")
-    if os.path.exists(kt):
+    if timed:
+        durs = [d for v in timed["by_kernel"].values() for d in v]
+    elif os.path.exists(kt):
         for r in csv.DictReader(open(kt)):
             if kernel_filter in r["Kernel_Name"]:
                 durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
