@@ -75,9 +75,10 @@ def parse_args(argv=None):
     ap.add_argument("--gamma", default="apple", choices=sorted(GAMMAS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
-    ap.add_argument("--content", default="random", choices=["random", "smooth"],
+    ap.add_argument("--content", default="random", choices=["random", "smooth", "flat"],
                     help="random: uniform bytes (headline; worst case for the LDS table). smooth: video-like "
-                         "low-frequency planes + small noise (neighbouring pixels share table buckets)")
+                         "low-frequency planes + small noise (neighbouring pixels share table buckets). flat: one grey "
+                         "value (every lane reads the same bucket: the LDS gathers at their conflict-free floor; lab)")
     ap.add_argument("--repeats", type=int, default=0, help="timed K-step regions; 0 = auto (>= 5, >= 150 ms in total, <= 40)")
     ap.add_argument("--share", type=int, default=0,
                     help="4k-batch8 only: frames per step of THIS rank (default 8 / world size); lets one GPU "
@@ -287,6 +288,8 @@ class GpuRunner:
             rng = np.random.default_rng(0x709 + i + 1000 * self.rank)
             if content == "random":  # full byte range: exercises saturation
                 buf = rng.integers(0, 256, (1, g["y_bytes"] + g["c_bytes"]), dtype=np.uint8)
+            elif content == "flat":
+                buf = np.full((1, g["y_bytes"] + g["c_bytes"]), 128, np.uint8)
             else:
                 if base_smooth is None:
                     base_smooth = smooth_frame(np, rng, g, 0)
@@ -676,7 +679,7 @@ def main(argv=None):
             "workload": "%dx%d NV12 BT.709 -> %dx%d BGRA8 sRGB, gamma=%s%s; per GPU a ring of %d distinct frames "
                         "(%s, seed 0x709+i) resident in HBM; %s"
                         % (g["W"], g["H"], g["OW"], g["OH"], args.gamma, ", fused 2:1 rescale" if g["half"] else "",
-                           g["ring"], "uniform random bytes" if args.content == "random" else "smooth video-like planes",
+                           g["ring"], {"random": "uniform random bytes", "smooth": "smooth video-like planes", "flat": "flat grey"}[args.content],
                            step_text),
             "frames_per_step_per_gpu": g["frames_per_step"],
             "streams": getattr(runner, "nstreams", 1),
@@ -711,7 +714,7 @@ def main(argv=None):
         result["parity_spot_frames"] = getattr(runner, "spot_frames", [])  # one ring frame per XCD band, 48 rows each
         if world == 1:
             result["roofline"].update(first_allocation_leg(runner, args, g, barrier, region_steps, achieved))
-            if args.workload == "4k" and args.content == "random" and not args.no_smooth_leg:
+            if args.workload in ("4k", "8k-half") and args.content == "random" and not args.no_smooth_leg:
                 result["roofline"]["smooth_content"] = smooth_leg(runner, args, g, barrier, region_steps)
             copy_gbps = runner.copy_ceiling()
             result["roofline"]["same_run_copy_GBps"] = round(copy_gbps, 1)

@@ -207,6 +207,93 @@ __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, f
                    encode_byte(r, __fmul_rn(sb, r.quarter_scale)), alpha_word);
 }
 
+// The two output pixels of a quad through the uniform encode table, SOFTWARE-PIPELINED over the LDS (round 4).  half_px
+// issues a batch of six bucket reads and waits for it at once (s_waitcnt lgkmcnt(0) right behind the ds_read_b128s): for the
+// whole LDS latency the wave has nothing to issue, and with 4 waves per SIMD (one 1024-lane workgroup per CU: the tables fill
+// the LDS) the other three do not always cover it -- measured: 371 us per 16-frame launch when the gathers are conflict-free
+// (flat content) = the VALU issue time, 413 us on uniform random bytes.  Here the four decode-side batches (a, b: pixel 0;
+// c, d: pixel 1) and the two encode-side triples rotate: a batch is consumed while the next two are in flight, so every
+// s_waitcnt leaves 6 to 12 reads outstanding (the LGKM counter holds 15).  Same arithmetic, same order of float operations
+// per value as half_px: the bytes cannot differ (tests compare both kernels with the oracle).
+#ifndef BT709_HALF_PIPELINE
+#define BT709_HALF_PIPELINE 1  // 0: the unpipelined form (half_px twice), for A/B runs
+#endif
+struct Batch6 {
+  u32x4 e[6];
+};
+__device__ __forceinline__ void batch_load(const RescaleLookup &r, const uint32_t *t, Batch6 &b) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) b.e[i] = *reinterpret_cast<LdsQuadPtr>((t[i] << r.dec_shift) + r.dec_off);
+}
+__device__ __forceinline__ void batch_use(const float *x, Batch6 &b, float *lin) {
+  asm volatile("" : "+v"(b.e[0]), "+v"(b.e[1]), "+v"(b.e[2]), "+v"(b.e[3]), "+v"(b.e[4]), "+v"(b.e[5]));  // one wait per batch
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    lin[i] = __builtin_amdgcn_fmed3f(__uint_as_float(b.e[i].y), __uint_as_float(b.e[i].z), __fadd_rn(x[i], -__uint_as_float(b.e[i].x)));
+}
+struct Encode3 {
+  u32x2 e[3];
+  float s[3];
+};
+__device__ __forceinline__ void encode_load(const RescaleLookup &r, const float *lin, Encode3 &q) {
+  const float *lr = lin, *lg = lin + 4, *lb = lin + 8;
+  q.s[0] = __fadd_rn(__fadd_rn(__fadd_rn(lr[0], lr[1]), lr[2]), lr[3]);
+  q.s[1] = __fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]);
+  q.s[2] = __fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t t = __float_as_uint(__builtin_fmaf(q.s[k], r.sum_to_xs, 8388608.0f));  // as encode_byte_uniform
+    q.e[k] = *reinterpret_cast<LdsPairPtr>((t << r.enc_shift) + r.enc_u_off);
+  }
+}
+__device__ __forceinline__ uint32_t encode_use(Encode3 &q, uint32_t alpha_word) {
+  asm volatile("" : "+v"(q.e[0]), "+v"(q.e[1]), "+v"(q.e[2]));
+  uint32_t b[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b[k] = q.e[k].y + (q.s[k] >= __uint_as_float(q.e[k].x) ? 1u : 0u);
+  return pack_bgra(b[0], b[1], b[2], alpha_word);
+}
+
+__device__ __forceinline__ u32x2 half_quad_pipelined(const RescaleLookup &r, uint32_t ya, uint32_t yb, uint32_t cw, uint32_t aw0,
+                                                     uint32_t aw1) {
+  const Chroma c0 = chroma_terms(byte_of(cw, 0), byte_of(cw, 1));
+  const Chroma c1 = chroma_terms(byte_of(cw, 2), byte_of(cw, 3));
+  float x0[12], x1[12];  // r0..r3, g0..g3, b0..b3 of each output pixel's 2x2 block
+  pixel_rgb(byte_of(ya, 0), c0, x0[0], x0[4], x0[8]);
+  pixel_rgb(byte_of(ya, 1), c0, x0[1], x0[5], x0[9]);
+  pixel_rgb(byte_of(yb, 0), c0, x0[2], x0[6], x0[10]);
+  pixel_rgb(byte_of(yb, 1), c0, x0[3], x0[7], x0[11]);
+  uint32_t t0[12], t1[12];
+  magic_index12(x0, t0, r.magic);
+  Batch6 a, b, c, d;
+  batch_load(r, t0, a);
+  batch_load(r, t0 + 6, b);
+  __builtin_amdgcn_sched_barrier(0);
+  pixel_rgb(byte_of(ya, 2), c1, x1[0], x1[4], x1[8]);
+  pixel_rgb(byte_of(ya, 3), c1, x1[1], x1[5], x1[9]);
+  pixel_rgb(byte_of(yb, 2), c1, x1[2], x1[6], x1[10]);
+  pixel_rgb(byte_of(yb, 3), c1, x1[3], x1[7], x1[11]);
+  magic_index12(x1, t1, r.magic);
+  float lin0[12], lin1[12];
+  batch_use(x0, a, lin0);          // waits for a: b stays in flight
+  batch_load(r, t1, c);
+  __builtin_amdgcn_sched_barrier(0);
+  batch_use(x0 + 6, b, lin0 + 6);  // c in flight
+  batch_load(r, t1 + 6, d);
+  Encode3 e0, e1;
+  encode_load(r, lin0, e0);
+  __builtin_amdgcn_sched_barrier(0);
+  batch_use(x1, c, lin1);          // d, e0 in flight
+  __builtin_amdgcn_sched_barrier(0);
+  batch_use(x1 + 6, d, lin1 + 6);  // e0 in flight
+  encode_load(r, lin1, e1);
+  __builtin_amdgcn_sched_barrier(0);
+  u32x2 v;
+  v.x = encode_use(e0, aw0);       // e1 in flight
+  v.y = encode_use(e1, aw1);
+  return v;
+}
+
 // the two output pixels of a quad (4x2 source pixels); aw0 / aw1 = their alpha words
 template <bool UNIFORM_ENCODE = false>
 __device__ __forceinline__ u32x2 half_quad(const RescaleLookup &r, uint32_t ya, uint32_t yb, uint32_t cw,
@@ -365,7 +452,7 @@ __device__ __forceinline__ QuadIn load_quad(const DecodeParams &p, const TileCur
 }  // namespace
 
 template <bool NT, int U, bool HAS_ALPHA>
-__global__ void __launch_bounds__(kRepBlockThreads)
+__global__ void __launch_bounds__(kRepBlockThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))  // one 16-wave workgroup per CU: 128 VGPRs are free
 decode_nv12_half_rep(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t row_pairs = p.height >> 1, quads = p.width >> 2;
@@ -422,7 +509,8 @@ decode_nv12_half_rep(const DecodeParams p) {
         aw0 = half_alpha_arith(byte_of(in[u].aa, 0), byte_of(in[u].aa, 1), byte_of(in[u].ab, 0), byte_of(in[u].ab, 1));
         aw1 = half_alpha_arith(byte_of(in[u].aa, 2), byte_of(in[u].aa, 3), byte_of(in[u].ab, 2), byte_of(in[u].ab, 3));
       }
-      const u32x2 v = half_quad<kRepUniformEncode>(r, in[u].ya, in[u].yb, in[u].cw, aw0, aw1);
+      const u32x2 v = BT709_HALF_PIPELINE ? half_quad_pipelined(r, in[u].ya, in[u].yb, in[u].cw, aw0, aw1)
+                                          : half_quad<kRepUniformEncode>(r, in[u].ya, in[u].yb, in[u].cw, aw0, aw1);
       const FramePlanes f = frame_planes(p, c.f);
       uint8_t *o = f.out + static_cast<size_t>(c.rp) * p.out_stride;
       // lanes past the row's end loaded the last quad (clamp), hold its result and store it again

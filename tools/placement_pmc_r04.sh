@@ -9,14 +9,20 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 N=${N:-8}; K=${K:-4}
 i=0
-for P in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum" \
-         "TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_SERIALIZATION_STALL_sum" \
-         "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE GRBM_TA_BUSY" \
-         "BT709_WRREQ_MAX BT709_WRREQ_MIN TCC_EA0_WRREQ_sum" \
-         "BT709_WRSTALL_MAX BT709_WRSTALL_MIN TCC_EA0_WRREQ_STALL_sum" \
-         "TCC_BUBBLE_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_TAG_STALL_sum TCC_EA0_WRREQ_64B_sum" \
-         "BT709_RDREQ_MAX BT709_RDREQ_MIN BT709_TCCBUSY_MAX BT709_TCCBUSY_MIN"; do
-  rocprofv3 --kernel-trace --pmc $P -E "$REPO/tools/placement_extra_counters.yaml" --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$REPO/tools/placement_pmc.py" $N $K > "$OUT/p$i.log" 2>&1
+# PASSES=tcc (default): the memory-side sets (fast: a few TCC / GRBM instances); PASSES=tcp: the translation sets, which take
+# ~7 minutes each under rocprofv3 (per-CU counters) -- they ran once (profiles/r04_placement_pmc.txt, passes T0 / T1)
+if [ "${PASSES:-tcc}" = tcp ]; then
+SETS=("TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum"
+      "TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_SERIALIZATION_STALL_sum")
+else
+SETS=("BT709_WRREQ_MAX BT709_WRREQ_MIN TCC_EA0_WRREQ_sum"
+      "BT709_WRSTALL_MAX BT709_WRSTALL_MIN TCC_EA0_WRREQ_STALL_sum"
+      "TCC_BUBBLE_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_TAG_STALL_sum TCC_EA0_WRREQ_64B_sum"
+      "BT709_RDREQ_MAX BT709_RDREQ_MIN BT709_TCCBUSY_MAX BT709_TCCBUSY_MIN"
+      "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE GRBM_TA_BUSY")
+fi
+for P in "${SETS[@]}"; do
+  timeout ${PASS_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc $P -E "$REPO/tools/placement_extra_counters.yaml" --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$REPO/tools/placement_pmc.py" $N $K > "$OUT/p$i.log" 2>&1
   echo "== pass $i: $P"
   grep "^SLAB" "$OUT/p$i.log" || tail -5 "$OUT/p$i.log"
   python3 - "$OUT/p$i" $K <<'PY'
