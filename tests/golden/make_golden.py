@@ -269,6 +269,7 @@ FULL_IMAGES = [
     ("qt_hd_srgb_full", "Renderer/QuickTime_Test_Pattern_HD_sRGB.png"),                # 1920 x 1080: BASELINE config 1's frame
     ("qt_hd_calibrated_full", "Renderer/QuickTime_Test_Pattern_HD_calibrated_RGB.png"),  # 1920 x 1080
     ("image_tga_full", "Renderer/Image.tga"),                                           # 512 x 512
+    ("clouds_full", "Renderer/clouds_reflecting_off_the_beach-wallpaper-2048x1536.jpg"),  # 2048 x 1536 photograph (round 4)
 ]
 
 

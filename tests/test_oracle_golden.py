@@ -162,11 +162,12 @@ def test_bundled_pattern_crops(oracle, refdata, patterns):
 
 def test_whole_bundled_patterns(oracle, full_patterns):
     """north_star: "bit-exact on the bundled test patterns" -- the WHOLE 1920x1080 QuickTime test pattern (both
-    renditions; BASELINE config 1's frame on the CPU path) and the 512x512 Image.tga, encoded to NV12 and decoded
+    renditions; BASELINE config 1's frame on the CPU path), the 512x512 Image.tga and (round 4) the whole 2048x1536
+    clouds photograph -- every image SURVEY 8(c) lists, none cropped -- encoded to NV12 and decoded
     by the reference headers in every gamma, and through decode + exact 2:1 pass 2: the oracle reproduces every
     byte (hashes: tests/golden/patterns_full.json)."""
     images, planes = full_patterns
-    assert {tuple(r["image_size"]) for r in images} == {(1920, 1080), (512, 512)} and len(images) == 3
+    assert {tuple(r["image_size"]) for r in images} == {(1920, 1080), (512, 512), (2048, 1536)} and len(images) == 4
     for rec in images:
         y, uv = planes[rec["tag"] + "_y"], planes[rec["tag"] + "_uv"]
         assert y.shape == (rec["image_size"][1], rec["image_size"][0])
