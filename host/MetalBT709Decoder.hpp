@@ -486,6 +486,80 @@ class InFlightFramePool {
   int lastStatus_ = BT709HIP_OK;
 };
 
+// Frames resident in DEVICE memory: a ring of same-sized NV12 inputs and BGRA outputs carved from two slabs and placed by
+// bt709hip_ring_create's hunt (include/bt709hip.h "frame ring"; round 4).  The reference's twin is its per-in-flight-frame
+// CVPixelBuffers + render texture (Renderer/AAPLRenderer.m:34, 530-862).
+class FrameRing {
+ public:
+  FrameRing(MetalBT709Decoder &decoder, int width, int height, int frames, bool halfScale = false, int tries = 0)
+      : decoder_(decoder) {
+    if (decoder.setupMetal()) lastStatus_ = bt709hip_ring_create(decoder.handle(), width, height, frames, halfScale ? 1 : 0, tries, &ring_);
+    else lastStatus_ = decoder.lastStatus();
+  }
+  ~FrameRing() { bt709hip_ring_destroy(ring_); }
+  FrameRing(const FrameRing &) = delete;
+  FrameRing &operator=(const FrameRing &) = delete;
+  bool valid() const { return ring_ != nullptr; }
+  int lastStatus() const { return lastStatus_; }
+  int frames() const { return bt709hip_ring_frames(ring_); }
+  bt709hip_ring_placement placement() const {
+    bt709hip_ring_placement p{};
+    bt709hip_ring_placement_info(ring_, &p);
+    return p;
+  }
+  // tight host planes -> frame i (blocking)
+  bool upload(int i, const uint8_t *y, const uint8_t *cbcr) {
+    bt709hip_frame f{};
+    if ((lastStatus_ = bt709hip_ring_frame(ring_, i, &f, nullptr, nullptr)) != BT709HIP_OK) return false;
+    bt709hip_context *ctx = bt709hip_decoder_context(decoder_.handle());
+    const size_t w = static_cast<size_t>(f.width), h = static_cast<size_t>(f.height);
+    lastStatus_ = bt709hip_upload(ctx, const_cast<void *>(f.y), f.y_stride, y, w, w, h, nullptr);
+    if (lastStatus_ == BT709HIP_OK) lastStatus_ = bt709hip_upload(ctx, const_cast<void *>(f.cbcr), f.cbcr_stride, cbcr, w, w, h / 2, nullptr);
+    if (lastStatus_ == BT709HIP_OK) lastStatus_ = bt709hip_stream_synchronize(ctx, nullptr);
+    return lastStatus_ == BT709HIP_OK;
+  }
+  // frames [first, first + count) in ONE launch
+  bool decode(int first, int count, bool waitUntilCompleted) {
+    return (lastStatus_ = bt709hip_ring_decode(ring_, first, count, nullptr, waitUntilCompleted ? 1 : 0)) == BT709HIP_OK;
+  }
+  // the reference's cadence: ONE -decodeBT709: call for frame i (with BT709HIP_OPT_COALESCE on and waitUntilCompleted
+  // false the call is validated and queued; a read-back, a flush or the n-th call issues the batch)
+  bool decodeFrame(int i, bool waitUntilCompleted) {
+    bt709hip_frame f{};
+    bt709hip_surface o{};
+    if ((lastStatus_ = bt709hip_ring_frame(ring_, i, &f, nullptr, &o)) != BT709HIP_OK) return false;
+    return (lastStatus_ = bt709hip_decode(decoder_.handle(), &f, nullptr, &o, f.width, f.height, nullptr, waitUntilCompleted ? 1 : 0)) ==
+           BT709HIP_OK;
+  }
+  // zero-fills every output frame (tests: a later decode must write every pixel again)
+  bool clearOutputs() {
+    bt709hip_context *ctx = bt709hip_decoder_context(decoder_.handle());
+    for (int i = 0; i < frames(); ++i) {
+      bt709hip_surface o{};
+      if ((lastStatus_ = bt709hip_ring_frame(ring_, i, nullptr, nullptr, &o)) != BT709HIP_OK) return false;
+      if ((lastStatus_ = bt709hip_memset(ctx, o.bgra, 0, o.stride * static_cast<size_t>(o.height), nullptr)) != BT709HIP_OK) return false;
+    }
+    return (lastStatus_ = bt709hip_stream_synchronize(ctx, nullptr)) == BT709HIP_OK;
+  }
+  // (A<<24)|(R<<16)|(G<<8)|B words of output frame i (the download is ordered behind queued frames)
+  std::vector<uint32_t> pixels(int i) {
+    bt709hip_surface o{};
+    std::vector<uint32_t> px;
+    if ((lastStatus_ = bt709hip_ring_frame(ring_, i, nullptr, nullptr, &o)) != BT709HIP_OK) return px;
+    px.resize(static_cast<size_t>(o.width) * o.height);
+    bt709hip_context *ctx = bt709hip_decoder_context(decoder_.handle());
+    const size_t row = static_cast<size_t>(o.width) * 4;
+    lastStatus_ = bt709hip_download(ctx, px.data(), row, o.bgra, o.stride, row, o.height, nullptr);
+    if (lastStatus_ == BT709HIP_OK) lastStatus_ = bt709hip_stream_synchronize(ctx, nullptr);
+    return px;
+  }
+
+ private:
+  MetalBT709Decoder &decoder_;
+  bt709hip_ring *ring_ = nullptr;
+  int lastStatus_ = BT709HIP_OK;
+};
+
 // ONE process, several GPUs (bt709hip_shard_*): frame i -> lane i mod n, each lane its own context, decoder and in-flight
 // pool on devices[lane]; no collective.  What AAPLRenderer's single queue with MaxBuffersInFlight frames
 // (Renderer/AAPLRenderer.m:34, 874-985) becomes on an 8-GPU node.  Driven by one thread at a time.

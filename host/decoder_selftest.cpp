@@ -5,7 +5,7 @@
 // file holds no oracle and no reference data.
 //
 //   g++ -std=c++17 host/decoder_selftest.cpp -Lmetalbt709decoder_amd -lbt709hip -o selftest
-//   ./selftest [--host] Y Cb Cr R G B [Y Cb Cr R G B ...]
+//   ./selftest [--host | --ring] Y Cb Cr R G B [Y Cb Cr R G B ...]
 // --host: the same vectors with the frame and the texture in HOST memory, through the unchanged
 // 8-argument selector's host overload (in-flight frame pool), three frames in flight.
 #include <cstdio>
@@ -163,6 +163,46 @@ static int run_two_pass(MetalRenderContext &ctx, MetalBT709Decoder &dec) {
   return failures ? 1 : 0;
 }
 
+// --ring: every vector is one 8 x 4 frame of a device-resident FrameRing (bt709hip_ring_*).  First the whole ring in one
+// launch; then the reference's cadence -- one decodeBT709 call per frame, waitUntilCompleted FALSE -- with the coalescing
+// submit on (BT709HIP_OPT_COALESCE = 4): calls are queued, the read-back of the LAST frame issues what is left.
+static int run_ring_vectors(MetalBT709Decoder &metalDecoder, int argc, char **argv) {
+  const int n = (argc - 1) / 6, width = 8, height = 4;
+  if (n < 1) return 2;
+  FrameRing ring(metalDecoder, width, height, n, false, 1);
+  if (!ring.valid() || ring.frames() != n) return 3;
+  std::vector<uint32_t> want(static_cast<size_t>(n));
+  for (int v = 0; v < n; ++v) {
+    const int i = 1 + 6 * v;
+    std::vector<uint8_t> y(static_cast<size_t>(width) * height, static_cast<uint8_t>(std::atoi(argv[i])));
+    std::vector<uint8_t> c(static_cast<size_t>(width) * height / 2);
+    for (size_t k = 0; k < c.size(); k += 2) c[k] = static_cast<uint8_t>(std::atoi(argv[i + 1])), c[k + 1] = static_cast<uint8_t>(std::atoi(argv[i + 2]));
+    if (!ring.upload(v, y.data(), c.data())) return 3;
+    want[static_cast<size_t>(v)] = 0xFF000000u | (static_cast<uint32_t>(std::atoi(argv[i + 3])) << 16) |
+                                   (static_cast<uint32_t>(std::atoi(argv[i + 4])) << 8) | static_cast<uint32_t>(std::atoi(argv[i + 5]));
+  }
+  int failures = 0;
+  auto check_all = [&](const char *what) {
+    for (int v = n - 1; v >= 0; --v)  // last frame first: with queued frames, its read-back is what issues them
+      for (uint32_t px : ring.pixels(v))
+        if (px != want[static_cast<size_t>(v)]) {
+          std::fprintf(stderr, "%s, frame %d: got %08x, want %08x\n", what, v, px, want[static_cast<size_t>(v)]);
+          ++failures;
+          break;
+        }
+  };
+  if (!ring.decode(0, n, true)) return 3;
+  check_all("one launch");
+  if (!ring.clearOutputs()) return 3;  // the second pass must write every pixel again
+  if (!metalDecoder.setOption(BT709HIP_OPT_COALESCE, 4)) return 3;
+  for (int v = 0; v < n; ++v)
+    if (!ring.decodeFrame(v, false)) ++failures;
+  check_all("coalesced one-frame calls");
+  if (!metalDecoder.setOption(BT709HIP_OPT_COALESCE, 0)) return 3;
+  std::printf("%s: %d ring frames, %d failures\n", failures ? "FAIL" : "ok", n, failures);
+  return failures ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && std::strcmp(argv[1], "--two-pass") == 0) {
     MetalRenderContext ctx;
@@ -170,6 +210,11 @@ int main(int argc, char **argv) {
     dec.metalRenderContext = &ctx;
     if (!dec.setupMetal()) return 3;
     return run_two_pass(ctx, dec);
+  }
+  const bool ring = argc > 1 && std::strcmp(argv[1], "--ring") == 0;
+  if (ring) {
+    --argc;
+    ++argv;
   }
   const bool host = argc > 1 && std::strcmp(argv[1], "--host") == 0;
   if (host) {
@@ -185,6 +230,7 @@ int main(int argc, char **argv) {
   metalDecoder.metalRenderContext = &metalRenderContext;
   if (!metalDecoder.setupMetal()) return 3;
   if (host) return run_host_vectors(metalDecoder, argc, argv);
+  if (ring) return run_ring_vectors(metalDecoder, argc, argv);
 
   int failures = 0;
   for (int i = 1; i + 5 < argc; i += 6) {

@@ -159,7 +159,8 @@ typedef enum {
   BT709HIP_CTX_OPT_GRID_MULT = 1,       /* general (unaligned-layout) kernels: workgroups per launch = CUs x 8 x this; default 2 */
   BT709HIP_CTX_OPT_ENCODE_ROW_PAIRS = 2,/* encoder: consecutive row pairs per workgroup; default 0 = sized per launch */
   BT709HIP_CTX_OPT_ENCODE_THREADS = 3,  /* encoder: lanes per workgroup (rounded down to whole waves); default 0 = from the width */
-  BT709HIP_CTX_OPT_XCD_BANDS = 4        /* encoder: 1 (default) XCD-aware work map for launches of a multiple of 8 pictures; 0 plain order */
+  BT709HIP_CTX_OPT_XCD_BANDS = 4,       /* encoder: 1 (default) XCD-aware work map for launches of a multiple of 8 pictures; 0 plain order */
+  BT709HIP_CTX_OPT_STREAMING_TRIES = 5  /* device buffers of 256 MB or more that the library allocates itself (in-flight pool slots, the sharder's lanes) go through bt709hip_malloc_streaming with this many candidates; default 4, 1 = plain allocation */
 } bt709hip_context_option;
 int bt709hip_context_set_option(bt709hip_context *ctx, int option, int value);
 

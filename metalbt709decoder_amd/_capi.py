@@ -41,6 +41,7 @@ CTX_OPT_GRID_MULT = 1
 CTX_OPT_ENCODE_ROW_PAIRS = 2
 CTX_OPT_ENCODE_THREADS = 3
 CTX_OPT_XCD_BANDS = 4
+CTX_OPT_STREAMING_TRIES = 5
 
 
 class RingPlacement(C.Structure):  # bt709hip_ring_placement

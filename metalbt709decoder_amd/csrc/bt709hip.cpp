@@ -42,6 +42,7 @@ struct bt709hip_context {
   int grid_blocks = 0;  // workgroups a general-path launch aims for (all frames together)
   int encode_row_pairs = 0, encode_threads = 0;  // BT709HIP_CTX_OPT_ENCODE_*: 0 = sized per launch
   int xcd_bands = 1;                             // BT709HIP_CTX_OPT_XCD_BANDS: XCD-aware work map of batched encoder launches
+  int streaming_tries = 4;                       // BT709HIP_CTX_OPT_STREAMING_TRIES: placement candidates for buffers of 256 MB and more that the library allocates itself
   std::mutex encoder_mutex;
   EncoderTables encoders[3][3];  // [input gamma][output gamma], built on first use
   // bt709hip_render_scaled (pass 2 alone): built on first use under encoder_mutex
@@ -444,6 +445,9 @@ int bt709hip_context_set_option(bt709hip_context *ctx, int option, int value) {
       return BT709HIP_OK;
     case BT709HIP_CTX_OPT_XCD_BANDS:
       ctx->xcd_bands = value != 0;
+      return BT709HIP_OK;
+    case BT709HIP_CTX_OPT_STREAMING_TRIES:
+      ctx->streaming_tries = value <= 0 ? 4 : clamp_int(value, 1, 32);
       return BT709HIP_OK;
     default:
       return BT709HIP_ERR_INVALID_ARG;
@@ -1238,6 +1242,23 @@ int bt709hip_pool_destroy(bt709hip_pool *pool) {
   return BT709HIP_OK;
 }
 
+namespace {
+// Device buffers the library allocates for itself (in-flight pool slots, hence the sharder's lanes): anything of 256 MB or
+// more streams from HBM, where placement matters, and goes through the placement-aware allocator with the
+// context's BT709HIP_CTX_OPT_STREAMING_TRIES candidates (default 4; 1 = plain hipMalloc).  A 4K slot is 33 MB + 12 MB: this
+// only triggers for very large frames (e.g. 8K x 8K); the pool is PCIe-bound either way.
+hipError_t alloc_pool_buffer(bt709hip_context *ctx, size_t bytes, uint8_t **out) {
+  constexpr size_t kStreamingBytes = 256u << 20;
+  if (bytes >= kStreamingBytes && ctx->streaming_tries > 1) {
+    void *p = nullptr;
+    const int rc = bt709hip_malloc_streaming(ctx, bytes, ctx->streaming_tries, &p, nullptr, nullptr);
+    *out = static_cast<uint8_t *>(p);
+    return rc == BT709HIP_OK ? hipSuccess : (tl_hip_error != hipSuccess ? tl_hip_error : hipErrorOutOfMemory);
+  }
+  return hipMalloc(reinterpret_cast<void **>(out), bytes);
+}
+}  // namespace
+
 int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth, bt709hip_pool **out) {
   if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
   *out = nullptr;
@@ -1259,8 +1280,8 @@ int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), pool->in_bytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), pool->out_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_in), pool->in_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_out), pool->out_bytes);
+    if (e == hipSuccess) e = alloc_pool_buffer(dec->ctx, pool->in_bytes, &s.d_in);
+    if (e == hipSuccess) e = alloc_pool_buffer(dec->ctx, pool->out_bytes, &s.d_out);
   }
   if (e != hipSuccess) {
     bt709hip_pool_destroy(pool);

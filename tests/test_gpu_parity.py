@@ -1303,3 +1303,18 @@ def test_coalescing_submit(gh, oracle):
     for i, slot in enumerate(slots):
         assert np.array_equal(pool.wait(slot), oracle.decode_nv12(0, *frames[i]))
     pool.release()
+
+
+def test_cpp_host_mirror_frame_ring_and_coalescing(gh, vectors, tmp_path):
+    """C++ mirror of the two round-4 extensions (host/MetalBT709Decoder.hpp FrameRing, BT709HIP_OPT_COALESCE): the 28
+    reference vectors as the frames of a device-resident ring, decoded in one launch and then by 28 one-frame
+    -decodeBT709: calls (waitUntilCompleted FALSE) gathered four to a launch; the last frame's read-back issues the rest."""
+    import subprocess
+    from test_host_cpu import build_cpp_selftest
+    exe = build_cpp_selftest(tmp_path)
+    args = ["--ring"]
+    for r in vectors["metal_decode"]:
+        args += [str(v) for v in r["ycbcr"] + r["rgb_out"]]
+    res = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "28 ring frames, 0 failures" in res.stdout
