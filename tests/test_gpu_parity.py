@@ -1318,3 +1318,72 @@ def test_cpp_host_mirror_frame_ring_and_coalescing(gh, vectors, tmp_path):
     res = subprocess.run([exe] + args, capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "28 ring frames, 0 failures" in res.stdout
+
+
+def test_coalescing_submit_in_a_recorded_graph_and_from_two_threads(gh, oracle):
+    """Queued frames and command-buffer recording: frames queued BEFORE beginRecording are issued (not recorded), frames
+    submitted during the recording are recorded -- as one batch launch -- when the recording ends, and a replay decodes them
+    again.  Then two threads share one coalescing decoder, each on a stream of its own (a queue per stream)."""
+    import threading
+    ctx = gh.context()
+    lib = ctx.lib
+    dec = gh.make_decoder(mb.MetalBT709GammaApple, options={_capi.OPT_COALESCE: 16})
+    w, h, n = 256, 16, 6
+    frames = [gh.random_nv12(w, h, seed=61000 + i) for i in range(n + 1)]
+    bufs = [gh.make_buffer(y, c, dec.gamma) for y, c in frames]
+    texs = [ctx.makeBGRATexture((w, h)) for _ in range(n + 1)]
+    cb = ctx.commandQueue.commandBuffer(new_stream=True)
+    assert dec.decodeBT709(bufs[n], None, texs[n], cb, None, w, h, False)   # queued before the recording
+    cb.beginRecording()                                                      # ... and issued by it, unrecorded
+    assert _launch_info(ctx).grid[2] == 1
+    for i in range(n):
+        assert dec.decodeBT709(bufs[i], None, texs[i], cb, None, w, h, False)
+        assert lib.bt709hip_last_kernel_name() == b"(queued: coalescing submit)"
+    rec = cb.endRecording()                                                  # the queue is recorded here: one launch of n frames
+    assert _launch_info(ctx).grid[2] == n
+    cb.waitUntilCompleted()
+    got = ctx.getBGRATexturePixels(texs[n]).view(np.uint8).reshape(h, w * 4)
+    assert np.array_equal(got, oracle.decode_nv12(0, *frames[n]))
+    for t in texs[:n]:                                                        # nothing of the recording has run yet
+        _capi.check(lib.bt709hip_memset(ctx.handle, t.ptr, 0x11, w * h * 4, cb.stream))
+    cb.waitUntilCompleted()
+    assert (ctx.getBGRATexturePixels(texs[0]).view(np.uint8) == 0x11).all()
+    for _ in range(2):
+        rec.replay(cb)
+    cb.waitUntilCompleted()
+    for i in range(n):
+        got = ctx.getBGRATexturePixels(texs[i]).view(np.uint8).reshape(h, w * 4)
+        assert np.array_equal(got, oracle.decode_nv12(0, *frames[i])), i
+    rec.release()
+    cb.release()
+
+    # two threads, one decoder, a stream each
+    per, rounds = 24, 3
+    errs = []
+
+    def worker(k):
+        try:
+            mine = ctx.commandQueue.commandBuffer(new_stream=True)
+            fr = [gh.random_nv12(w, h, seed=62000 + 100 * k + i) for i in range(per)]
+            bb = [gh.make_buffer(y, c, dec.gamma) for y, c in fr]
+            tt = [ctx.makeBGRATexture((w, h)) for _ in range(per)]
+            for _ in range(rounds):
+                for i in range(per):
+                    if not dec.decodeBT709(bb[i], None, tt[i], mine, None, w, h, False):
+                        errs.append((k, i, dec.lastStatus))
+                mine.waitUntilCompleted()
+            for i in range(per):
+                raw = np.empty((h, w * 4), np.uint8)
+                _capi.check(lib.bt709hip_download(ctx.handle, raw.ctypes.data, w * 4, tt[i].ptr, tt[i].stride, w * 4, h, mine.stream))
+                mine.waitUntilCompleted()
+                if not np.array_equal(raw, oracle.decode_nv12(0, *fr[i])):
+                    errs.append((k, i, "pixels"))
+            mine.release()
+        except Exception as exc:  # noqa: BLE001
+            errs.append((k, repr(exc)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs[:5]

@@ -17,6 +17,9 @@ python bench.py --workload 4k-batch8 --share 1 --graph --no-cpu-baseline --steps
 for c in 8 32; do python bench.py --workload 4k-batch8 --share 1 --streams 1 --coalesce $c --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_1stream_coalesce$c.json 2>/dev/null; done
 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_4k_plain_command_2ranks_one_gpu.json 2> $O/bench_4k_plain_command_2ranks_one_gpu.err
 python bench.py --gpus 4 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_4k_plain_command_4ranks_one_gpu.json 2> $O/bench_4k_plain_command_4ranks_one_gpu.err
+# and the driver's launcher line, 2 ranks wrapped onto this one GPU
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_4k_torchrun_2ranks_one_gpu.json 2> $O/bench_4k_torchrun_2ranks_one_gpu.err
+python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py --workload 8k-half --content flat --no-cpu-baseline > $O/bench_8k-half_flat.json 2>/dev/null
 { tools/ab_batch8.sh; echo "# two frames per step"; SHARE=2 STREAMS="1 2 3 4" tools/ab_batch8.sh; } > $O/batch8_streams.txt 2>&1
 tools/encode_single_shapes.sh "320 512" "1 3" > $O/encode_single_shapes.txt 2>&1
