@@ -130,7 +130,33 @@ def test_decoder_and_context_options(lib):
     assert lib.bt709hip_decoder_get_option(d, _capi.OPT_HALF_LDS_KB, C.byref(v)) == 0 and v.value == 160
     assert lib.bt709hip_decoder_set_option(d, 99, 1) == _capi.ERR_INVALID_ARG
     assert lib.bt709hip_decoder_get_option(d, 99, C.byref(v)) == _capi.ERR_INVALID_ARG
+    # round 4: the coalescing submit is off by default, clamped to 2..32 frames per launch, 0 / 1 turn it off; a decoder
+    # without a render context queues nothing (decode fails with NOT_SETUP as before) and flushes trivially
+    assert lib.bt709hip_decoder_get_option(d, _capi.OPT_COALESCE, C.byref(v)) == 0 and v.value == 0
+    for asked, got in ((8, 8), (1000, 32), (1, 0), (-3, 0), (2, 2)):
+        assert lib.bt709hip_decoder_set_option(d, _capi.OPT_COALESCE, asked) == 0
+        assert lib.bt709hip_decoder_get_option(d, _capi.OPT_COALESCE, C.byref(v)) == 0 and v.value == got
+    assert lib.bt709hip_decoder_flush(d, None) == 0 and lib.bt709hip_decoder_flush_all(d) == 0
+    assert lib.bt709hip_decoder_flush(None, None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_decoder_has_alpha(d) == 0 and lib.bt709hip_decoder_context(d) is None
+    f = _capi.Frame(1, 16, 1, 16, 16, 2, 1, 1)
+    o = _capi.Surface(1, 64, 16, 2, 0, 0)
+    assert lib.bt709hip_decode(d, C.byref(f), None, C.byref(o), 16, 2, None, 0) == _capi.ERR_NOT_SETUP
     lib.bt709hip_decoder_destroy(d)
+    # the frame ring: argument errors need no GPU; a decoder without a context cannot make one
+    r = C.c_void_p()
+    assert lib.bt709hip_ring_create(None, 64, 16, 4, 0, 1, C.byref(r)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_decoder_create(None, 0, 0, C.byref(d)) == 0
+    assert lib.bt709hip_ring_create(d, 64, 16, 4, 0, 1, None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_ring_create(d, 63, 16, 4, 0, 1, C.byref(r)) == _capi.ERR_ODD_DIMENSIONS
+    assert lib.bt709hip_ring_create(d, 64, 16, 70000, 0, 1, C.byref(r)) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_ring_create(d, 64, 16, 4, 0, 1, C.byref(r)) == _capi.ERR_NOT_SETUP and not r.value
+    lib.bt709hip_decoder_destroy(d)
+    assert lib.bt709hip_ring_destroy(None) == 0 and lib.bt709hip_ring_frames(None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_ring_decode(None, 0, 1, None, 0) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_ring_placement_info(None, None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_mem_info(None, None, None) == _capi.ERR_INVALID_ARG
+    assert lib.bt709hip_last_launch_info(None) == _capi.ERR_INVALID_ARG
     assert lib.bt709hip_context_set_option(None, _capi.CTX_OPT_GRID_MULT, 2) == _capi.ERR_INVALID_ARG
     assert lib.bt709hip_abi_version() == _capi.ABI_VERSION
     hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()

@@ -1,8 +1,8 @@
 """4K 1:1 decode in the sRGB mode with and without an alpha plane and in the other gamma modes, over a ring of RING frames (default 256: the
 alpha planes of a 32-frame ring are 265 MB, about the size of the Infinity Cache -- round 2's and the first round-3 figure for the
 alpha decoder, 0.86, was measured on such a ring with cached alpha loads and was mostly cache hits), PER_LAUNCH frames per launch
-(environment, default = the ring; from 64 on the XCD-aware work map applies), slabs placed by bt709hip_malloc_streaming with TRIES
-candidates (runs on the GPU box):
+(environment, default = the ring; from 64 on the XCD-aware work map applies), the ring made by bt709hip_ring_create with TRIES
+candidates per slab (runs on the GPU box):
     [PER_LAUNCH=32] [ONLY_ALPHA=1] [BANDS=0] python tools/bench_alpha11.py [library|-] [ring=256] [tries=1]"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,27 +20,20 @@ ctx = gh.context(); lib, h = ctx.lib, ctx.handle
 for alpha, gamma in ((1, mb.MetalBT709GammaSRGB), (0, mb.MetalBT709GammaSRGB), (0, mb.MetalBT709GammaApple), (0, mb.MetalBT709GammaLinear), (0, mb.MetalBT709GammaITU709)):
     if os.environ.get("ONLY_ALPHA") and not alpha: continue
     dec = gh.make_decoder(gamma, has_alpha=bool(alpha), options={_capi.OPT_XCD_BANDS: int(os.environ.get("BANDS", "1"))})
-    in_pitch = W * H * 3 // 2; a_pitch = W * H; out_pitch = W * H * 4
-    si, sa, so = DeviceBuffer(ctx, ring * in_pitch, tries), DeviceBuffer(ctx, ring * a_pitch if alpha else 256, tries if alpha else 1), DeviceBuffer(ctx, ring * out_pitch, tries)
-    frames, alphas, surfs = (_capi.Frame * ring)(), (_capi.Frame * ring)(), (_capi.Surface * ring)()
+    # round 4: the ring is the product's (bt709hip_ring_create: the decoder's own launch as the placement probe, `tries` candidates per
+    # slab; an alpha decoder's ring carries the alpha plane as the third plane of the input slab)
+    fr = mb.FrameRing(dec, (W, H), ring, tries=tries)
     y, c = gh.random_nv12(W, H, seed=1); a = np.random.default_rng(2).integers(0, 256, (H, W), dtype=np.uint8)
     for i in range(ring):
-        b = si.ptr + i * in_pitch
-        ctx._upload(b, W, y, None); ctx._upload(b + W * H, W, c, None); ctx._sync(None)
-        if alpha: ctx._upload(sa.ptr + i * a_pitch, W, a, None); ctx._sync(None)
-        buf = mb.CVPixelBuffer(ctx, W, H, W, W, planes=(b, b + W * H))
-        buf.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2); buf.setAttachment("TransferFunction", gh.TRANSFER_FOR_GAMMA[dec.gamma])
-        frames[i] = buf.frame()
-        ab = mb.CVPixelBuffer(ctx, W, H, W, W, planes=(sa.ptr + (i * a_pitch if alpha else 0), b + W * H))
-        ab.setAttachment("YCbCrMatrix", mb.kCVImageBufferYCbCrMatrix_ITU_R_709_2); ab.setAttachment("TransferFunction", mb.kCVImageBufferTransferFunction_Linear)
-        alphas[i] = ab.frame()
-        surfs[i] = _capi.Surface(so.ptr + i * out_pitch, W * 4, W, H, _capi.FORMAT_BGRA8_SRGB, 0)
+        fr.pixelBuffer(i).upload_planes(y, c)
+        if alpha:
+            ab = fr.alphaPixelBuffer(i)
+            ctx._upload(ab.y_ptr, ab.y_stride, a, None); ctx._sync(None)
     per = int(os.environ.get("PER_LAUNCH", ring))
-    fsz, ssz = C.sizeof(_capi.Frame), C.sizeof(_capi.Surface)
+    out_pitch = W * H * 4
     def step():
         for i in range(0, ring, per):
-            fp = C.cast(C.byref(frames, i * fsz), C.POINTER(_capi.Frame)); ap = C.cast(C.byref(alphas, i * fsz), C.POINTER(_capi.Frame)); sp = C.cast(C.byref(surfs, i * ssz), C.POINTER(_capi.Surface))
-            rc = lib.bt709hip_decode_batch(dec._handle, per, fp, ap if alpha else None, sp, None, 0); assert rc == 0, rc
+            assert fr.decode(i, per), dec.lastStatus
     import time
     t_end = time.perf_counter() + 0.4
     while time.perf_counter() < t_end:
@@ -54,4 +47,7 @@ for alpha, gamma in ((1, mb.MetalBT709GammaSRGB), (0, mb.MetalBT709GammaSRGB), (
     ms = C.c_float(); lib.bt709hip_event_elapsed_ms(h, e0, e1, C.byref(ms))
     us = ms.value * 1e3 / (n * ring)
     nbytes = W * H * 3 // 2 + (W * H if alpha else 0) + out_pitch
-    print("4K 1:1 ring %d x %d per launch gamma=%d alpha=%d: %.2f us/frame %.1f Gpx/s %.3f of 8TB/s %s" % (ring, per, gamma, alpha, us, W * H / us / 1e3, nbytes / us / 1e3 / 8000, lib.bt709hip_last_kernel_name().decode()))
+    pl = fr.placement()
+    print("4K 1:1 ring %d x %d per launch gamma=%d alpha=%d: %.2f us/frame %.1f Gpx/s %.3f of 8TB/s %s  (ring placement: first pairing %.0f, chosen %.0f GB/s of %d x %d candidates)"
+          % (ring, per, gamma, alpha, us, W * H / us / 1e3, nbytes / us / 1e3 / 8000, lib.bt709hip_last_kernel_name().decode(), pl.first_GBps, pl.chosen_GBps, pl.in_candidates, pl.out_candidates))
+    fr.release()
