@@ -19,12 +19,6 @@ constexpr int kBlockThreads = 256;     // general-path workgroup: 4 waves of 64
 #endif
 constexpr int kMaxBlockThreads = BT709_MAX_BLOCK_THREADS;  // fast-path workgroup is sized per frame width, up to 8 waves
 constexpr int kQuadsPerLane = BT709_QUADS_PER_LANE;        // 4x2-pixel quads a fast-path lane owns per row pair
-// a bucket table of this size or more (the LINEAR mode's 33 KiB) is shared by kBigTableRows row pairs' worth of lanes
-#ifndef BT709_BIG_TABLE_ROWS
-#define BT709_BIG_TABLE_ROWS 2
-#endif
-constexpr int kBigTableRows = BT709_BIG_TABLE_ROWS;  // 1 or 2 (2 x kMaxBlockThreads = 1024 lanes, the workgroup limit)
-constexpr uint32_t kBigTableBytes = 16u * 1024u;
 constexpr int kMaxBatch = 32;          // == BT709HIP_MAX_BATCH: frames in the kernarg table
 // XCD-aware work map (bt709_kernels.hip decode_nv12_quads): used for launches of a multiple of 8 frames from this many on.
 // Measured (round 3, same call, plain vs banded): decode 32 frames 0.756 / 0.741-0.761, 64 0.741 / 0.745-0.760, 128 0.72 / 0.77,
@@ -237,9 +231,9 @@ inline uint32_t quads_block_threads(uint32_t width) {
 
 // Row pairs stacked in one workgroup (blockDim.y): only when one tile spans the row and the
 // row needs few threads, so the workgroup still has up to kMaxBlockThreads threads.
-inline uint32_t quads_rows_per_block(uint32_t block_threads, uint32_t tiles, uint32_t max_threads = kMaxBlockThreads) {
+inline uint32_t quads_rows_per_block(uint32_t block_threads, uint32_t tiles) {
   if (tiles != 1 || block_threads == 0) return 1;
-  const uint32_t by = max_threads / block_threads;
+  const uint32_t by = kMaxBlockThreads / block_threads;
   return by < 1 ? 1 : by;
 }
 

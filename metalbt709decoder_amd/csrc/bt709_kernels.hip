@@ -98,11 +98,8 @@ __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[
 // alpha pointers and strides 4-byte aligned; output pointer and stride 16-byte
 // aligned.  grid = (tiles, H/2, frames); a tile is blockDim * kQuadsPerLane quads.
 // ---------------------------------------------------------------------------
-// MAXT: the largest workgroup the instantiation is launched with.  kMaxBlockThreads for every decoder but one: a gamma whose
-// bucket table is large (the LINEAR mode's 4 096 buckets = 33 KiB against 4-8 KiB) stages it once per workgroup, so its
-// workgroups cover TWO row pairs with 2 x kMaxBlockThreads lanes (launch_decode): half the staging per pixel.
-template <bool HAS_ALPHA, bool NT, bool QUANT, int MAXT = kMaxBlockThreads>
-__global__ void __launch_bounds__(MAXT)
+template <bool HAS_ALPHA, bool NT, bool QUANT>
+__global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_quads(const DecodeParams p) {
   constexpr int UNROLL = kQuadsPerLane;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -344,11 +341,8 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
     return launch_decode(tail, frames - head, variant, has_alpha, quantiser, nontemporal, 0, grid_x, block_threads, stream);
   }
   if (variant == kVariantQuads) {
-    // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y -- and so does a decoder with a big table
-    // (see the kernel's MAXT): measured on the LINEAR mode, 4K x 256 per launch, tools/r04_linear_rows.sh
-    const bool big_table = !quant && !has_alpha && p_in.table_unit_bytes >= kBigTableBytes && kBigTableRows > 1;
-    const uint32_t by = big_table ? quads_rows_per_block(block_threads, grid_x, kMaxBlockThreads * kBigTableRows)
-                                  : quads_rows_per_block(block_threads, grid_x);
+    // grid_x = tiles per row pair; narrow frames stack row pairs in blockDim.y
+    const uint32_t by = quads_rows_per_block(block_threads, grid_x);
     dim3 grid(grid_x, (p_in.height / 2 + by - 1) / by, static_cast<uint32_t>(frames));
     const dim3 block(block_threads, by, 1);
     DecodeParams banded = p_in;
@@ -372,11 +366,6 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
       if (nontemporal) hipLaunchKernelGGL((decode_nv12_quads<false, true, true>), grid, block, lds, stream, p);
       else hipLaunchKernelGGL((decode_nv12_quads<false, false, true>), grid, block, lds, stream, p);
       return nontemporal ? "decode_nv12_quads<nt,quantiser>" : "decode_nv12_quads<quantiser>";
-    }
-    if (big_table) {
-      if (nontemporal) hipLaunchKernelGGL((decode_nv12_quads<false, true, false, kMaxBlockThreads * kBigTableRows>), grid, block, lds, stream, p);
-      else hipLaunchKernelGGL((decode_nv12_quads<false, false, false, kMaxBlockThreads * kBigTableRows>), grid, block, lds, stream, p);
-      return nontemporal ? "decode_nv12_quads<nt>" : "decode_nv12_quads";
     }
     if (nontemporal) {
       hipLaunchKernelGGL((decode_nv12_quads<false, true, false>), grid, block, lds, stream, p);
@@ -415,8 +404,6 @@ hipError_t prepare_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false, true>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, true, false>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false, false>),
-      reinterpret_cast<const void *>(&decode_nv12_quads<false, true, false, kMaxBlockThreads * kBigTableRows>),
-      reinterpret_cast<const void *>(&decode_nv12_quads<false, false, false, kMaxBlockThreads * kBigTableRows>),
       reinterpret_cast<const void *>(&unconvert_packed444<true, false>),
       reinterpret_cast<const void *>(&unconvert_packed444<false, false>),
       reinterpret_cast<const void *>(&decode_nv12_blocks<true, true>),

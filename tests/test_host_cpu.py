@@ -329,12 +329,12 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
             if candidate_fmas:  # and their results go nowhere but into v_log_f32 / v_exp_f32
                 assert len(re.findall(r"\bv_log_f32", body)) == 12 and len(re.findall(r"\bv_exp_f32", body)) == 12, kernel
             n += 1
-    assert n == 41  # every instantiation the launchers can pick (round 4: + the two 1024-lane forms of the big-table decoders)
+    assert n == 39  # every instantiation the launchers can pick
     assert fused > 300
 
 
 def test_isa_memory_shape(asm):
-    body = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1ELb0ELi512EE")
+    body = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1ELb0EE")
     assert body.count("global_store_dwordx4") == 4          # 2 quads x 2 rows, 16 B per lane
     assert len(re.findall(r"global_store_dwordx4 .* nt", body)) == 4  # streaming (non-temporal) stores
     assert len(re.findall(r"global_load_dword\s", body)) == 6  # 2 quads x (2 luma rows + 1 CbCr row)
@@ -347,7 +347,7 @@ def test_isa_memory_shape(asm):
     first, last = body.index("global_store_dwordx4"), body.rindex("global_store_dwordx4")
     assert "vmcnt" not in body[first:last]
     assert "scratch_" not in body                           # no spills
-    meta = re.search(r"\.name:\s+_ZN5bt70917decode_nv12_quadsILb0ELb1ELb0ELi512EE.*?\.vgpr_count:\s+(\d+)", asm, flags=re.S)
+    meta = re.search(r"\.name:\s+_ZN5bt70917decode_nv12_quadsILb0ELb1ELb0EE.*?\.vgpr_count:\s+(\d+)", asm, flags=re.S)
     assert meta and int(meta.group(1)) <= 64                # 8 waves per SIMD
 
 
@@ -357,7 +357,7 @@ def test_isa_valu_budget_contract(asm):
     from a plain float add (no v_cvt_u32_f32 in the 1:1 kernel), the decode kernels never touch the
     MODE register (round-to-nearest bucket index), and in the encoder every switch of the rounding
     mode is undone inside the same asm statement."""
-    quads = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1ELb0ELi512EE")
+    quads = _kernel_body(asm, "17decode_nv12_quadsILb0ELb1ELb0EE")
     assert len(re.findall(r"\bv_cvt_f32_ubyte[0-3]", quads)) == 24          # 16 luma + 8 chroma bytes per 16 pixels
     assert not re.search(r"\bv_cvt_f32_i32|\bv_cvt_u32_f32|\bv_add_u32_sdwa", quads)
     assert len(re.findall(r"v_add_f32_e64 .* clamp", quads)) == 48            # saturation rides on the adds
@@ -367,7 +367,7 @@ def test_isa_valu_budget_contract(asm):
         for body in _kernel_bodies(asm, kernel):
             assert "s_setreg" not in body, kernel
             n += 1
-    assert n == 27
+    assert n == 25
     for kernel in ("16encode_bgra_nv12", "23encode_bgra_nv12_blocks"):
         for body in _kernel_bodies(asm, kernel):
             to_zero = len(re.findall(r"s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 0, 2\), 3", body))
