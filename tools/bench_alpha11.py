@@ -3,7 +3,7 @@ alpha planes of a 32-frame ring are 265 MB, about the size of the Infinity Cache
 alpha decoder, 0.86, was measured on such a ring with cached alpha loads and was mostly cache hits), PER_LAUNCH frames per launch
 (environment, default = the ring; from 64 on the XCD-aware work map applies), the ring made by bt709hip_ring_create with TRIES
 candidates per slab (runs on the GPU box):
-    [PER_LAUNCH=32] [ONLY_ALPHA=1] [BANDS=0] python tools/bench_alpha11.py [library|-] [ring=256] [tries=1]"""
+    [PER_LAUNCH=32] [ONLY_ALPHA=1] [ONLY_GAMMA=2] [BANDS=0] python tools/bench_alpha11.py [library|-] [ring=256] [tries=1]"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -19,6 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] != "-": _capi.load(os.path.abspath(sys.argv
 ctx = gh.context(); lib, h = ctx.lib, ctx.handle
 for alpha, gamma in ((1, mb.MetalBT709GammaSRGB), (0, mb.MetalBT709GammaSRGB), (0, mb.MetalBT709GammaApple), (0, mb.MetalBT709GammaLinear), (0, mb.MetalBT709GammaITU709)):
     if os.environ.get("ONLY_ALPHA") and not alpha: continue
+    if os.environ.get("ONLY_GAMMA") and (alpha or gamma != int(os.environ["ONLY_GAMMA"])): continue
     dec = gh.make_decoder(gamma, has_alpha=bool(alpha), options={_capi.OPT_XCD_BANDS: int(os.environ.get("BANDS", "1"))})
     # round 4: the ring is the product's (bt709hip_ring_create: the decoder's own launch as the placement probe, `tries` candidates per
     # slab; an alpha decoder's ring carries the alpha plane as the third plane of the input slab)
