@@ -885,55 +885,29 @@ decode_nv12_scaled(const DecodeParams p) {
 // The sum is saturated (a unorm render target clamps), rgb goes through the sRGB-encode table,
 // alpha is round(255 v) in arithmetic (alpha_word_of).
 // ---------------------------------------------------------------------------
-// lin[256] of the BGRA8 form in 2^kRenderLinCopiesLog2 interleaved copies (lane l reads copy l & (copies - 1)): a ds_read_b32 is
-// served in two groups of 32 lanes over 32 banks, so the single 1 KiB copy costs ~6.85 LDS cycles per gather on random bytes
-// (32 random entries on 32 banks: expected worst bank 3.4-way) against 2 conflict-free; entry b of copy c sits at
-// ((b << log2) + c) * 4.  Measured: tools/r04_render_lin_copies.sh.
-#ifndef BT709_RENDER_LIN_COPIES_LOG2
-#define BT709_RENDER_LIN_COPIES_LOG2 0
-#endif
-constexpr uint32_t kRenderLinCopiesLog2 = BT709_RENDER_LIN_COPIES_LOG2;
-constexpr uint32_t kRenderLinBytes = 1024u << kRenderLinCopiesLog2;
-
 template <bool IN_RGBA16F>
 __global__ void __launch_bounds__(kBlockThreads)
 render_scaled(const RenderParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  constexpr uint32_t kLinLog2 = IN_RGBA16F ? 0u : kRenderLinCopiesLog2;  // the RGBA16F form reads no lin[]
-  constexpr uint32_t kLinBytes = 1024u << kLinLog2;
-  {  // stage: lin[256] (x copies) | encode buckets.  lin[] sits at LDS address 0 (this kernel has no static LDS, so its dynamic
-     // segment starts there; trapped below if that ever changes): a texel's byte then becomes its table address by ONE SDWA shift
-     // (plus the lane's copy offset when the table is replicated).
+  {  // stage: lin[256] | encode buckets.  lin[] sits at LDS address 0 (this kernel has no static LDS, so its dynamic segment
+     // starts there; trapped below if that ever changes): a texel's byte then becomes its table address by ONE SDWA shift.
     const uint32_t tid = threadIdx.x, n = blockDim.x;
     u32x4 *d = reinterpret_cast<u32x4 *>(lds_raw);
     const u32x4 *e = reinterpret_cast<const u32x4 *>(p.table_encode);
+    const u32x4 *l = reinterpret_cast<const u32x4 *>(p.table_lin);
     const uint32_t ne = p.table_encode_bytes / 16;
-    if (kLinLog2 == 0) {
-      const u32x4 *l = reinterpret_cast<const u32x4 *>(p.table_lin);
-      stage_batched(d, ne + 64u, tid, n, [&](uint32_t i) { return i < 64u ? l[i] : e[i - 64u]; });  // one batch: both tables' loads in flight together
-    } else {
-      // 16-byte unit i of the replicated image holds dwords 4i .. 4i + 3 = entry (4i + k) >> log2, each copy the same value
-      const uint32_t *l = reinterpret_cast<const uint32_t *>(p.table_lin);
-      constexpr uint32_t kUnits = kLinBytes / 16u;
-      stage_batched(d, ne + kUnits, tid, n, [&](uint32_t i) {
-        if (i >= kUnits) return e[i - kUnits];
-        u32x4 v;
-        v.x = l[(4u * i) >> kLinLog2], v.y = l[(4u * i + 1u) >> kLinLog2], v.z = l[(4u * i + 2u) >> kLinLog2], v.w = l[(4u * i + 3u) >> kLinLog2];
-        return v;
-      });
-    }
+    stage_batched(d, ne + 64u, tid, n, [&](uint32_t i) { return i < 64u ? l[i] : e[i - 64u]; });  // one batch: both tables' loads in flight together
     if (lds_address(lds_raw) != 0u) __builtin_trap();
   }
   __syncthreads();
   RescaleLookup r = {};
   r.enc_shift = 3;
-  r.enc_off = kLinBytes;  // behind lin[256] and its copies
+  r.enc_off = 1024u;  // behind lin[256]
   r.split_offset = p.encode_offset;
   r.split_shift = p.encode_shift;
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
-  uint32_t two = 2u + kLinLog2;  // SDWA operands cannot be inline constants; the shift that turns a byte into its entry's address
+  uint32_t two = 2u;  // SDWA operands cannot be inline constants
   asm("" : "+v"(two));
-  const uint32_t lin_copy = (threadIdx.x & ((1u << kLinLog2) - 1u)) << 2;  // this lane's copy of lin[]
 
   const uint32_t oy0 = blockIdx.y * p.rows, oy1 = min(oy0 + p.rows, p.out_height);
   const StripTaps vt = strip_taps(oy0, p.scale_y);  // before any lane leaves
@@ -1010,7 +984,6 @@ render_scaled(const RenderParams p) {
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(ar) : "v"(two), "v"(v));
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ag) : "v"(two), "v"(v));
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(ab) : "v"(two), "v"(v));
-        if (kLinLog2 != 0) ar |= lin_copy, ag |= lin_copy, ab |= lin_copy;
         s[0] = *reinterpret_cast<LdsFloatPtr>(ar);  // R: byte 2
         s[1] = *reinterpret_cast<LdsFloatPtr>(ag);  // G: byte 1
         s[2] = *reinterpret_cast<LdsFloatPtr>(ab);  // B: byte 0
@@ -1078,7 +1051,7 @@ const char *launch_render_scaled(const RenderParams &p_in, int frames, bool in_r
   // the kernel forms row offsets in 32 bits
   if (static_cast<uint64_t>(p.height) * p.in_stride >= (1ull << 31) || static_cast<uint64_t>(p.out_height) * p.out_stride >= (1ull << 31)) return nullptr;
   const dim3 grid(cols, (p.out_height + rows - 1) / rows, static_cast<uint32_t>(frames));
-  const size_t lds = static_cast<size_t>(p.table_encode_bytes) + (in_rgba16f ? 1024u : kRenderLinBytes);
+  const size_t lds = static_cast<size_t>(p.table_encode_bytes) + 1024;
   if (in_rgba16f) hipLaunchKernelGGL(render_scaled<true>, grid, dim3(kBlockThreads), lds, stream, p);
   else hipLaunchKernelGGL(render_scaled<false>, grid, dim3(kBlockThreads), lds, stream, p);
   return in_rgba16f ? "render_scaled<rgba16f>" : "render_scaled<bgra8>";
