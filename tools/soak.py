@@ -1,7 +1,8 @@
 """Random soak of every GPU path against the oracle (runs on the GPU box):
     python tools/soak.py [seed] [cases]
 decode (opaque / alpha, 8-bit and RGBA16Float targets), exact 2:1 (both kernels, with alpha), any-ratio
-(with alpha), the reference's two passes through both intermediate formats, the encoder.
+(with alpha), the reference's two passes through both intermediate formats, the encoder, the frame ring and the
+coalescing submit (round 4).
 Fresh seeds every time it is used; the committed tests hold the fixed-seed fuzz."""
 import os
 import sys
@@ -17,7 +18,7 @@ ctx = gh.context()
 scale = mb.MetalScaleRenderContext(); assert scale.setupRenderPipelines(ctx)
 bad, counts = 0, {}
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 8))
     counts[kind] = counts.get(kind, 0) + 1
     gamma = int(rng.integers(0, 4))
     w = 4 * int(rng.integers(1, 600)); h = 4 * int(rng.integers(1, 40))
@@ -52,6 +53,33 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
         got = ctx.getBGRATexturePixels(view).view(np.uint8).reshape(oh, ow * 4)
         src = oracle.decode_nv12_rgba16f(g, y, c, alpha=a) if fmt == mb.MTLPixelFormatRGBA16Float else oracle.decode_nv12(g, y, c, alpha=a)
         want = oracle.render_scaled(src, ow, oh)
+    elif kind == 6:  # round 4: a device-resident ring (bt709hip_ring_*), a random sub-range in one launch, 1:1 or exact 2:1
+        n, half = int(rng.integers(1, 12)), bool(rng.integers(0, 3) == 0)
+        dec = gh.make_decoder(g, has_alpha=a is not None)
+        ring = mb.FrameRing(dec, (w, h), n, halfScale=half, tries=1)
+        frs = [gh.random_nv12(w, h, seed=int(rng.integers(0, 1 << 30))) for _ in range(n)]
+        for i, (fy, fc) in enumerate(frs):
+            ring.pixelBuffer(i).upload_planes(fy, fc)
+            if a is not None:
+                ab = ring.alphaPixelBuffer(i); ctx._upload(ab.y_ptr, ab.y_stride, a, None); ctx._sync(None)
+        first = int(rng.integers(0, n)); count = int(rng.integers(1, n - first + 1))
+        assert ring.decode(first, count, waitUntilCompleted=True)
+        ow, oh = (w // 2, h // 2) if half else (w, h)
+        got = np.concatenate([ctx.getBGRATexturePixels(ring.texture(i)).view(np.uint8).reshape(-1) for i in range(first, first + count)])
+        want = np.concatenate([(oracle.decode_nv12_half(g, fy, fc, alpha=a) if half else oracle.decode_nv12(g, fy, fc, alpha=a)).reshape(-1)
+                               for fy, fc in frs[first:first + count]])
+        ring.release()
+    elif kind == 7:  # round 4: the coalescing submit, a random window and a random number of one-frame calls, read back without a sync
+        n, window = int(rng.integers(1, 20)), int(rng.integers(2, 33))
+        dec = gh.make_decoder(g, has_alpha=a is not None, options={_capi.OPT_COALESCE: window})
+        frs = [gh.random_nv12(w, h, seed=int(rng.integers(0, 1 << 30))) for _ in range(n)]
+        bufs = [gh.make_buffer(fy, fc, dec.gamma) for fy, fc in frs]
+        abuf = gh.make_alpha_buffer(a) if a is not None else None
+        texs = [ctx.makeBGRATexture((w, h)) for _ in range(n)]
+        for b, t in zip(bufs, texs):
+            assert dec.decodeBT709(b, abuf, t, None, None, w, h, False)
+        got = np.concatenate([ctx.getBGRATexturePixels(t).view(np.uint8).reshape(-1) for t in reversed(texs)])
+        want = np.concatenate([oracle.decode_nv12(g, fy, fc, alpha=a).reshape(-1) for fy, fc in reversed(frs)])
     else:  # encoder: BGRA -> NV12, then compare planes
         ig, og = [(1, 0), (1, 1), (2, 2), (0, 0), (1, 2)][int(rng.integers(0, 5))]
         bgra = rng.integers(0, 1 << 32, w * h, dtype=np.uint32)
