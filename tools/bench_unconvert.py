@@ -24,8 +24,9 @@ pitch = W * H * 4
 src, dst = DeviceBuffer(ctx, ring * pitch), DeviceBuffer(ctx, ring * pitch)
 words = np.random.default_rng(7).integers(0, 1 << 24, (H, W), dtype=np.uint32)
 for i in range(ring):
-    ctx._upload(src.ptr + i * pitch, W * 4, np.roll(words, i, axis=1).view(np.uint8).reshape(H, W * 4), None)
-ctx._sync(None)
+    frame = np.ascontiguousarray(np.roll(words, i, axis=1)).view(np.uint8).reshape(H, W * 4)
+    ctx._upload(src.ptr + i * pitch, W * 4, frame, None)
+    ctx._sync(None)  # the upload is asynchronous: the host array must outlive it
 surfs = [_capi.Surface(dst.ptr + i * pitch, W * 4, W, H, 0, 0) for i in range(ring)]
 e0, e1 = C.c_void_p(), C.c_void_p(); lib.bt709hip_event_create(h, C.byref(e0)); lib.bt709hip_event_create(h, C.byref(e1))
 for nstreams in (1, 2, 3):
