@@ -248,44 +248,57 @@ template <bool VEC, bool QUANT>
 __global__ void __launch_bounds__(kBlockThreads)
 unconvert_packed444(const UnconvertParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  // VEC: a lane owns 4 consecutive pixels of TWO consecutive rows (height is even: BGRAToBT709Converter.m:69-74), both 16-byte
+  // loads issued before the table is staged -- the table's 4 KiB are then shared by 2 048 pixels instead of 1 024 and the
+  // loads overlap the staging, as in the 1:1 kernel (round 4: 12.7 -> 11.x us per 4K frame, tools/bench_unconvert.py).
+  // Frame words are touched once: non-temporal.  !VEC: one pixel per lane, one row per workgroup row, any alignment.
+  constexpr uint32_t N = VEC ? 4 : 1, ROWS = VEC ? 2 : 1;
+  const uint32_t row0 = blockIdx.y * ROWS;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // group of N pixels
+  const bool live = i * N < p.width;
+  const uint32_t ic = live ? i : 0u;  // lanes past the row's end load a valid group and do not store (every lane stages the table)
+  uint32_t w[ROWS][N];
+#pragma unroll
+  for (uint32_t r = 0; r < ROWS; ++r) {
+    const uint8_t *in = p.in + static_cast<size_t>(row0 + r) * p.in_stride;
+    if (VEC) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in + 16 * ic));
+      w[r][0] = v.x, w[r][N > 1 ? 1 : 0] = v.y, w[r][N > 2 ? 2 : 0] = v.z, w[r][N > 3 ? 3 : 0] = v.w;
+    } else {
+      w[r][0] = *reinterpret_cast<const uint32_t *>(in + 4 * ic);
+    }
+  }
   if (!QUANT) {
-    stage_table(lds_raw, p.table_unit, p.table_unit_bytes);
+    stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the loads are in flight
     __syncthreads();
   }
   const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
-  const uint32_t row = blockIdx.y;
-  const uint8_t *in = p.in + static_cast<size_t>(row) * p.in_stride;
-  uint8_t *out = p.out + static_cast<size_t>(row) * p.out_stride;
-  constexpr uint32_t N = VEC ? 4 : 1;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // group of N pixels
-  if (i * N >= p.width) return;
-  uint32_t w[N], o[N];
-  if (VEC) {
-    const u32x4 v = *reinterpret_cast<const u32x4 *>(in + 16 * i);
-    w[0] = v.x, w[N > 1 ? 1 : 0] = v.y, w[N > 2 ? 2 : 0] = v.z, w[N > 3 ? 3 : 0] = v.w;
-  } else {
-    w[0] = *reinterpret_cast<const uint32_t *>(in + 4 * i);
-  }
-  float x[3 * N];
+  if (!live) return;
 #pragma unroll
-  for (uint32_t k = 0; k < N; ++k) {
-    const Chroma c = chroma_terms(byte_of(w[k], 1), byte_of(w[k], 2));
-    pixel_rgb(byte_of(w[k], 0), c, x[3 * k], x[3 * k + 1], x[3 * k + 2]);
-  }
+  for (uint32_t r = 0; r < ROWS; ++r) {
+    float x[3 * N];
 #pragma unroll
-  for (uint32_t k = 0; k < N; ++k) {
-    uint32_t b[3];
+    for (uint32_t k = 0; k < N; ++k) {
+      const Chroma c = chroma_terms(byte_of(w[r][k], 1), byte_of(w[r][k], 2));
+      pixel_rgb(byte_of(w[r][k], 0), c, x[3 * k], x[3 * k + 1], x[3 * k + 2]);
+    }
+    uint32_t o[N];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
-      b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)));
-    o[k] = pack_bgra(b[0], b[1], b[2], p.alpha_word);
-  }
-  if (VEC) {
-    u32x4 v;
-    v.x = o[0], v.y = o[N > 1 ? 1 : 0], v.z = o[N > 2 ? 2 : 0], v.w = o[N > 3 ? 3 : 0];
-    *reinterpret_cast<u32x4 *>(out + 16 * i) = v;
-  } else {
-    *reinterpret_cast<uint32_t *>(out + 4 * i) = o[0];
+    for (uint32_t k = 0; k < N; ++k) {
+      uint32_t b[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)));
+      o[k] = pack_bgra(b[0], b[1], b[2], p.alpha_word);
+    }
+    uint8_t *out = p.out + static_cast<size_t>(row0 + r) * p.out_stride;
+    if (VEC) {
+      u32x4 v;
+      v.x = o[0], v.y = o[N > 1 ? 1 : 0], v.z = o[N > 2 ? 2 : 0], v.w = o[N > 3 ? 3 : 0];
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + 16 * i));
+    } else {
+      *reinterpret_cast<uint32_t *>(out + 4 * i) = o[0];
+    }
   }
 }
 
@@ -303,7 +316,7 @@ const char *launch_unconvert(const DecodeParams &t, const void *in, size_t in_st
   p.unit_magic = t.unit_magic;
   p.alpha_word = t.alpha_word;
   const uint32_t groups = vec ? width / 4 : width;
-  const dim3 grid((groups + kBlockThreads - 1) / kBlockThreads, height, 1);
+  const dim3 grid((groups + kBlockThreads - 1) / kBlockThreads, vec ? height / 2 : height, 1);  // vec: two rows per workgroup row
   const size_t lds = quantiser ? 0 : t.table_unit_bytes;
   if (vec) {
     if (quantiser) hipLaunchKernelGGL((unconvert_packed444<true, true>), grid, dim3(kBlockThreads), lds, stream, p);
