@@ -810,7 +810,9 @@ def test_unconvert_packed_444_words(gh, oracle, vectors, gamma):
     ctx = gh.context()
     rng = np.random.default_rng(40 + gamma)
     dec = gh.make_decoder(gamma, alpha_fill=0)
-    for w, h in ((64, 8), (30, 6), (1024, 2)):
+    # (3840, 6) / (1028, 4): the vectorised kernel's partial last tile (a lane past the row's end stages the table and stores
+    # nothing), several two-row groups; (4100, 2): more than one tile plus a ragged end
+    for w, h in ((64, 8), (30, 6), (1024, 2), (3840, 6), (1028, 4), (4100, 2)):
         words = rng.integers(0, 1 << 24, (h, w), dtype=np.uint32)
         tex = ctx.makeBGRATexture((w, h))
         assert mb.BGRAToBT709Converter.unconvert(dec, words, tex, w, h), dec.lastStatus
