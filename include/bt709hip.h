@@ -390,8 +390,8 @@ int bt709hip_pool_release(bt709hip_pool *pool, int slot);
  * keeping its rate).  bt709hip_ring_create therefore allocates up to `tries` candidates per slab (0 = the
  * default, 6; 1 = first allocation, no probing; rings under 256 MB never probe), times the DECODER'S OWN LAUNCH over the ring
  * on the pairings (~15 ms each; every output candidate under input 0 first -- twice or three times `tries` of them when they
- * all look alike -- then every input with the `tries` fastest outputs, then the three best pairings again three times as
- * long), keeps the fastest pairing and frees the rest.  It always leaves 4 GiB of the device free and hunts among what it
+ * all look alike -- then every input with the `tries` fastest outputs, then the three best pairings and the first-allocated
+ * one again, six times as long), keeps the fastest pairing and frees the rest.  It always leaves 4 GiB of the device free and hunts among what it
  * could allocate.  Set-up cost: 1-2 s for a 12 GB ring.  half_scale != 0: outputs are (W/2) x (H/2) and the ring decodes
  * through bt709hip_decode_half_batch.  A decoder with an alpha channel gets an alpha plane per frame (third plane of the
  * input slab).  The memory is NOT cleared.  The decoder must outlive the ring. */
