@@ -623,6 +623,10 @@ def main(argv=None):
         return [float(v) for v in t]
 
     runner.run_steps(args.warmup)
+    runner.sync()
+    kernel_name = runner.kernel_name()  # of the step's launch: read here, before any sentinel / copy dispatch replaces it
+    if not args.dry_run and not kernel_name.startswith("decode_nv12"):
+        sys.exit("bench.py: the step launched %r, not a decode kernel" % kernel_name)
     # The contract's region: EXACTLY K steps between barrier + sync on both sides.  It is timed first and reported
     # (`k_step_region_ms`); with the driver's K = 20 it is ~10 ms of GPU work, too short to quote alone (SURVEY 8(d)
     # asks for >= 100 ms per timing), so the figure that is reported as `value` comes from regions of m * K steps,
@@ -698,7 +702,7 @@ def main(argv=None):
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "kernel": runner.kernel_name(),
+            "kernel": kernel_name,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_us": round(avg_launch_s * 1e6, 3),
             "read_GBps": round(read_gbps, 1),
