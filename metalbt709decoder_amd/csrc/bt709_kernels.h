@@ -83,7 +83,6 @@ struct DecodeParams {
   // XCD-aware work map of the short-lived kernels (filled by the launchers): grid.x = 8 x tiles, x & 7 = the workgroup's
   // place in the round-robin over the XCDs, which owns frames [(x & 7) * frames_per_band, ...) of the launch
   uint32_t xcd_bands, frames_per_band;
-  uint32_t band_chunk_log2;  // xcd_bands == 3: frames per XCD class and group = 2^this
 };
 
 // Pass 1 into an RGBA16Float target (bt709_rgba16f.hip): the threshold table of transfer_tables.h

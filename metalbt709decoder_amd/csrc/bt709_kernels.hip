@@ -113,13 +113,8 @@ decode_nv12_quads(const DecodeParams p) {
   // [b F/8, (b + 1) F/8): eight sequential streams that cannot drift into each other.  Long launches then GAIN (no tail,
   // no boundary): 256 frames per launch 0.80-0.81.  Speed only: nothing depends on which XCD a workgroup really lands on.
   const uint32_t tile = p.xcd_bands ? blockIdx.x >> 3 : blockIdx.x;
-  // xcd_bands 1: contiguous bands; 2: bands interleaved frame by frame; 3: bands in chunks of 2^band_chunk_log2 frames (XCD class
-  // b owns frames [g * 8c + b * c, + c) of every group g of 8c frames: the eight streams stay c frames apart instead of F/8)
   const uint32_t frame = p.xcd_bands == 1 ? (blockIdx.x & 7u) * p.frames_per_band + blockIdx.z
-                       : (p.xcd_bands == 2 ? blockIdx.z * 8u + (blockIdx.x & 7u)
-                       : (p.xcd_bands == 3 ? ((blockIdx.z >> p.band_chunk_log2) << (p.band_chunk_log2 + 3u)) + ((blockIdx.x & 7u) << p.band_chunk_log2) +
-                                             (blockIdx.z & ((1u << p.band_chunk_log2) - 1u))
-                                           : blockIdx.z));
+                       : (p.xcd_bands == 2 ? blockIdx.z * 8u + (blockIdx.x & 7u) : blockIdx.z);
   const FramePlanes f = frame_planes(p, frame);
   const uint32_t quads = p.width >> 2;
   const uint32_t row_pairs = p.height >> 1;
@@ -365,12 +360,8 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
     const dim3 block(block_threads, by, 1);
     DecodeParams banded = p_in;
     if (xcd_bands && frames >= kXcdBandMinFrames && frames % 8 == 0) {  // see the kernel: 8 contiguous bands of frames, one per XCD class
-      banded.xcd_bands = static_cast<uint32_t>(xcd_bands > 2 ? 3 : xcd_bands);
+      banded.xcd_bands = static_cast<uint32_t>(xcd_bands);
       banded.frames_per_band = static_cast<uint32_t>(frames) / 8u;
-      if (xcd_bands > 2) {  // option value 3, 4, 5, ...: chunks of 2, 4, 8, ... frames per XCD class; the launch must be whole groups
-        banded.band_chunk_log2 = static_cast<uint32_t>(xcd_bands - 2);
-        if (banded.frames_per_band % (1u << banded.band_chunk_log2) != 0) banded.xcd_bands = 1, banded.band_chunk_log2 = 0;
-      }
       grid = dim3(grid_x * 8u, grid.y, banded.frames_per_band);
     }
     const DecodeParams &p = banded;

@@ -763,7 +763,7 @@ int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value) {
     case BT709HIP_OPT_HALF_KERNEL: dec->half_rep = clamp_int(value, -1, 1); return BT709HIP_OK;
     case BT709HIP_OPT_HALF_WORKGROUPS: dec->half_workgroups = clamp_int(value, 0, 1 << 20); return BT709HIP_OK;
     case BT709HIP_OPT_HALF_LDS_KB: dec->half_lds_kb = clamp_int(value, 0, 160); return BT709HIP_OK;
-    case BT709HIP_OPT_XCD_BANDS: dec->xcd_bands = clamp_int(value, 0, 8); return BT709HIP_OK;
+    case BT709HIP_OPT_XCD_BANDS: dec->xcd_bands = clamp_int(value, 0, 2); return BT709HIP_OK;
     case BT709HIP_OPT_COALESCE: set_coalescing(dec, value <= 1 ? 0 : clamp_int(value, 2, kMaxBatch)); return BT709HIP_OK;
     default: return BT709HIP_ERR_INVALID_ARG;
   }

@@ -4,7 +4,9 @@ ONE process, two rings of 256 4K frames -- the first allocation (tries = 1, ofte
 ring the 256-frame launch under every work map: plain, contiguous bands (shipped: streams 32 frames = 1.06 GB apart), bands
 interleaved frame by frame, bands in chunks of 2 / 4 / 8 / 16 frames (streams 66 MB ... 531 MB apart), and the plain map in
 32-frame launches.  Same frames (random bytes) on both rings; every map's output checksummed against the shipped map's.
-    python tools/band_chunks_lab.py [rounds=2]"""
+    python tools/band_chunks_lab.py [rounds=2]
+NEEDS the chunked map, which lived in the kernel only for this experiment (BT709HIP_OPT_XCD_BANDS values 3..6 of commit 8045956;
+the product clamps the option to 0..2 again): check that commit out to re-run it.  Result: profiles/r04_band_chunks.txt."""
 import ctypes as C
 import os
 import sys
