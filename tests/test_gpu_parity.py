@@ -1216,9 +1216,15 @@ def test_frame_ring_with_placement_hunt(gh, oracle):
         got = ctx.getBGRATexturePixels(small.texture(i)).view(np.uint8).reshape(8, 32 * 4)
         assert np.array_equal(got, oracle.decode_nv12_half(1, fr[i][0], fr[i][1], alpha=al[i])), i
     small.release()
-    # argument errors, no GPU work
-    h_ = C.c_void_p()
+    # a ring the device cannot hold (60 000 x 4K = 2.7 TB): a clean BT709HIP_ERR_HIP, nothing leaked, with and without a hunt
     lib = ctx.lib
+    free0, free1, h_ = C.c_size_t(), C.c_size_t(), C.c_void_p()
+    _capi.check(lib.bt709hip_mem_info(ctx.handle, C.byref(free0), None))
+    for t in (1, 3):
+        assert lib.bt709hip_ring_create(dec._handle, 3840, 2160, 60000, 0, t, C.byref(h_)) == _capi.ERR_HIP and not h_.value
+    _capi.check(lib.bt709hip_mem_info(ctx.handle, C.byref(free1), None))
+    assert abs(free1.value - free0.value) < (64 << 20), (free0.value, free1.value)
+    # argument errors, no GPU work
     assert lib.bt709hip_ring_create(dec._handle, 63, 16, 4, 0, 1, C.byref(h_)) == _capi.ERR_ODD_DIMENSIONS
     assert lib.bt709hip_ring_create(dec._handle, 66, 16, 4, 1, 1, C.byref(h_)) == _capi.ERR_ODD_DIMENSIONS
     assert lib.bt709hip_ring_create(dec._handle, 64, 16, 0, 0, 1, C.byref(h_)) == _capi.ERR_INVALID_ARG
