@@ -611,3 +611,50 @@ def test_cpp_host_mirror_builds_and_fails_without_gpu(lib, tmp_path):
         pytest.skip("a GPU is present")
     r = subprocess.run([exe, "235", "128", "128", "255", "255", "255"], capture_output=True, text=True)
     assert r.returncode == 3  # setupMetal() false: no device, no fallback
+
+
+def test_profile_summary_cuts_a_kernel_trace_to_the_sentinel_bracketed_regions(tmp_path):
+    """tools/pmc_summary.py: bench.py brackets every timed region with two sentinel dispatches (copy_probe, 512 work-items
+    opening, 1024 closing); only the decode dispatches between a pair are averaged -- set-up probes, warm-up, spot check and
+    side legs run the same kernel and must not count (round 3's rocprof mean was off for that reason)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    rows = [("Kernel_Name", "Grid_Size", "Start_Timestamp", "End_Timestamp", "Dispatch_Id", "Counter_Name", "Counter_Value")]
+    t = [1000]
+
+    def add(name, grid, dur, did):
+        rows.append((name, grid, t[0], t[0] + dur, did, "X", dur))
+        t[0] += dur + 10
+    dq = "void bt709::decode_nv12_quads<false, true, false>(bt709::DecodeParams)"
+    did = 0
+    for dur in (374, 375):                      # the hunt's probes: outside any region
+        did += 1; add(dq, 1 << 20, dur, did)
+    did += 1; add("bt709::copy_probe(...)", 1 << 22, 5000, did)   # a big copy (the ring copy): not a sentinel
+    for region in ((413, 414, 415), (412, 416)):
+        did += 1; add("bt709::copy_probe(...)", 512, 2, did)
+        for dur in region:
+            did += 1; add(dq, 1 << 20, dur, did)
+        did += 1; add("bt709::copy_probe(...)", 1024, 2, did)
+        did += 1; add(dq, 1 << 20, 999, did)    # spot check / side leg between regions
+    did += 1; add("bt709::copy_probe(...)", 512, 2, did)           # an opening sentinel that never closes
+    did += 1; add(dq, 1 << 20, 777, did)
+    trace = tmp_path / "trace.csv"
+    import csv
+    with open(trace, "w", newline="") as f:
+        csv.writer(f).writerows(rows)
+    timed = pmc_summary.timed_dispatches(str(trace), "decode_nv12")
+    assert timed["regions"] == 2 and sorted(timed["by_kernel"][dq]) == [412, 413, 414, 415, 416]  # the region that never closed is dropped
+    out = tmp_path / "stats.csv"
+    pmc_summary.write_timed_stats(str(out), {"regions": 2, "by_kernel": {dq: [413, 414, 415, 412, 416]}})
+    rec = list(csv.DictReader(open(out)))[0]
+    assert rec["Calls"] == "5" and float(rec["AverageNs"]) == 414.0 and rec["MedianNs"] == "414" and "2 sentinel-bracketed" in rec["Scope"]
+    # the same cut for a --pmc pass (by dispatch id): the probes and the unclosed tail stay out
+    keep = pmc_summary.timed_dispatch_ids(list(csv.DictReader(open(trace))))
+    durs = sorted(int(r["Counter_Value"]) for r in csv.DictReader(open(trace)) if r["Dispatch_Id"] in keep and "decode" in r["Kernel_Name"])
+    assert durs == [412, 413, 414, 415, 416]
+    # a trace without sentinels (another program than bench.py): no cut
+    plain = tmp_path / "plain.csv"
+    with open(plain, "w", newline="") as f:
+        csv.writer(f).writerows([rows[0], rows[1], rows[2]])
+    assert pmc_summary.timed_dispatches(str(plain), "decode_nv12") is None
+    assert pmc_summary.timed_dispatch_ids(list(csv.DictReader(open(plain)))) is None

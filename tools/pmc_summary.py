@@ -37,19 +37,21 @@ def timed_dispatches(kernel_trace_csv, kernel_filter):
             return int(r["Grid_Size"])
         return int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    by_kernel, regions, inside, in_region = collections.defaultdict(list), 0, False, 0
+    by_kernel, regions, inside, pending = collections.defaultdict(list), 0, False, []
     for r in rows:
         name = r["Kernel_Name"]
         if "copy_probe" in name and grid(r) in (512, 1024):
             if grid(r) == 512:
-                inside, in_region = True, 0
+                inside, pending = True, []  # a region that never closed is dropped
             elif inside:
                 inside = False
-                regions += 1 if in_region else 0
+                for k, d in pending:  # committed only when the closing sentinel has been seen
+                    by_kernel[k].append(d)
+                regions += 1 if pending else 0
+                pending = []
             continue
         if inside and kernel_filter in name:
-            by_kernel[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-            in_region += 1
+            pending.append((name, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     return {"regions": regions, "by_kernel": dict(by_kernel)} if regions else None
 
 
@@ -61,17 +63,19 @@ def timed_dispatch_ids(pmc_rows):
     by_id = {}
     for r in pmc_rows:
         by_id.setdefault(int(r["Dispatch_Id"]), r)
-    keep, inside, pairs = set(), False, 0
+    keep, inside, pairs, pending = set(), False, 0, []
     for did in sorted(by_id):
         r = by_id[did]
         if "copy_probe" in r["Kernel_Name"] and int(r["Grid_Size"]) in (512, 1024):
             if int(r["Grid_Size"]) == 512:
-                inside = True
+                inside, pending = True, []
             elif inside:
                 inside, pairs = False, pairs + 1
+                keep.update(pending)
+                pending = []
             continue
         if inside:
-            keep.add(r["Dispatch_Id"])
+            pending.append(r["Dispatch_Id"])
     return keep if pairs else None
 
 
