@@ -88,8 +88,9 @@ struct DecodeParams {
 // Pass 1 into an RGBA16Float target (bt709_rgba16f.hip): the threshold table of transfer_tables.h
 // HalfTable and the constants of the candidate.  Travels beside DecodeParams (frames, pitches).
 struct HalfParams {
-  const void *table;     // float T[]: T[i] = smallest x with H(x) >= h_min + i; nullptr: no curve (LINEAR)
-  uint32_t table_bytes;  // 0 without a table
+  const void *table;     // float T[]: T[i] = smallest x with H(x) >= h_min + i, then the candidate tangents; nullptr: no curve (LINEAR)
+  uint32_t table_bytes;  // 0 without a table; else thresholds + candidates
+  uint32_t cand_offset;  // byte offset of the candidate tangents {value, slope} (transfer_tables.h HalfTable::cand) in `table`
   uint32_t h_min, h_max; // codes the table covers
   float split, low_scale, pre_add, pre_scale, exponent;
   uint32_t row_pairs_per_block;  // filled by the launcher

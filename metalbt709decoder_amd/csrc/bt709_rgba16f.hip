@@ -8,11 +8,14 @@
 // with the reference's double-precision pow inside the curve.  No GPU pow is bit-identical to libm's, so:
 //   * below the curve's split point the reference multiplies by a constant: one exact float multiply
 //     and the hardware conversion (v_cvt_f16_f32, round to nearest even) give H directly;
-//   * above it, exp2(g * log2(base)) from v_log_f32 / v_exp_f32 is good to ~2^-20 -- far finer than a
-//     half's 2^-11 spacing -- and is pushed down a little on purpose, so its half h0 is H or H - 1 and the
-//     one threshold above h0 settles it exactly:  H = h0 + (x >= T[h0 + 1])   (transfer_tables.h HalfTable).
-// T is indexed by the OUTPUT code: one entry per step of H, 24-34 KiB in LDS, staged once per
-// workgroup; a workgroup therefore walks several row pairs (the 8-bit kernel's 4 KiB table allows
+//   * above it, a CANDIDATE whose half h0 is H or H - 1 is settled exactly by the one threshold above h0:
+//     H = h0 + (x >= T[h0 + 1])   (transfer_tables.h HalfTable).  The candidate is the tangent of the curve at the
+//     start of x's bucket (641 buckets {value, slope}: the floats sharing an exponent and 7 mantissa bits), one
+//     exact subtraction and one fma: it lies below the convex curve by at most 1.0e-4 of the value, a fifth of a
+//     half's spacing.  (Rounds 2-3: exp2(g * log2(base)) from v_log_f32 / v_exp_f32, two quarter-rate
+//     instructions per channel -- 36 to 40 issue cycles per channel against 18 now.)
+// T is indexed by the OUTPUT code: one entry per step of H, 24-34 KiB in LDS, plus 5 KiB of tangents, staged once
+// per workgroup; a workgroup therefore walks several row pairs (the 8-bit kernel's 4 KiB table allows
 // one short-lived workgroup per row pair, this one's does not).
 //
 // Memory plan (HBM-bound: 1.5 B read + 8 B written per pixel): a lane owns a 2x2 block -- two
@@ -28,13 +31,11 @@
 namespace bt709 {
 namespace {
 
-constexpr float kHalfBias = 2.0e-5f;  // log2 units: the candidate is low by a factor 2^-kHalfBias
-
 struct HalfLookup {
-  float split, low_scale, pre_add, pre_scale, exponent;
-  float pre_add_scaled;  // pre_add * pre_scale
-  uint32_t h_below;      // h_min - 1
-  uint32_t table_off;    // LDS address of T[h_min] - 4 * h_min
+  float split, low_scale;
+  uint32_t h_below;    // h_min - 1
+  uint32_t table_off;  // LDS address of T[h_min] - 4 * h_min
+  uint32_t cand_off;   // LDS address of the candidate tangents - 8 * kHalfCandFirst's low 10 bits (see half_code)
 };
 
 __device__ __forceinline__ uint32_t half_bits(float v) {
@@ -43,27 +44,26 @@ __device__ __forceinline__ uint32_t half_bits(float v) {
 }
 
 // H(x) for a saturated x in [0, 1]
-// HAS_PRE: the curve's base is (x + a) / (1 + a) (sRGB, ITU); without it the base is x itself (Apple)
-template <bool HAS_TABLE, bool HAS_PRE>
+template <bool HAS_TABLE>
 __device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
   // The product is rounded to binary32 first, THEN to binary16, as on the CPU: the empty asm keeps hipcc
   // from fusing multiply and conversion into v_fma_mixlo_f16 (one rounding instead of two).
   float lowv = __fmul_rn(x, t.low_scale);  // exact below the split for 1/16; x itself when there is no curve
   asm("" : "+v"(lowv));
   if (!HAS_TABLE) return half_bits(lowv);
-  // (Round 2's first form -- unbiased candidate, both neighbours' thresholds, x clamped to the split, the low piece
-  // converted apart: commit 8e386e3 -- ran at 0.70 against 0.77, profiles/r02_ab_rgba16f.txt.)
-  // Above the split the candidate is pushed DOWN by kHalfBias in the exponent (a factor 1 - 1.4e-5: several
-  // times the error of v_log_f32 * g -> v_exp_f32, a thirtieth of a half's spacing), so its half is H or
-  // H - 1, never H + 1, and ONE threshold settles it: H = h0 + (x >= T[h0 + 1]).  The bias rides in the fma
-  // that replaces the multiply, and the (x + a) / (1 + a) step is one fma too: both belong to the CANDIDATE,
-  // not to the reference's arithmetic -- any value within the stated bounds gives the same H.
+  // Above the split: the tangent at the start of x's bucket (transfer_tables.h).  Bucket = bits(x) >> 16; its low 10 bits
+  // index the table (v_bfe_u32 + v_lshl_add_u32: cand_off already holds "- 8 * (kHalfCandFirst & 0x3ff)"); an x below
+  // 2^-5 reads some bytes of the threshold table in front of the tangents instead -- inside the LDS allocation, and unused:
+  // such an x is below every split and takes the exact product.  x - x_q is exact (same binade); the fma belongs to the
+  // CANDIDATE, not to the reference's arithmetic -- any value in (true * (1 - 4.8e-4), true] gives the same H.
   // Below the split the exact product takes the candidate's place before the one conversion; its half IS H,
   // and it goes through the same settlement: the index is held at h_min - 1 from below, T[h_min] is the
   // smallest x of the WHOLE curve that reaches h_min, so nothing is added (and a value of the low piece that
   // already rounds to h_min is compared with T[h_min + 1] > split).  No clamp of x, no second conversion.
-  const float base = HAS_PRE ? __builtin_fmaf(x, t.pre_scale, t.pre_add_scaled) : x;
-  const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(t.exponent, __builtin_amdgcn_logf(base), -kHalfBias));  // v_log_f32 is log2
+  const uint32_t xb = __float_as_uint(x);
+  const u32x2 c = *reinterpret_cast<LdsPairPtr>((((xb >> 16) & 0x3ffu) << 3) + t.cand_off);  // {value, slope}
+  const float dx = __fadd_rn(x, -__uint_as_float(xb & 0xffff0000u));
+  const float p = __builtin_fmaf(dx, __uint_as_float(c.y), __uint_as_float(c.x));
   const uint32_t h0 = half_bits(x < t.split ? lowv : p);
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
   const LdsFloatPtr e = reinterpret_cast<LdsFloatPtr>((max(h0, t.h_below) << 2) + t.table_off);
@@ -73,23 +73,20 @@ __device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
 }  // namespace
 
 // grid = (tiles of blockDim 2x2 blocks, groups of row_pairs_per_block row pairs, frames)
-// CURVE: 0 = no curve (LINEAR), 1 = power curve on x itself (Apple), 2 = power curve on (x + a) / (1 + a) (sRGB, ITU)
+// CURVE: 0 = no curve (LINEAR: the conversion alone), 1 = a power curve above a split point (Apple, sRGB, ITU: the tables decide which)
 template <int CURVE, bool HAS_ALPHA, bool PAIRS>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
-  constexpr bool HAS_TABLE = CURVE != 0, HAS_PRE = CURVE == 2;
+  constexpr bool HAS_TABLE = CURVE != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   if (HAS_TABLE) stage_table(lds_raw, hp.table, hp.table_bytes);  // the device copy starts with the guard entry T[h_min - 1]
   __syncthreads();
   HalfLookup t;
   t.split = hp.split;
   t.low_scale = hp.low_scale;
-  t.pre_add = hp.pre_add;
-  t.pre_scale = hp.pre_scale;
-  t.exponent = hp.exponent;
-  t.pre_add_scaled = __fmul_rn(hp.pre_add, hp.pre_scale);
   t.h_below = hp.h_min - 1u;
   t.table_off = lds_address(lds_raw) + 4u - (hp.h_min << 2);
+  t.cand_off = lds_address(lds_raw) + hp.cand_offset - ((kHalfCandFirst & 0x3ffu) << 3);
 
   // XCD-aware work map (p.xcd_bands, launches of a multiple of 8 frames): see bt709_kernels.hip decode_nv12_quads
   const uint32_t tile = p.xcd_bands ? blockIdx.x >> 3 : blockIdx.x;
@@ -149,8 +146,7 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
     for (int px = 0; px < 4; ++px) {
       float r, g, b;
       pixel_rgb(yv[px], c, r, g, b);
-      const uint32_t hr = half_code<HAS_TABLE, HAS_PRE>(t, r), hg = half_code<HAS_TABLE, HAS_PRE>(t, g),
-                     hb = half_code<HAS_TABLE, HAS_PRE>(t, b);
+      const uint32_t hr = half_code<HAS_TABLE>(t, r), hg = half_code<HAS_TABLE>(t, g), hb = half_code<HAS_TABLE>(t, b);
       const uint32_t ha = HAS_ALPHA ? (half_bits(alpha_value(av[px])) << 16) : opaque;  // linear alpha, unquantised
       w[2 * px] = hr | (hg << 16);
       w[2 * px + 1] = hb | ha;
@@ -207,7 +203,7 @@ const char *launch_decode_rgba16f(const DecodeParams &p_in, const HalfParams &hp
   }
   const dim3 block(threads);
   const bool pairs = in_align >= 2;
-  const int curve = hp.table_bytes == 0 ? 0 : ((hp.pre_add == 0.0f && hp.pre_scale == 1.0f) ? 1 : 2);
+  const int curve = hp.table_bytes == 0 ? 0 : 1;
   const size_t lds = curve ? hp.table_bytes : 16;
 #define BT709_LAUNCH_RGBA16F(C, A, P) hipLaunchKernelGGL((decode_nv12_rgba16f<C, A, P>), grid, block, lds, stream, p, hp)
 #define BT709_LAUNCH_RGBA16F_AP(C)                                                            \
@@ -216,8 +212,7 @@ const char *launch_decode_rgba16f(const DecodeParams &p_in, const HalfParams &hp
     else { if (pairs) BT709_LAUNCH_RGBA16F(C, false, true); else BT709_LAUNCH_RGBA16F(C, false, false); }         \
   } while (0)
   if (curve == 0) BT709_LAUNCH_RGBA16F_AP(0);
-  else if (curve == 1) BT709_LAUNCH_RGBA16F_AP(1);
-  else BT709_LAUNCH_RGBA16F_AP(2);
+  else BT709_LAUNCH_RGBA16F_AP(1);
 #undef BT709_LAUNCH_RGBA16F_AP
 #undef BT709_LAUNCH_RGBA16F
   return has_alpha ? "decode_nv12_rgba16f<alpha>" : "decode_nv12_rgba16f";
@@ -230,8 +225,6 @@ hipError_t prepare_rgba16f_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_rgba16f<0, false, true>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<0, false, false>),
       reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, true, true>),  reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, true, false>),
       reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, false, true>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, false, false>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<2, true, true>),  reinterpret_cast<const void *>(&decode_nv12_rgba16f<2, true, false>),
-      reinterpret_cast<const void *>(&decode_nv12_rgba16f<2, false, true>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<2, false, false>),
   };
   for (const void *fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

@@ -239,6 +239,9 @@ int ensure_half_table(bt709hip_decoder *dec, void *stream) {
     image.push_back(std::numeric_limits<float>::infinity());
     image.push_back(std::numeric_limits<float>::infinity());
     while (image.size() % 4 != 0) image.push_back(std::numeric_limits<float>::infinity());
+    hp.cand_offset = static_cast<uint32_t>(image.size() * sizeof(float));  // the candidate tangents ride behind the thresholds
+    image.insert(image.end(), t.cand.begin(), t.cand.end());
+    while (image.size() % 4 != 0) image.push_back(0.0f);
     hp.table_bytes = static_cast<uint32_t>(image.size() * sizeof(float));
     void *d = nullptr;
     if (int rc = upload_table(image.data(), hp.table_bytes, &d)) return rc;

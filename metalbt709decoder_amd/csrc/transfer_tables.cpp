@@ -248,7 +248,24 @@ bool build_half_table(int gamma, HalfTable *out) {
   }
   out->thresholds.push_back(inf);  // T[h_max + 1]
   while (out->thresholds.size() % 4 != 0) out->thresholds.push_back(inf);
+  // candidate tangents (transfer_tables.h): in double from the curve's constants, biased down by 2^-20, rounded to float
+  out->cand.clear();
+  const double a = out->pre_add, s = out->pre_scale, g = out->exponent, keep = 1.0 - 1.0 / 1048576.0;
+  for (uint32_t k = kHalfCandFirst; k < kHalfCandFirst + kHalfCandCount; ++k) {
+    const double xq = from_bits(k << 16);
+    const double base = (xq + a) * s;
+    out->cand.push_back(static_cast<float>(std::pow(base, g) * keep));
+    out->cand.push_back(static_cast<float>(g * s * std::pow(base, g - 1.0) * keep));
+  }
   return true;
+}
+
+float half_candidate(const HalfTable &t, float x) {
+  const uint32_t xb = to_bits(x), k = xb >> 16;
+  if (t.cand.empty() || k < kHalfCandFirst || k >= kHalfCandFirst + kHalfCandCount) return 0.0f;
+  volatile float dx = x - from_bits(xb & 0xffff0000u);  // exact
+  volatile float p = std::fmaf(dx, t.cand[2 * (k - kHalfCandFirst) + 1], t.cand[2 * (k - kHalfCandFirst)]);
+  return p;
 }
 
 uint32_t uniform_index(float v, float n) {

@@ -7,6 +7,7 @@ the pin is tests/golden/pass2.json: half codes of all 2^24 (Y,Cb,Cr) computed fr
 matrix step and curve functions (oracle/ref_harness.c), and the fused-rescale goldens the two-pass
 route must reproduce."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -92,6 +93,34 @@ def test_half_lookup_correction_step(pass2):
                 want = fn(gamma, x, 0, None)
                 assert fn(gamma, x, -1, None) == want, (gamma, x)
         assert fn(gamma, 0.5, 1, None) < 0
+
+
+def test_half_candidate_is_H_or_H_minus_1_for_every_float(tmp_path, oracle):
+    """Round 4: the RGBA16Float kernel takes its candidate from a table of tangents (one exact subtraction + one fma) instead
+    of v_log_f32 / v_exp_f32.  The host replay of exactly those two operations over the product's own table, for EVERY float
+    from each curve's split point to 1.0 (36-38 million per gamma), against the oracle's curve with the reference's double
+    pow: the candidate never exceeds the true value and its half is H or H - 1 -- what the single-threshold settlement needs
+    (tests/native/half_candidate_sweep.cpp).  The GPU sweeps over all 2^24 triples check the kernel's end result."""
+    import ctypes as C
+    import subprocess
+    out = str(tmp_path / "libhalf_candidate_sweep.so")
+    HERE = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(HERE)
+    odir, csrc = os.path.join(root, "oracle"), os.path.join(root, "metalbt709decoder_amd", "csrc")
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-Wall", "-Werror",
+                        "-I", csrc, "-I", odir, os.path.join(HERE, "native", "half_candidate_sweep.cpp"),
+                        os.path.join(csrc, "transfer_tables.cpp"), "-o", out, "-L", odir, "-loracle", "-Wl,-rpath," + odir,
+                        "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = C.CDLL(out)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    for gamma in (0, 1, 3):  # Apple, sRGB, ITU-709: the curves (LINEAR has no curve and no candidate)
+        res = (C.c_uint64 * 5)()
+        assert lib.sweep_half_candidate(gamma, threads, res) == 0
+        swept, above, outside, below, first = list(res)
+        assert swept > 30_000_000 and above == 0 and outside == 0, (gamma, swept, above, outside, hex(first))
+        assert 0 < below < swept // 4  # the tangent is low by up to a fifth of a half's spacing: H - 1 happens, not often
+    assert lib.sweep_half_candidate(2, threads, (C.c_uint64 * 5)()) == -1
 
 
 # ------------------------------------------------------------------ GPU

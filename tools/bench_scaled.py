@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--out-height", type=int, default=1440)
     ap.add_argument("--frames-per-launch", type=int, default=1)
     ap.add_argument("--xcd-bands", type=int, default=1, help="decoder option BT709HIP_OPT_XCD_BANDS")
+    ap.add_argument("--gamma", default="apple", choices=["apple", "srgb", "linear", "itu709"])
     ap.add_argument("--library", default=None, help="a variant build of libbt709hip.so (python -m metalbt709decoder_amd.build --variant)")
     args = ap.parse_args()
     if args.library:
@@ -53,7 +54,9 @@ def main():
     ring = args.ring - args.ring % fpl
     ctx = gh.context()
     lib, h = ctx.lib, ctx.handle
-    dec = gh.make_decoder(mb.MetalBT709GammaApple, options={_capi.OPT_XCD_BANDS: args.xcd_bands})
+    gamma = {"apple": mb.MetalBT709GammaApple, "srgb": mb.MetalBT709GammaSRGB, "linear": mb.MetalBT709GammaLinear,
+             "itu709": mb.MetalBT709GammaITU709}[args.gamma]
+    dec = gh.make_decoder(gamma, options={_capi.OPT_XCD_BANDS: args.xcd_bands})
 
     in_px = {"render8": 4, "render16": 8}.get(path)          # bytes per input texel of pass 2 alone
     out_px = 8 if path == "rgba16f" else 4
