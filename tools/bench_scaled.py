@@ -78,7 +78,7 @@ def main():
             y, c = gh.random_nv12(W, H, seed=0x709 + i)
             ctx._upload(base, W, y, None)
             ctx._upload(base + W * H, W, c, None)
-            frames[i] = _capi.Frame(base, W, base + W * H, W, W, H, 1, 1)
+            frames[i] = _capi.Frame(base, W, base + W * H, W, W, H, 1, gh.TRANSFER_FOR_GAMMA[dec.gamma])
         ctx._sync(None)
         surfs[i] = _capi.Surface(slab_out.ptr + i * out_pitch, OW * out_px, OW, OH,
                                  _capi.FORMAT_RGBA16F if path == "rgba16f" else _capi.FORMAT_BGRA8_SRGB, 0)

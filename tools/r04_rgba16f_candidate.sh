@@ -9,6 +9,6 @@ for round in 1 2; do
     run --ring 128 --frames-per-launch 128 $lib
     run --frames-per-launch 16 $lib
     run --frames-per-launch 1 $lib
-    run --ring 128 --frames-per-launch 128 --gamma srgb $lib
+    run --ring 128 --frames-per-launch 128 --gamma srgb $lib; run --ring 128 --frames-per-launch 128 --gamma itu709 $lib
   done
 done
