@@ -118,6 +118,10 @@ thread_local const char *tl_kernel_name = "";
 
 int hip_fail(hipError_t e) {
   tl_hip_error = e;
+  // The runtime keeps the error as this thread's "last error" until somebody reads it, and every launch here ends in
+  // hipGetLastError(): without this, a failed allocation (reported to its caller, as it should be) would also fail the NEXT
+  // decode of the thread with a stale out-of-memory (round 4: found by a test that asks for a ring the device cannot hold).
+  (void)hipGetLastError();
   return BT709HIP_ERR_HIP;
 }
 
@@ -395,6 +399,7 @@ int bt709hip_device_count(void) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) {
     tl_hip_error = e;
+    (void)hipGetLastError();  // read and cleared: see hip_fail
     return e == hipErrorNoDevice ? 0 : BT709HIP_ERR_HIP;
   }
   return n;

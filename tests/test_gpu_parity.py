@@ -1224,6 +1224,12 @@ def test_frame_ring_with_placement_hunt(gh, oracle):
         assert lib.bt709hip_ring_create(dec._handle, 3840, 2160, 60000, 0, t, C.byref(h_)) == _capi.ERR_HIP and not h_.value
     _capi.check(lib.bt709hip_mem_info(ctx.handle, C.byref(free1), None))
     assert abs(free1.value - free0.value) < (64 << 20), (free0.value, free1.value)
+    # ... and the failed allocation does not linger as the thread's "last HIP error": the next decode succeeds (it used to
+    # fail with a stale out-of-memory, found by this very test)
+    ys, cs = gh.random_nv12(64, 16, seed=5)
+    assert np.array_equal(gh.gpu_decode(ys, cs, mb.MetalBT709GammaApple, decoder=dec), oracle.decode_nv12(0, ys, cs))
+    assert lib.bt709hip_malloc(ctx.handle, 1 << 50, C.byref(h_)) == _capi.ERR_HIP and lib.bt709hip_last_hip_error() != 0
+    assert np.array_equal(gh.gpu_decode(ys, cs, mb.MetalBT709GammaApple, decoder=dec), oracle.decode_nv12(0, ys, cs))
     # argument errors, no GPU work
     assert lib.bt709hip_ring_create(dec._handle, 63, 16, 4, 0, 1, C.byref(h_)) == _capi.ERR_ODD_DIMENSIONS
     assert lib.bt709hip_ring_create(dec._handle, 66, 16, 4, 1, 1, C.byref(h_)) == _capi.ERR_ODD_DIMENSIONS
