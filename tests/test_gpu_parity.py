@@ -1401,3 +1401,30 @@ def test_coalescing_submit_in_a_recorded_graph_and_from_two_threads(gh, oracle):
     for t in threads:
         t.join()
     assert not errs, errs[:5]
+
+
+def test_bench_line_on_the_gpu():
+    """bench.py end to end on the GPU with a short ring (48 x 4K: its input is still twice the Infinity Cache): one JSON line,
+    the step's kernel named (not a sentinel or a probe), the product ring's placement report, both roofline fractions -- the
+    hunted ring's and the first allocation's --, the 8-band parity spot check, a same-run copy figure.  (The headline itself
+    is the driver's to run; this keeps the wiring under the GPU test step.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ring", "48", "--steps", "3", "--warmup", "1",
+                        "--placement-tries", "2", "--no-cpu-baseline", "--no-smooth-leg"], capture_output=True, text=True,
+                       timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    rf = d["roofline"]
+    assert d["parity_spot_check"] == "ok" and len(d["parity_spot_frames"]) == 8 and d["value"] > 100.0
+    assert rf["kernel"] == "decode_nv12_quads<nt>" and rf["bound"] == "hbm" and 0.3 < rf["frac"] < 1.0
+    assert 0.3 < rf["first_allocation_frac"] < 1.0 and rf["same_run_copy_GBps"] > 1000.0
+    assert rf["algorithmic_bytes_per_launch"] == 48 * 45_619_200
+    pl = d["config"]["placement"]
+    assert pl["tries"] == 2 and pl["rings_resident"] == ["first", "hunted"] and pl["pairings_probed"] >= 2
+    assert abs(d["value"] - 48 * 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
