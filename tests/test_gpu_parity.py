@@ -1409,6 +1409,7 @@ def test_bench_line_on_the_gpu():
     hunted ring's and the first allocation's --, the 8-band parity spot check, a same-run copy figure.  (The headline itself
     is the driver's to run; this keeps the wiring under the GPU test step.)"""
     import json
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
