@@ -580,7 +580,9 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python3 bench.py --gpus N`: this process becomes the launcher of N ranks and never touches a GPU
-        sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv)))
+        # a rank that hangs (a wedged GPU) must not hang the launcher for ever: one hour covers any run of this script
+        sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv),
+                             timeout_s=float(os.environ.get("BT709_BENCH_LAUNCH_TIMEOUT_S", "3600"))))
     if world != args.gpus:
         args.gpus = world  # under torch.distributed.run the launcher's world size is authoritative
 
