@@ -90,6 +90,15 @@ def parse_args(argv=None):
     ap.add_argument("--placement-tries", type=int, default=6,
                     help="bt709hip_ring_create's `tries`: candidates per slab of the ring, the fastest-streaming pairing kept (untimed "
                          "set-up); 1 = first allocation only")
+    ap.add_argument("--hunt-max-gb", type=float, default=0.0,
+                    help="bt709hip_ring_options.max_bytes of the placement hunt in GB (device memory the hunt may hold at once, ring "
+                         "included); 0 = the library's default, half of the free memory")
+    ap.add_argument("--hunt-max-ms", type=int, default=0, help="bt709hip_ring_options.max_ms: wall-clock budget of the hunt; 0 = none")
+    ap.add_argument("--hunt-frugal", action="store_true", help="bt709hip_ring_options.frugal: the incumbent pair + one candidate pair only")
+    ap.add_argument("--launcher", default="processes", choices=["processes", "threads"],
+                    help="--gpus N > 1: `processes` = one process per GPU (the driver's torch.distributed.run line, or this script "
+                         "starting its own ranks); `threads` = ONE process driving N GPUs through bt709hip_ringset_* (a ring per "
+                         "device, one launch per device per step issued from one thread): the reference's one-process shape")
     ap.add_argument("--coalesce", type=int, default=0,
                     help="BT709HIP_OPT_COALESCE: gather this many one-frame submits into one launch (4k-batch8; 0 = off)")
     ap.add_argument("--stream-priorities", default="", metavar="P1,P2,...",
@@ -99,6 +108,9 @@ def parse_args(argv=None):
                     help="bt709hip_decoder_set_option(ID, VALUE) on the bench decoder (tuning sweeps)")
     ap.add_argument("--library", default=None,
                     help="load this build of libbt709hip.so (python -m metalbt709decoder_amd.build --variant ...) for A/B runs")
+    ap.add_argument("--allow-shared-devices", action="store_true",
+                    help="let ranks wrap onto fewer GPUs than ranks (functional runs of the N > 1 path on a smaller box); the line then says "
+                         "\"shared_devices\": true and n_gpus counts the DISTINCT devices.  Without it such a job is refused")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: sleep instead of decoding (control-flow test)")
     return ap.parse_args(argv)
 
@@ -157,6 +169,8 @@ class GpuRunner:
             sys.exit("HIP device %d could not be set up" % (local_rank % ndev))
         self.lib, self.h = self.ctx.lib, self.ctx.handle
         info = self.ctx.info()
+        # which physical device this rank drives: the line reports one record per rank (config.devices) and counts the DISTINCT ones
+        self.identity = {"rank": rank, "ordinal": info.device_ordinal, "pci_bus_id": info.pci_bus_id.decode(), "uuid": info.uuid.decode()}
         self.arch = info.arch.decode()
         self.device = info.name.decode() or self.arch  # some ROCm builds leave the marketing name empty
         self.props = {"compute_units": info.compute_units, "memory_clock_khz": info.memory_clock_khz,
@@ -190,6 +204,7 @@ class GpuRunner:
         # runs on a smaller box) would hunt over each other's memory: one ring, no hunt, there.
         shared = int(os.environ.get("WORLD_SIZE", "1")) > ndev
         tries = 1 if shared else max(1, args.placement_tries)
+        self.hunt_s = 0.0
         self.rings = {}
         self.rings["first"] = self.make_ring(1)
         self.use_ring("first")
@@ -200,6 +215,7 @@ class GpuRunner:
             self.copy_ring_input("first", "hunted")
             self.use_ring("hunted")
         self.placement = self.placement_report()
+        self.lanes, self.identities, self.placements = 1, [self.identity], [self.placement]
         self.pos = 0          # 4k-batch8: ring position of the next step
         self.graph = None
         self.turn = 0
@@ -239,14 +255,21 @@ class GpuRunner:
     def make_ring(self, tries):
         g = self.g
         r = C.c_void_p()
-        self._capi.check(self.lib.bt709hip_ring_create(self.dec._handle, g["W"], g["H"], g["ring"], 1 if g["half"] else 0, tries,
-                                                       C.byref(r)), "bt709hip_ring_create")
+        t0 = time.perf_counter()
+        opt = ring_options(self._capi, self.args)
+        self._capi.check(self.lib.bt709hip_ring_create_ex(self.dec._handle, g["W"], g["H"], g["ring"], 1 if g["half"] else 0, tries,
+                                                          C.byref(opt), C.byref(r)), "bt709hip_ring_create_ex")
+        if tries > 1:
+            self.hunt_s += time.perf_counter() - t0
         return r
 
     def use_ring(self, name):
         """Frame / surface descriptors of ring `name` as the arrays the launches take."""
         g, ring = self.g, self.rings[name]
         self.ring_name = name
+        if getattr(self, "graph", None) is not None:  # a recorded graph holds the OTHER ring's pointers
+            self.lib.bt709hip_graph_destroy(self.h, self.graph[1])
+            self.graph = None
         self.frames = (self.Frame * g["ring"])()
         self.surfs = (self.Surface * g["ring"])()
         for i in range(g["ring"]):
@@ -265,43 +288,12 @@ class GpuRunner:
 
     def placement_report(self):
         """config.placement: what bt709hip_ring_create did for the ring the headline runs on (untimed set-up)."""
-        p = self.RingPlacement()
-        self._capi.check(self.lib.bt709hip_ring_placement_info(self.rings[self.ring_name], C.byref(p)))
-        free_b, total_b = C.c_size_t(), C.c_size_t()
-        self._capi.check(self.lib.bt709hip_mem_info(self.h, C.byref(free_b), C.byref(total_b)))
-        kept = [k for k in p.out_kept if k >= 0]
-        return {"allocator": "bt709hip_ring_create (csrc/bt709_ring.cpp): candidates per slab, the decoder's own launch as the probe",
-                "tries": p.tries, "candidates": [p.in_candidates, p.out_candidates], "chosen": [p.chosen_in, p.chosen_out],
-                "pairings_probed": p.probes,
-                "probe_GBps": {"first_pairing": round(p.first_GBps, 1), "chosen_confirmed": round(p.chosen_GBps, 1),
-                               "best": round(p.best_GBps, 1), "worst": round(p.worst_GBps, 1)},
-                # allocation order; `kept` = the indices (same order) that went on to the pairing probes
-                "output_prescan_GBps": [round(v, 1) for v in p.out_prescan_GBps[:p.out_candidates]], "output_kept": kept,
-                "rings_resident": sorted(self.rings), "device_memory_free_GB": round(free_b.value / 1e9, 1),
-                "device_memory_total_GB": round(total_b.value / 1e9, 1)}
+        return placement_dict(self._capi, self.lib, self.h, self.rings[self.ring_name], sorted(self.rings))
 
     def fill_ring(self, content):
         """Uploads (outside every timed region) the ring's frames: seeded PRNG bytes or smooth planes."""
-        np, g, lib, h = self.np, self.g, self.lib, self.h
-        base_smooth = None
-        for i in range(g["ring"]):
-            rng = np.random.default_rng(0x709 + i + 1000 * self.rank)
-            if content == "random":  # full byte range: exercises saturation
-                buf = rng.integers(0, 256, (1, g["y_bytes"] + g["c_bytes"]), dtype=np.uint8)
-            elif content == "flat":
-                buf = np.full((1, g["y_bytes"] + g["c_bytes"]), 128, np.uint8)
-            else:
-                if base_smooth is None:
-                    base_smooth = smooth_frame(np, rng, g, 0)
-                # one synthesised frame, shifted by a different amount per ring entry (cheap, still distinct)
-                y, c = split_planes(base_smooth, g)
-                buf = np.concatenate([np.roll(y, (2 * i, 4 * i), (0, 1)).reshape(-1),
-                                      np.roll(c, (i, 4 * i), (0, 1)).reshape(-1)]).reshape(1, -1)
-            self._capi.check(lib.bt709hip_upload(h, self.d_in.value + i * self.in_stride, buf.shape[1], buf.ctypes.data,
-                                                 buf.shape[1], buf.shape[1], 1, None), "upload")
-            self._capi.check(lib.bt709hip_stream_synchronize(h, None))
-            if i in self.sample_frames:
-                self.host_frames[i] = buf.reshape(-1)
+        self.host_frames.update(upload_frames(self.np, self._capi, self.lib, self.h, self.d_in.value, self.in_stride, self.g, content,
+                                              1000 * self.rank, self.sample_frames))
 
     def launch(self, first, n, stream=None):
         stream = stream if stream is not None else self.stream
@@ -366,7 +358,13 @@ class GpuRunner:
     def event_ms(self):
         ms = C.c_float()
         self._capi.check(self.lib.bt709hip_event_elapsed_ms(self.h, self.ev0, self.ev1, C.byref(ms)))
+        self.lane_ms = [ms.value]
         return ms.value
+
+    def spot_checks(self, gamma):
+        """[(verdict, frames checked)] per lane (this runner has one)."""
+        verdict = self.spot_check(gamma)
+        return [(verdict, getattr(self, "spot_frames", []))]
 
     def kernel_name(self):
         return self.lib.bt709hip_last_kernel_name().decode()
@@ -399,7 +397,6 @@ class GpuRunner:
         out of EACH of the 8 XCD bands of the launch (ring frames 0, 37, 70, 103, 136, 169, 202, 255 of 256: the banded map gives
         band b the frames [b F/8, (b+1) F/8), csrc/bt709_kernels.hip) -- the last rows of the last frame included -- against the
         oracle.  The ring is decoded once more first, so the bytes compared are the ones the timed launch shape writes."""
-        import oracle_lib
         np, g = self.np, self.g
         rows = 16
         self.run_steps(1)
@@ -407,25 +404,82 @@ class GpuRunner:
             for i in self.sample_frames:
                 self.launch(i - i % g["per_launch"], g["per_launch"])
         self.sync()
-        o = oracle_lib.Oracle()
-        checked = []
-        for i in self.sample_frames:
-            y, c = split_planes(self.host_frames[i], g)
-            for r0 in (0, (g["OH"] // 2) // 4 * 4, g["OH"] - rows):
-                got = np.empty((rows, g["OW"] * 4), np.uint8)
-                self._capi.check(self.lib.bt709hip_download(self.h, got.ctypes.data, got.shape[1],
-                                                            self.surfs[i].bgra + r0 * self.surfs[i].stride,
-                                                            self.surfs[i].stride, got.shape[1], rows, self.stream))
-                self.sync()
-                if g["half"]:
-                    want = o.decode_nv12_half(gamma, y[2 * r0:2 * (r0 + rows)], c[r0:r0 + rows])
-                else:
-                    want = o.decode_nv12(gamma, y, c, rows=(r0, r0 + rows))[r0:r0 + rows]
-                if not np.array_equal(got, want):
-                    return "MISMATCH in ring frame %d at output row %d" % (i, r0)
-            checked.append(i)
-        self.spot_frames = checked
-        return "ok"
+        verdict, self.spot_frames = compare_with_oracle(np, self._capi, self.lib, self.h, self.stream, g, gamma, self.sample_frames,
+                                                        self.host_frames, lambda i: (self.surfs[i].bgra, self.surfs[i].stride), rows)
+        return verdict
+
+
+def upload_frames(np, _capi, lib, ctx, d_in, in_stride, g, content, seed_offset, keep):
+    """The ring's frames into device memory at d_in + i * in_stride (blocking, untimed): seeded PRNG bytes (0x709 + i +
+    seed_offset), smooth video-like planes or flat grey.  Returns {i: host bytes} for the frames in `keep` (the spot check's)."""
+    kept, base_smooth = {}, None
+    for i in range(g["ring"]):
+        rng = np.random.default_rng(0x709 + i + seed_offset)
+        if content == "random":  # full byte range: exercises saturation
+            buf = rng.integers(0, 256, (1, g["y_bytes"] + g["c_bytes"]), dtype=np.uint8)
+        elif content == "flat":
+            buf = np.full((1, g["y_bytes"] + g["c_bytes"]), 128, np.uint8)
+        else:
+            if base_smooth is None:
+                base_smooth = smooth_frame(np, rng, g, 0)
+            # one synthesised frame, shifted by a different amount per ring entry (cheap, still distinct)
+            y, c = split_planes(base_smooth, g)
+            buf = np.concatenate([np.roll(y, (2 * i, 4 * i), (0, 1)).reshape(-1),
+                                  np.roll(c, (i, 4 * i), (0, 1)).reshape(-1)]).reshape(1, -1)
+        _capi.check(lib.bt709hip_upload(ctx, d_in + i * in_stride, buf.shape[1], buf.ctypes.data, buf.shape[1], buf.shape[1], 1, None), "upload")
+        _capi.check(lib.bt709hip_stream_synchronize(ctx, None))
+        if i in keep:
+            kept[i] = buf.reshape(-1)
+    return kept
+
+
+def compare_with_oracle(np, _capi, lib, ctx, stream, g, gamma, picks, host_frames, surface_of, rows=16):
+    """`rows` output rows at the top, middle and bottom of every picked ring frame, downloaded and byte-compared with the CPU
+    oracle's decode of the frame's host bytes.  -> ("ok" | "MISMATCH ...", frames checked).  Checker code: untimed."""
+    import oracle_lib
+    o = oracle_lib.Oracle()
+    checked = []
+    for i in picks:
+        y, c = split_planes(host_frames[i], g)
+        ptr, stride = surface_of(i)
+        for r0 in (0, (g["OH"] // 2) // 4 * 4, g["OH"] - rows):
+            got = np.empty((rows, g["OW"] * 4), np.uint8)
+            _capi.check(lib.bt709hip_download(ctx, got.ctypes.data, got.shape[1], ptr + r0 * stride, stride, got.shape[1], rows, stream))
+            _capi.check(lib.bt709hip_stream_synchronize(ctx, stream))
+            if g["half"]:
+                want = o.decode_nv12_half(gamma, y[2 * r0:2 * (r0 + rows)], c[r0:r0 + rows])
+            else:
+                want = o.decode_nv12(gamma, y, c, rows=(r0, r0 + rows))[r0:r0 + rows]
+            if not np.array_equal(got, want):
+                return "MISMATCH in ring frame %d at output row %d" % (i, r0), checked
+        checked.append(i)
+    return "ok", checked
+
+
+def ring_options(_capi, args):
+    return _capi.RingOptions(int(args.hunt_max_gb * 1e9), int(args.hunt_max_ms), int(bool(args.hunt_frugal)))
+
+
+def placement_dict(_capi, lib, ctx, ring, rings_resident):
+    """What bt709hip_ring_create[_ex] did for `ring` (untimed set-up): candidates, probes, the choice, what the hunt cost."""
+    p = _capi.RingPlacement()
+    _capi.check(lib.bt709hip_ring_placement_info(ring, C.byref(p)))
+    free_b, total_b = C.c_size_t(), C.c_size_t()
+    _capi.check(lib.bt709hip_mem_info(ctx, C.byref(free_b), C.byref(total_b)))
+    kept = [k for k in p.out_kept if k >= 0]
+    return {"allocator": "bt709hip_ring_create_ex (csrc/bt709_ring.cpp): candidates per slab under a byte / time budget, the decoder's own launch as the probe",
+            "tries": p.tries, "candidates": [p.in_candidates, p.out_candidates], "chosen": [p.chosen_in, p.chosen_out],
+            "pairings_probed": p.probes,
+            "probe_GBps": {"first_pairing": round(p.first_GBps, 1), "chosen_confirmed": round(p.chosen_GBps, 1),
+                           "best": round(p.best_GBps, 1), "worst": round(p.worst_GBps, 1)},
+            # allocation order; `kept` = the indices (same order) that went on to the pairing probes
+            "output_prescan_GBps": [round(v, 1) for v in p.out_prescan_GBps[:p.out_candidates]], "output_kept": kept,
+            # the hunt's cost: duration, the most device memory it held at once (ring included), its budget, slabs freed early to
+            # stay inside it, and what ended it (0 ran to its end, 1 the byte budget cut candidates, 2 the time budget)
+            "hunt_ms": round(p.hunt_ms, 1), "peak_bytes": int(p.peak_bytes), "budget_bytes": int(p.budget_bytes),
+            "evicted": p.evicted, "stopped_by": p.stopped_by,
+            "rings_resident": rings_resident, "device_memory_free_GB": round(free_b.value / 1e9, 1),
+            "device_memory_total_GB": round(total_b.value / 1e9, 1)}
 
 
 def sample_frames(ring):
@@ -439,15 +493,145 @@ def sample_frames(ring):
     return sorted(picks)
 
 
-class DryRunner:
-    """CPU stand-in used only by --dry-run (tests of the N>1 control flow)."""
-    device, arch, props, host_frames = "dry-run", "none", {}, {}
+class SetRunner:
+    """--launcher threads: ONE process driving `lanes` GPUs through bt709hip_ringset_* -- a context, a decoder and a ring (placed
+    by its own hunt) per device, one ring launch per device per step issued from this one thread, no thread per device and no
+    collective.  The reference's shape (one process that drives everything, Renderer/AAPLRenderer.m:874-985) widened to a node.
+    Same interface as GpuRunner; clocks, identity, placement and parity check exist per lane."""
 
-    def __init__(self):
-        self.t = [0.0, 0.0]
+    def __init__(self, args, g, lanes, ndev):
+        import numpy as np
+        import metalbt709decoder_amd as mb
+        from metalbt709decoder_amd import _capi
+        self.np, self._capi, self.g, self.args, self.lanes = np, _capi, g, args, lanes
+        if g["batch8"] or args.graph or args.coalesce or args.streams:
+            sys.exit("--launcher threads runs the whole-ring workloads (4k, 1080p, 8k-half) only")
+        if args.library:
+            _capi.load(os.path.abspath(args.library))
+        lib = self.lib = mb.load_library()
+        ordinals = [lane % ndev for lane in range(lanes)]  # beyond the device count only with --allow-shared-devices
+        shared = lanes > ndev
+        tries = 1 if shared else max(1, args.placement_tries)
+        opt = ring_options(_capi, args)
+        h = C.c_void_p()
+        t0 = time.perf_counter()
+        _capi.check(lib.bt709hip_ringset_create((C.c_int * lanes)(*ordinals), lanes, GAMMAS[args.gamma], 0, g["W"], g["H"], g["ring"],
+                                                1 if g["half"] else 0, tries, C.byref(opt), C.byref(h)), "bt709hip_ringset_create")
+        self.hunt_s = time.perf_counter() - t0
+        self.set = h
+        self.ctxs = [lib.bt709hip_ringset_lane_context(h, lane) for lane in range(lanes)]
+        self.decs = [lib.bt709hip_ringset_lane_decoder(h, lane) for lane in range(lanes)]
+        self.rings = [lib.bt709hip_ringset_lane_ring(h, lane) for lane in range(lanes)]
+        self.sample_frames = sample_frames(g["ring"])
+        self.identities, self.placements, self.surfs, self.events, self.scratch, self.host_frames_by_lane = [], [], [], [], [], []
+        for lane in range(lanes):
+            ctx = self.ctxs[lane]
+            for kv in args.decoder_option:
+                k, v = kv.split("=")
+                _capi.check(lib.bt709hip_decoder_set_option(self.decs[lane], int(k), int(v)), "decoder option")
+            info = _capi.DeviceInfo()
+            _capi.check(lib.bt709hip_context_info(ctx, C.byref(info)))
+            self.identities.append({"rank": lane, "ordinal": info.device_ordinal, "pci_bus_id": info.pci_bus_id.decode(), "uuid": info.uuid.decode()})
+            if lane == 0:
+                self.arch = info.arch.decode()
+                self.device = info.name.decode() or self.arch
+                self.props = {"compute_units": info.compute_units, "memory_clock_khz": info.memory_clock_khz,
+                              "memory_bus_width_bits": info.memory_bus_width_bits, "clock_khz": info.clock_khz}
+            self.placements.append(placement_dict(_capi, lib, ctx, self.rings[lane], ["ring set lane %d" % lane]))
+            f0, f1, surfs = _capi.Frame(), _capi.Frame(), (_capi.Surface * g["ring"])()
+            _capi.check(lib.bt709hip_ring_frame(self.rings[lane], 0, C.byref(f0), None, None))
+            in_stride = g["y_bytes"] + g["c_bytes"]
+            if g["ring"] > 1:
+                _capi.check(lib.bt709hip_ring_frame(self.rings[lane], 1, C.byref(f1), None, None))
+                in_stride = f1.y - f0.y
+            for i in range(g["ring"]):
+                _capi.check(lib.bt709hip_ring_frame(self.rings[lane], i, None, None, C.byref(surfs[i])))
+            self.surfs.append(surfs)
+            # every lane's ring holds frames of its own (seed 0x709 + i + 1000 lane): a lane that decoded another lane's
+            # frames, or none, cannot pass its spot check
+            self.host_frames_by_lane.append(upload_frames(np, _capi, lib, ctx, f0.y, in_stride, g, args.content, 1000 * lane, self.sample_frames))
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            _capi.check(lib.bt709hip_event_create(ctx, C.byref(e0)))
+            _capi.check(lib.bt709hip_event_create(ctx, C.byref(e1)))
+            self.events.append((e0, e1))
+            sc = C.c_void_p()
+            _capi.check(lib.bt709hip_malloc(ctx, 128 << 10, C.byref(sc)))
+            self.scratch.append(sc)
+        self.placement, self.identity = self.placements[0], self.identities[0]
+        self.host_frames = self.host_frames_by_lane[0]
+        self.nstreams, self.lane_ms = 1, [0.0] * lanes
+        t_end = time.perf_counter() + float(os.environ.get("BT709_BENCH_PREWARM_S", "0.4"))
+        while time.perf_counter() < t_end:
+            self.run_steps(1)
+            self.sync()
 
     def run_steps(self, k):
-        time.sleep(0.002 * k)
+        for _ in range(k):  # one launch per lane per step, every lane's enqueued before the next step's
+            rc = self.lib.bt709hip_ringset_decode(self.set, 0, self.g["ring"], 0)
+            if rc != 0:
+                raise self._capi.Bt709Error(rc, "ringset decode")
+
+    def sync(self):
+        self._capi.check(self.lib.bt709hip_ringset_synchronize(self.set), "ringset synchronize")
+
+    def mark(self, which):
+        for ctx, ev in zip(self.ctxs, self.events):
+            self._capi.check(self.lib.bt709hip_event_record(ctx, ev[which], None))
+
+    def event_ms(self):
+        ms = C.c_float()
+        for lane, (ctx, ev) in enumerate(zip(self.ctxs, self.events)):
+            self._capi.check(self.lib.bt709hip_event_elapsed_ms(ctx, ev[0], ev[1], C.byref(ms)))
+            self.lane_ms[lane] = ms.value
+        return max(self.lane_ms)
+
+    def kernel_name(self):
+        return self.lib.bt709hip_last_kernel_name().decode()
+
+    def sentinel(self, closing):
+        for ctx, sc in zip(self.ctxs, self.scratch):
+            self._capi.check(self.lib.bt709hip_copy_probe(ctx, sc.value + (64 << 10), sc.value, (32 << 10) if closing else (4 << 10), None), "sentinel")
+
+    def spot_checks(self, gamma):
+        self.run_steps(1)
+        self.sync()
+        out = []
+        for lane in range(self.lanes):
+            surfs = self.surfs[lane]
+            out.append(compare_with_oracle(self.np, self._capi, self.lib, self.ctxs[lane], None, self.g, gamma, self.sample_frames,
+                                           self.host_frames_by_lane[lane], lambda i, s=surfs: (s[i].bgra, s[i].stride)))
+        return out
+
+
+class DryRunner:
+    """CPU stand-in used only by --dry-run (tests of the N>1 control flow).  BT709_BENCH_DRY_DEVICES = how many (fake) GPUs the
+    box has (default: one per rank); BT709_BENCH_DRY_MISMATCH_RANK = the rank whose parity spot check reports a mismatch;
+    BT709_BENCH_DRY_SLOW_RANK = a rank that takes 1.5 x as long per step (a straggler)."""
+    device, arch, props, host_frames = "dry-run", "none", {}, {}
+
+    def __init__(self, rank=0, local_rank=0, world=1, lanes=1):
+        """lanes > 1: the --launcher threads shape (one process, `lanes` devices); unit u = rank * lanes + lane."""
+        self.t = [0.0, 0.0]
+        self.rank, self.lanes = rank, lanes
+        ndev = dry_device_count(world * lanes)
+        units = [local_rank * lanes + lane for lane in range(lanes)]
+        self.identities = [{"rank": rank * lanes + lane, "ordinal": u % ndev, "pci_bus_id": "0000:%02x:00.0" % (u % ndev), "uuid": "dry-%d" % (u % ndev)}
+                           for lane, u in enumerate(units)]
+        self.identity = self.identities[0]
+        self.placement = {"chosen": [0, 0], "probe_GBps": {"first_pairing": 0.0, "chosen_confirmed": 0.0}}
+        self.placements = [self.placement] * lanes
+        slow = os.environ.get("BT709_BENCH_DRY_SLOW_RANK")
+        self.lane_factor = [1.5 if slow == str(i["rank"]) else 1.0 for i in self.identities]
+        self.step_s = 0.002 * max(self.lane_factor)
+        self.spot_frames = []
+
+    def spot_checks(self, gamma):
+        bad = os.environ.get("BT709_BENCH_DRY_MISMATCH_RANK")
+        return [("MISMATCH in ring frame 0 at output row 0 (forced: BT709_BENCH_DRY_MISMATCH_RANK)" if bad == str(i["rank"]) else "ok", [])
+                for i in self.identities]
+
+    def run_steps(self, k):
+        time.sleep(self.step_s * k)
 
     def sync(self):
         pass
@@ -456,13 +640,30 @@ class DryRunner:
         self.t[which] = time.perf_counter()
 
     def event_ms(self):
-        return (self.t[1] - self.t[0]) * 1e3
+        ms = (self.t[1] - self.t[0]) * 1e3
+        self.lane_ms = [ms * f / max(self.lane_factor) for f in self.lane_factor]
+        return ms
 
     def kernel_name(self):
         return "dry-run"
 
     def sentinel(self, closing):
         pass
+
+
+def dry_device_count(world):
+    return max(1, int(os.environ.get("BT709_BENCH_DRY_DEVICES", str(world))))
+
+
+def visible_devices(args, world):
+    """GPUs this box shows (no device is initialised by the count); --dry-run: BT709_BENCH_DRY_DEVICES."""
+    if args.dry_run:
+        return dry_device_count(world)
+    import metalbt709decoder_amd as mb
+    from metalbt709decoder_amd import _capi
+    if args.library:
+        _capi.load(os.path.abspath(args.library))
+    return mb.load_library().bt709hip_device_count()
 
 
 def self_launch(n, argv, timeout_s=None):
@@ -578,13 +779,17 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    lanes = 1  # devices THIS process drives: > 1 only with --launcher threads
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.launcher == "threads":
+        lanes = args.gpus  # ONE process, N GPUs (bt709hip_ringset_*): no ranks are started
+    elif "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python3 bench.py --gpus N`: this process becomes the launcher of N ranks and never touches a GPU
         # a rank that hangs (a wedged GPU) must not hang the launcher for ever: one hour covers any run of this script
         sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv),
                              timeout_s=float(os.environ.get("BT709_BENCH_LAUNCH_TIMEOUT_S", "3600"))))
-    if world != args.gpus:
+    if world != args.gpus and lanes == 1:
         args.gpus = world  # under torch.distributed.run the launcher's world size is authoritative
+    units = world * lanes  # GPUs the whole job asks for
 
     dist = None
     if world > 1:
@@ -606,15 +811,41 @@ def main(argv=None):
             os.dup2(saved, 1)
             os.close(saved)
 
-    g = geometry(args.workload, args.ring, 65535, args.frames_per_launch, world, args.share)
+    g = geometry(args.workload, args.ring, 65535, args.frames_per_launch, units, args.share)
     if g["ring_input_over_cache"] < 2.0 and not args.dry_run:
         sys.exit("--ring %d: the ring's input (%.0f MB) must be at least twice the 256 MB Infinity Cache, or the run measures the cache"
                  % (g["ring"], g["ring_input_over_cache"] * 256))
-    runner = DryRunner() if args.dry_run else GpuRunner(args, g, rank, local_rank)
+    # One rank per GPU is the contract.  Ranks that wrap onto fewer devices measure something else (several processes
+    # sharing one GPU): refused before anything is allocated unless the caller asks for exactly that.
+    ndev = visible_devices(args, units)
+    if units > max(ndev, 0) and ndev > 0 and not args.allow_shared_devices:
+        if rank == 0:
+            sys.stderr.write("bench.py: %d ranks but %d visible GPU(s): one rank per GPU is the contract; pass --allow-shared-devices "
+                             "for a functional run of the N > 1 path on a smaller box (the line is then labelled shared_devices)\n" % (units, ndev))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(2)
+    if args.dry_run:
+        runner = DryRunner(rank, local_rank, world, lanes)
+    elif lanes > 1:
+        if ndev <= 0:
+            sys.exit("no HIP device: the product has no CPU fallback")
+        runner = SetRunner(args, g, lanes, ndev)
+    else:
+        runner = GpuRunner(args, g, rank, local_rank)
 
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    def gather(obj):
+        """Every rank's `obj`, in rank order, on every rank (control plane: gloo, pickled CPU objects)."""
+        if dist is None:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
 
     def max_over_ranks(values):
         if dist is None:
@@ -634,7 +865,13 @@ def main(argv=None):
     # asks for >= 100 ms per timing), so the figure that is reported as `value` comes from regions of m * K steps,
     # m the smallest integer that makes a region >= 100 ms (every rank must agree: MAX over ranks), bracketed the
     # same way; `ms_per_step` = median region / (m * K).
-    first = max_over_ranks(list(timed_region(runner, args.steps, barrier, headline=True)))
+    own = []  # this process's own (host seconds, [event ms per lane]) of every region that counts: per_rank below
+
+    def region(steps):
+        mine = list(timed_region(runner, steps, barrier, headline=True))
+        own.append((steps, mine[0], list(runner.lane_ms)))
+        return max_over_ranks(mine)
+    first = region(args.steps)
     stretch = int(max(1, min(4096, -(-0.100 // max(first[0], 1e-6)))))
     stretch = int(max_over_ranks([float(stretch)])[0])
     region_steps = args.steps * stretch
@@ -644,22 +881,50 @@ def main(argv=None):
         repeats = int(max(5, min(40, -(-0.150 // (first[0] * stretch)))))
         repeats = int(max_over_ranks([float(repeats)])[0])
     while len(samples) < repeats:
-        samples.append(max_over_ranks(list(timed_region(runner, region_steps, barrier, headline=True))))
+        samples.append(region(region_steps))
     samples.sort()
     elapsed, ev_ms = samples[len(samples) // 2]  # the median region (by host time) and ITS event time
     fastest, slowest = samples[0][0], samples[-1][0]
 
     # whole job per step: every rank decodes frames_per_step frames (4k-batch8: the ranks' shares add up to 8)
-    out_px_per_step = world * g["frames_per_step"] * g["OW"] * g["OH"]
+    out_px_per_step = units * g["frames_per_step"] * g["OW"] * g["OH"]
     to_value = lambda seconds: region_steps * out_px_per_step / seconds / 1e9
     bytes_per_launch = g["bytes_per_frame"] * g["per_launch"]
     avg_launch_s = (ev_ms / 1e3) / (region_steps * g["launches"])
     achieved = bytes_per_launch / avg_launch_s / 1e9
     read_gbps = (g["W"] * g["H"] * 3 // 2) * g["per_launch"] / avg_launch_s / 1e9
 
+    # Which devices ran, and how each of them did: the line's `value` is the whole job over the SLOWEST unit (MAX over ranks and
+    # lanes), so a straggler GPU -- every ring has a placement of its own -- must be tellable from a launcher problem.  One record
+    # per rank (--launcher threads: per lane of the one process): its own median region (same regions as the headline's, its own
+    # clocks), its device and its ring's placement.
+    mine = sorted((host_s, lane_ms) for steps, host_s, lane_ms in own if steps == region_steps)
+    my_host_s, my_lane_ms = mine[len(mine) // 2]
+    # Parity tripwire on EVERY unit, each over its OWN ring (the frames differ: seed 0x709 + i + 1000 unit); a mismatch on any of
+    # them nulls `value` and fails the whole job.  Untimed.
+    checks = runner.spot_checks(GAMMAS[args.gamma])
+    my_records = []
+    for lane in range(lanes):
+        launch_s = (my_lane_ms[lane] / 1e3) / (region_steps * g["launches"])
+        pl = runner.placements[lane] or {}
+        ident = dict(runner.identities[lane])
+        ident["rank"] = rank * lanes + lane
+        my_records.append(dict(ident,
+                               # a process's host clock per step; the lanes of one process share it, their own GPU-side time is avg_launch_us
+                               ms_per_step=round((my_host_s if lanes == 1 else my_lane_ms[lane] / 1e3) / region_steps * 1e3, 5),
+                               avg_launch_us=round(launch_s * 1e6, 3), frac=round(bytes_per_launch / launch_s / 1e9 / HBM_PEAK_GBPS, 4),
+                               placement={"chosen": pl.get("chosen"), "first_GBps": (pl.get("probe_GBps") or {}).get("first_pairing"),
+                                          "chosen_GBps": (pl.get("probe_GBps") or {}).get("chosen_confirmed"),
+                                          "hunt_ms": pl.get("hunt_ms"), "peak_bytes": pl.get("peak_bytes")},
+                               parity_spot_check=checks[lane][0], parity_spot_frames=checks[lane][1]))
+    per_rank = [r for records in gather(my_records) for r in records]
+    failed = any(r["parity_spot_check"] != "ok" for r in per_rank)
+    devices = sorted({(r["pci_bus_id"], r["uuid"]) for r in per_rank})
+    n_distinct = len(devices)
+
     if g["batch8"]:
         step_text = ("one step = %d x 4K frames over the whole job = ONE launch of %d frame(s) per GPU, frame i -> "
-                     "GPU i mod %d, walking the ring%s" % (world * g["per_launch"], g["per_launch"], world,
+                     "GPU i mod %d, walking the ring%s" % (units * g["per_launch"], g["per_launch"], units,
                                                             "; K steps replayed from one HIP graph" if args.graph else ""))
     else:
         step_text = "one step = the whole ring = %d launches x %d frames" % (g["launches"], g["per_launch"])
@@ -667,7 +932,9 @@ def main(argv=None):
         "metric": "Gpixel/s, %s NV12->sRGB BGRA decode (output pixels)" % args.workload,
         "value": round(to_value(elapsed), 3),
         "unit": "Gpixel/s",
-        "n_gpus": world,
+        "n_gpus": n_distinct,  # DISTINCT physical devices (by PCI bus id); == ranks unless shared_devices
+        "ranks": units,  # processes x the devices each drives (--launcher threads: 1 x N)
+        "shared_devices": n_distinct < units,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / region_steps * 1e3, 5),
@@ -692,11 +959,15 @@ def main(argv=None):
             "coalesce": args.coalesce,
             "sharding": "independent frames per GPU, no collective",
             "launcher": ("self (bench.py started its %d ranks)" % world if os.environ.get("BT709_BENCH_SELF_LAUNCHED")
-                         else "torch.distributed.run" if world > 1 else "single process"),
-            "placement": getattr(runner, "placement", None),  # ring allocated `tries` times, the fastest-streaming one kept (untimed set-up)
+                         else "torch.distributed.run" if world > 1
+                         else "threads (ONE process drives %d GPUs through bt709hip_ringset_*: one launch per device per step from one thread)" % lanes
+                         if lanes > 1 else "single process"),
+            "placement": getattr(runner, "placement", None),  # rank 0's ring: allocated `tries` times, the fastest-streaming pairing kept (untimed set-up)
             "device": runner.device,
             "arch": runner.arch,
             "device_props": runner.props,
+            # one record per rank, rank order: which physical device it drove
+            "devices": [{"rank": r["rank"], "ordinal": r["ordinal"], "pci_bus_id": r["pci_bus_id"], "uuid": r["uuid"]} for r in per_rank],
         },
         "roofline": {
             "bound": "hbm",
@@ -709,26 +980,27 @@ def main(argv=None):
             "avg_launch_us": round(avg_launch_s * 1e6, 3),
             "read_GBps": round(read_gbps, 1),
         },
+        # every rank's own clocks over the headline's regions (value comes from the MAX over ranks), device, placement, spot check
+        "per_rank": [{k: r[k] for k in ("rank", "ordinal", "pci_bus_id", "ms_per_step", "avg_launch_us", "frac", "placement",
+                                        "parity_spot_check")} for r in per_rank],
+        "parity_spot_check": "ok" if not failed else "; ".join("rank %d: %s" % (r["rank"], r["parity_spot_check"]) for r in per_rank
+                                                                if r["parity_spot_check"] != "ok"),
+        "parity_spot_check_ranks": len(per_rank),  # every rank checks its own ring
+        "parity_spot_frames": per_rank[0]["parity_spot_frames"],  # one ring frame per XCD band, 48 rows each; the same picks on every rank
     }
     result["roofline"].update(load_traffic(args.workload, g))
 
-    failed = False
-    if rank == 0 and not args.dry_run:
-        # parity tripwire on every run (rank 0 of a multi-GPU job too); a mismatch fails the run
-        result["parity_spot_check"] = runner.spot_check(GAMMAS[args.gamma])
-        failed = result["parity_spot_check"] != "ok"
-        result["parity_spot_frames"] = getattr(runner, "spot_frames", [])  # one ring frame per XCD band, 48 rows each
-        if world == 1:
-            result["roofline"].update(first_allocation_leg(runner, args, g, barrier, region_steps, achieved))
-            if args.workload in ("4k", "8k-half") and args.content == "random" and not args.no_smooth_leg:
-                result["roofline"]["smooth_content"] = smooth_leg(runner, args, g, barrier, region_steps)
-            copy_gbps = runner.copy_ceiling()
-            result["roofline"]["same_run_copy_GBps"] = round(copy_gbps, 1)
-            result["roofline"]["frac_of_same_run_copy"] = round(achieved / copy_gbps, 4)
-            if not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline(runner.host_frames[0], g, GAMMAS[args.gamma], args.cpu_seconds)
-        if failed:
-            result["value"] = None  # a wrong-output kernel yields no benchmark record
+    if rank == 0 and not args.dry_run and not failed and units == 1:
+        result["roofline"].update(first_allocation_leg(runner, args, g, barrier, region_steps, achieved))
+        if args.workload in ("4k", "8k-half") and args.content == "random" and not args.no_smooth_leg:
+            result["roofline"]["smooth_content"] = smooth_leg(runner, args, g, barrier, region_steps)
+        copy_gbps = runner.copy_ceiling()
+        result["roofline"]["same_run_copy_GBps"] = round(copy_gbps, 1)
+        result["roofline"]["frac_of_same_run_copy"] = round(achieved / copy_gbps, 4)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(runner.host_frames[0], g, GAMMAS[args.gamma], args.cpu_seconds)
+    if failed:
+        result["value"] = None  # a wrong-output kernel on ANY rank yields no benchmark record
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -491,9 +491,12 @@ class InFlightFramePool {
 // CVPixelBuffers + render texture (Renderer/AAPLRenderer.m:34, 530-862).
 class FrameRing {
  public:
-  FrameRing(MetalBT709Decoder &decoder, int width, int height, int frames, bool halfScale = false, int tries = 0)
+  // options: the hunt's budget (bt709hip_ring_options; nullptr = half of the free device memory, no time limit)
+  FrameRing(MetalBT709Decoder &decoder, int width, int height, int frames, bool halfScale = false, int tries = 0,
+            const bt709hip_ring_options *options = nullptr)
       : decoder_(decoder) {
-    if (decoder.setupMetal()) lastStatus_ = bt709hip_ring_create(decoder.handle(), width, height, frames, halfScale ? 1 : 0, tries, &ring_);
+    if (decoder.setupMetal())
+      lastStatus_ = bt709hip_ring_create_ex(decoder.handle(), width, height, frames, halfScale ? 1 : 0, tries, options, &ring_);
     else lastStatus_ = decoder.lastStatus();
   }
   ~FrameRing() { bt709hip_ring_destroy(ring_); }
@@ -557,6 +560,66 @@ class FrameRing {
  private:
   MetalBT709Decoder &decoder_;
   bt709hip_ring *ring_ = nullptr;
+  int lastStatus_ = BT709HIP_OK;
+};
+
+// ONE process, several GPUs, frames resident in DEVICE memory (bt709hip_ringset_*, round 5): a ring per lane, each with a
+// context and a decoder of its own on devices[lane], all driven by the calling thread -- decode() issues one ring launch per
+// lane and returns; the devices run concurrently.  The reference's shape: one process that drives everything
+// (Renderer/AAPLRenderer.m:874-985).  Host frames: FrameSharder below.
+class FrameRingSet {
+ public:
+  FrameRingSet(const std::vector<int> &devices, int width, int height, int frames, MetalBT709Gamma gamma = MetalBT709GammaApple,
+               bool hasAlphaChannel = false, bool halfScale = false, int tries = 0, const bt709hip_ring_options *options = nullptr) {
+    lastStatus_ = bt709hip_ringset_create(devices.data(), static_cast<int>(devices.size()), gamma, hasAlphaChannel ? 1 : 0, width,
+                                          height, frames, halfScale ? 1 : 0, tries, options, &set_);
+  }
+  ~FrameRingSet() { bt709hip_ringset_destroy(set_); }
+  FrameRingSet(const FrameRingSet &) = delete;
+  FrameRingSet &operator=(const FrameRingSet &) = delete;
+  bool valid() const { return set_ != nullptr; }
+  int lastStatus() const { return lastStatus_; }
+  int lanes() const { return bt709hip_ringset_lanes(set_); }
+  bt709hip_context *laneContext(int lane) { return bt709hip_ringset_lane_context(set_, lane); }
+  bt709hip_decoder *laneDecoder(int lane) { return bt709hip_ringset_lane_decoder(set_, lane); }
+  bt709hip_ring *laneRing(int lane) { return bt709hip_ringset_lane_ring(set_, lane); }
+  // which physical device a lane sits on (ordinal + PCI bus id)
+  bt709hip_device_info laneDevice(int lane) {
+    bt709hip_device_info info{};
+    lastStatus_ = bt709hip_context_info(laneContext(lane), &info);
+    return info;
+  }
+  // tight host planes -> frame i of lane's ring (blocking)
+  bool upload(int lane, int i, const uint8_t *y, const uint8_t *cbcr) {
+    bt709hip_frame f{};
+    if ((lastStatus_ = bt709hip_ring_frame(laneRing(lane), i, &f, nullptr, nullptr)) != BT709HIP_OK) return false;
+    bt709hip_context *ctx = laneContext(lane);
+    const size_t w = static_cast<size_t>(f.width), h = static_cast<size_t>(f.height);
+    lastStatus_ = bt709hip_upload(ctx, const_cast<void *>(f.y), f.y_stride, y, w, w, h, nullptr);
+    if (lastStatus_ == BT709HIP_OK) lastStatus_ = bt709hip_upload(ctx, const_cast<void *>(f.cbcr), f.cbcr_stride, cbcr, w, w, h / 2, nullptr);
+    if (lastStatus_ == BT709HIP_OK) lastStatus_ = bt709hip_stream_synchronize(ctx, nullptr);
+    return lastStatus_ == BT709HIP_OK;
+  }
+  // frames [first, first + count) of EVERY lane: one launch per lane, all enqueued before any is waited for
+  bool decode(int first, int count, bool waitUntilCompleted) {
+    return (lastStatus_ = bt709hip_ringset_decode(set_, first, count, waitUntilCompleted ? 1 : 0)) == BT709HIP_OK;
+  }
+  bool synchronize() { return (lastStatus_ = bt709hip_ringset_synchronize(set_)) == BT709HIP_OK; }
+  // (A<<24)|(R<<16)|(G<<8)|B words of output frame i of lane's ring
+  std::vector<uint32_t> pixels(int lane, int i) {
+    bt709hip_surface o{};
+    std::vector<uint32_t> px;
+    if ((lastStatus_ = bt709hip_ring_frame(laneRing(lane), i, nullptr, nullptr, &o)) != BT709HIP_OK) return px;
+    px.resize(static_cast<size_t>(o.width) * o.height);
+    bt709hip_context *ctx = laneContext(lane);
+    const size_t row = static_cast<size_t>(o.width) * 4;
+    lastStatus_ = bt709hip_download(ctx, px.data(), row, o.bgra, o.stride, row, o.height, nullptr);
+    if (lastStatus_ == BT709HIP_OK) lastStatus_ = bt709hip_stream_synchronize(ctx, nullptr);
+    return px;
+  }
+
+ private:
+  bt709hip_ringset *set_ = nullptr;
   int lastStatus_ = BT709HIP_OK;
 };
 

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "MetalBT709Decoder.hpp"
 
@@ -203,7 +205,64 @@ static int run_ring_vectors(MetalBT709Decoder &metalDecoder, int argc, char **ar
   return failures ? 1 : 0;
 }
 
+// --devices all | N: every vector is one 8 x 4 frame; a FrameRingSet (bt709hip_ringset_*: ONE process, a ring per device) over every
+// visible device -- or over N lanes, wrapping onto the visible devices -- decodes all of them on every lane with one launch per
+// lane, and every lane's frames are read back and compared.  Lane l's ring holds the vectors rotated by l, so a lane that
+// served another lane's pixels cannot pass.  With one GPU visible this is one lane on device 0; on an 8-GPU node it is eight.
+static int run_ringset_vectors(const char *devices_arg, int argc, char **argv) {
+  const int n = (argc - 1) / 6, width = 8, height = 4;
+  if (n < 1) return 2;
+  const int visible = bt709hip_device_count();
+  if (visible <= 0) return 3;
+  const int lanes = std::strcmp(devices_arg, "all") == 0 ? visible : std::atoi(devices_arg);
+  if (lanes < 1 || lanes > 64) return 2;
+  std::vector<int> devices;
+  for (int l = 0; l < lanes; ++l) devices.push_back(l % visible);
+  FrameRingSet set(devices, width, height, n, MetalBT709GammaApple, false, false, 1);
+  if (!set.valid() || set.lanes() != lanes) return 3;
+  int failures = 0;
+  std::vector<std::string> seen;
+  for (int l = 0; l < lanes; ++l) {
+    const bt709hip_device_info info = set.laneDevice(l);
+    if (info.device_ordinal != devices[static_cast<size_t>(l)]) ++failures;
+    if (l < visible) {  // the first `visible` lanes sit on DISTINCT physical devices
+      for (const std::string &s : seen)
+        if (s == info.pci_bus_id) ++failures;
+      seen.push_back(info.pci_bus_id);
+    }
+    std::printf("lane %d: device %d, pci %s, uuid %s\n", l, info.device_ordinal, info.pci_bus_id, info.uuid);
+  }
+  std::vector<uint32_t> want(static_cast<size_t>(n));
+  for (int l = 0; l < lanes; ++l)
+    for (int v = 0; v < n; ++v) {
+      const int i = 1 + 6 * ((v + l) % n);  // lane l holds vector (v + l) mod n in frame v
+      std::vector<uint8_t> y(static_cast<size_t>(width) * height, static_cast<uint8_t>(std::atoi(argv[i])));
+      std::vector<uint8_t> c(static_cast<size_t>(width) * height / 2);
+      for (size_t k = 0; k < c.size(); k += 2) c[k] = static_cast<uint8_t>(std::atoi(argv[i + 1])), c[k + 1] = static_cast<uint8_t>(std::atoi(argv[i + 2]));
+      if (!set.upload(l, v, y.data(), c.data())) return 3;
+    }
+  if (!set.decode(0, n, false) || !set.synchronize()) return 3;
+  for (int l = 0; l < lanes; ++l)
+    for (int v = 0; v < n; ++v) {
+      const int i = 1 + 6 * ((v + l) % n);
+      const uint32_t w = 0xFF000000u | (static_cast<uint32_t>(std::atoi(argv[i + 3])) << 16) | (static_cast<uint32_t>(std::atoi(argv[i + 4])) << 8) |
+                         static_cast<uint32_t>(std::atoi(argv[i + 5]));
+      for (uint32_t px : set.pixels(l, v))
+        if (px != w) {
+          std::fprintf(stderr, "lane %d, frame %d: got %08x, want %08x\n", l, v, px, w);
+          ++failures;
+          break;
+        }
+    }
+  std::printf("%s: %d lanes on %d visible device(s), %d ring frames each, %d failures\n", failures ? "FAIL" : "ok", lanes, visible, n, failures);
+  return failures ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 2 && std::strcmp(argv[1], "--devices") == 0) {
+    if ((argc - 3) < 6 || (argc - 3) % 6 != 0) return 2;
+    return run_ringset_vectors(argv[2], argc - 2, argv + 2);
+  }
   if (argc > 1 && std::strcmp(argv[1], "--two-pass") == 0) {
     MetalRenderContext ctx;
     MetalBT709Decoder dec;

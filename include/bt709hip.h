@@ -41,7 +41,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout or a signature in this file changes.  Bindings compare
  * it with bt709hip_abi_version() so that a library older than the header is refused, not mis-called. */
-#define BT709HIP_VERSION 400
+#define BT709HIP_VERSION 500
 
 typedef struct bt709hip_context bt709hip_context; /* ~ MetalRenderContext */
 typedef struct bt709hip_decoder bt709hip_decoder; /* ~ MetalBT709Decoder  */
@@ -138,6 +138,12 @@ typedef struct {
   uint64_t total_memory_bytes;
   char name[128];
   char arch[64];
+  /* Which physical device this is, for callers that must prove N contexts sit on N GPUs (bench.py's per-rank records; device
+   * ordinals are per process and say nothing once HIP_VISIBLE_DEVICES differs between ranks): hipDeviceGetPCIBusId
+   * ("0000:c1:00.0") and the 16 bytes of hipDeviceGetUuid as 32 hex digits.  MTLDevice has registryID for this
+   * (the reference keeps one device, Renderer/MetalRenderContext.m:59-63, and never needs it). */
+  char pci_bus_id[32];
+  char uuid[40];
 } bt709hip_device_info;
 
 #define BT709HIP_MAX_BATCH 32
@@ -240,7 +246,8 @@ typedef enum {
   BT709HIP_OPT_HALF_WORKGROUPS = 3,  /* persistent 2:1 kernel: workgroups; 0 (default) = one per compute unit */
   BT709HIP_OPT_HALF_LDS_KB = 4,      /* persistent 2:1 kernel: KiB of LDS a workgroup may fill with table copies; 0 (default) = 160 */
   BT709HIP_OPT_XCD_BANDS = 5,        /* 1 (default): batched 1:1 launches of 64 frames or more give each XCD a contiguous band of the frames (a count that is not a multiple of 8: that map over the multiple of 8, the plain map over the rest); 0: plain (tile, row pair, frame) order */
-  BT709HIP_OPT_COALESCE = 6          /* 0 (default) off; n in 2..32: coalescing submit, see bt709hip_decode */
+  BT709HIP_OPT_COALESCE = 6,         /* 0 (default) off; n in 2..32: coalescing submit, see bt709hip_decode */
+  BT709HIP_OPT_COALESCE_MAX_AGE_US = 7 /* 0 (default): queued frames wait for their stream's next call, however long; t > 0: a queue whose oldest frame was queued more than t microseconds ago is issued by the next bt709hip_* call that touches ANY stream of the context (or any decode of any decoder of it) */
 } bt709hip_decoder_option;
 int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value);
 int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *value);
@@ -270,8 +277,13 @@ int bt709hip_decode(bt709hip_decoder *dec,
  *   - when it holds n frames, or a call with another geometry / format / decoder state arrives for that stream,
  *   - by any bt709hip_* call that takes that stream (stream_synchronize, event_record, stream_wait_event, download, upload,
  *     memset, graph capture, copy_probe, a decode with wait_until_completed != 0, every other decode / encode / rescale
- *     entry point) -- so the stream keeps its order for everything issued through this API,
+ *     entry point -- of THIS decoder or of any other decoder of the context, coalescing or not) -- so the stream keeps its
+ *     order for everything issued through this API (tests/test_fake_hip.py enumerates this header's `void *stream` exports
+ *     and checks each one),
  *   - by bt709hip_decoder_flush, and when the decoder is destroyed or the option is turned off.
+ * There is no timer thread: a queue is only ever issued from inside a bt709hip_* call.  A caller that may go idle with frames
+ * queued either flushes before it does, or sets BT709HIP_OPT_COALESCE_MAX_AGE_US, which bounds the wait by the time to the
+ * context's NEXT call of any kind (a renderer's per-frame bt709hip_stream_synchronize / event poll on another stream is enough).
  * The command-buffer analogy: queued frames are "encoded, not yet committed".  What the caller gives up: work submitted to
  * the raw hipStream_t behind this API's back (its own kernels, hipStreamSynchronize) is not ordered after queued frames --
  * call bt709hip_decoder_flush first.  Frame and surface descriptors are copied at the call; the buffers they point to must
@@ -391,8 +403,12 @@ int bt709hip_pool_release(bt709hip_pool *pool, int slot);
  * default, 6; 1 = first allocation, no probing; rings under 256 MB never probe), times the DECODER'S OWN LAUNCH over the ring
  * on the pairings (~15 ms each; every output candidate under input 0 first -- twice or three times `tries` of them when they
  * all look alike -- then every input with the `tries` fastest outputs, then the three best pairings and the first-allocated
- * one again, six times as long), keeps the fastest pairing and frees the rest.  It always leaves 4 GiB of the device free and hunts among what it
- * could allocate.  Set-up cost: 1-2 s for a 12 GB ring.  half_scale != 0: outputs are (W/2) x (H/2) and the ring decodes
+ * one again, six times as long), keeps the fastest pairing and frees the rest.  TRANSIENT FOOTPRINT: every candidate is device
+ * memory held until the choice is made -- unbounded that is up to 6 input + 18 output slabs (172 GB for a 256-frame 4K ring) --
+ * so the hunt runs under a BUDGET (bt709hip_ring_options): by default it never holds more than HALF of the memory that was free
+ * at the call (ring included) and always leaves 4 GiB of the device free; when a new candidate does not fit, the slowest slab
+ * seen so far is freed first (the fastest ones stay for the pairing probes), down to the incumbent pair + one candidate.  The
+ * duration and the peak footprint are reported (hunt_ms, peak_bytes).  Set-up cost: 1-2 s for a 12 GB ring.  half_scale != 0: outputs are (W/2) x (H/2) and the ring decodes
  * through bt709hip_decode_half_batch.  A decoder with an alpha channel gets an alpha plane per frame (third plane of the
  * input slab).  The memory is NOT cleared.  The decoder must outlive the ring. */
 typedef struct bt709hip_ring bt709hip_ring;
@@ -407,8 +423,26 @@ typedef struct {
   float best_GBps, worst_GBps;       /* over the pairing probes */
   float out_prescan_GBps[18];        /* output candidates under input 0, allocation order; 0 = none */
   int32_t out_kept[18];              /* allocation-order indices of the outputs that went on to the pairing probes; -1 = none */
+  float hunt_ms;                     /* wall-clock time of the whole hunt (allocations, probes, frees); 0 without a hunt */
+  int32_t stopped_by;                /* 0: ran to its end; 1: the byte budget cut candidates; 2: the time budget ended it early */
+  uint64_t peak_bytes;               /* most device memory this call held at once, the ring's own two slabs included */
+  uint64_t budget_bytes;             /* the byte budget it ran under (after defaults and clamping) */
+  int32_t evicted;                   /* candidate slabs freed before the choice to make room (0 when the budget held them all) */
+  int32_t reserved;
 } bt709hip_ring_placement;
+/* Budget of the placement hunt.  A zeroed struct (or NULL) = the defaults. */
+typedef struct {
+  uint64_t max_bytes;   /* most device memory the call may hold at once, the ring's two slabs included; 0 = half of the memory free
+                           at the call.  A budget that cannot hold the ring plus one more slab leaves nothing to compare: the ring
+                           is then allocated without a hunt */
+  uint32_t max_ms;      /* wall-clock budget of the hunt in milliseconds (checked before every probe); 0 = none */
+  int32_t frugal;       /* != 0: max_bytes = the ring + ONE candidate pair, whatever is free: the incumbent pair and the pair being
+                           probed are all that ever lives */
+} bt709hip_ring_options;
 int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frames, int half_scale, int tries, bt709hip_ring **out);
+/* the same with an explicit budget (bt709hip_ring_create = options NULL) */
+int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int frames, int half_scale, int tries,
+                            const bt709hip_ring_options *options, bt709hip_ring **out);
 int bt709hip_ring_destroy(bt709hip_ring *ring);
 int bt709hip_ring_frames(const bt709hip_ring *ring);
 /* Descriptors of frame `index` (any of the three pointers may be NULL; alpha is zeroed for an opaque decoder). */
@@ -416,6 +450,27 @@ int bt709hip_ring_frame(const bt709hip_ring *ring, int index, bt709hip_frame *fr
 int bt709hip_ring_placement_info(const bt709hip_ring *ring, bt709hip_ring_placement *info);
 /* Frames [first, first + count) in ONE launch on `stream`. */
 int bt709hip_ring_decode(bt709hip_ring *ring, int first, int count, void *stream, int wait_until_completed);
+
+/* ----------------------------------------------------------------- ring set */
+/* ONE process, SEVERAL GPUs, frames resident in DEVICE memory: a bt709hip_ring per lane, each with a context and a decoder of
+ * its own on device_ordinals[lane] (ordinals may repeat), driven by ONE thread -- the reference's shape, one process that drives
+ * everything (Renderer/AAPLRenderer.m:874-985), widened to the GPUs of a node.  bt709hip_ringset_decode issues ONE ring launch
+ * per lane, in lane order, on each lane's default stream and returns (the launches run concurrently, one per device; a launch
+ * call costs ~10 us of host time against ~1.8 ms of kernel for a 256-frame 4K ring); _synchronize waits for every lane.  No
+ * collective, no peer access: nothing crosses GPUs.  The host-frame counterpart is the frame sharder below.  Each lane's ring
+ * is created like bt709hip_ring_create_ex's (placement hunt per device, same budget semantics, per device).  Fill the rings
+ * through bt709hip_ringset_lane_ring + bt709hip_ring_frame + bt709hip_upload on bt709hip_ringset_lane_context. */
+typedef struct bt709hip_ringset bt709hip_ringset;
+int bt709hip_ringset_create(const int *device_ordinals, int lanes, int gamma, int has_alpha, int width, int height, int frames,
+                            int half_scale, int tries, const bt709hip_ring_options *options, bt709hip_ringset **out);
+int bt709hip_ringset_destroy(bt709hip_ringset *set);
+int bt709hip_ringset_lanes(const bt709hip_ringset *set);
+bt709hip_context *bt709hip_ringset_lane_context(bt709hip_ringset *set, int lane);
+bt709hip_decoder *bt709hip_ringset_lane_decoder(bt709hip_ringset *set, int lane);
+bt709hip_ring *bt709hip_ringset_lane_ring(bt709hip_ringset *set, int lane);
+/* frames [first, first + count) of EVERY lane's ring: one launch per lane, issued from the calling thread */
+int bt709hip_ringset_decode(bt709hip_ringset *set, int first, int count, int wait_until_completed);
+int bt709hip_ringset_synchronize(bt709hip_ringset *set);
 
 /* ------------------------------------------------------------ frame sharder */
 /* ONE process driving SEVERAL GPUs: independent frames shard with no exchange step, frame i (in submission
@@ -431,7 +486,8 @@ int bt709hip_ring_decode(bt709hip_ring *ring, int first, int count, void *stream
  *              frames of its lane were cancelled or failed in between); BT709HIP_ERR_INVALID_ARG once recycled
  *   cancel  -> hands an acquired, uncommitted ticket back
  * Threading: a shard is driven by ONE thread at a time (like a pool); that thread only enqueues, the lanes'
- * streams run concurrently.  Several feeding threads use a shard each (contexts are per shard). */
+ * streams run concurrently.  Several feeding threads use a shard each (contexts are per shard).
+ * Frames that already live in device memory: bt709hip_ringset_* above. */
 typedef struct bt709hip_shard bt709hip_shard;
 int bt709hip_shard_create(const int *device_ordinals, int lanes, int gamma, int has_alpha, int width, int height, int depth,
                           bt709hip_shard **out);

@@ -7,7 +7,7 @@ imports, links or runs oracle/: that directory is test infrastructure.
 """
 from . import _capi
 from ._capi import Bt709Error, load as load_library
-from .decoder import (BGRATexture, BGRAToBT709Converter, CommandBuffer, CVPixelBuffer, FrameRing, FrameSharder, InFlightFramePool, MetalBT709Decoder,
+from .decoder import (BGRATexture, BGRAToBT709Converter, CommandBuffer, CVPixelBuffer, FrameRing, FrameRingSet, FrameSharder, InFlightFramePool, MetalBT709Decoder,
                       MetalBT709GammaApple, MetalBT709GammaITU709, MetalBT709GammaLinear, MetalBT709GammaSRGB,
                       MetalRenderContext, MetalScaleRenderContext, MTLRenderPassDescriptor, MTLPixelFormatBGRA8Unorm_sRGB, MTLPixelFormatRGBA16Float,
                       kCVImageBufferTransferFunction_ITU_R_709_2, kCVImageBufferTransferFunction_Linear,

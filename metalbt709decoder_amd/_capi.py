@@ -24,7 +24,7 @@ class Surface(C.Structure):  # bt709hip_surface
                 ("format", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 400  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
+ABI_VERSION = 500  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
 
 # bt709hip_format
 FORMAT_BGRA8_SRGB = 0
@@ -37,6 +37,7 @@ OPT_HALF_WORKGROUPS = 3
 OPT_HALF_LDS_KB = 4
 OPT_XCD_BANDS = 5
 OPT_COALESCE = 6
+OPT_COALESCE_MAX_AGE_US = 7
 CTX_OPT_GRID_MULT = 1
 CTX_OPT_ENCODE_ROW_PAIRS = 2
 CTX_OPT_ENCODE_THREADS = 3
@@ -48,7 +49,13 @@ class RingPlacement(C.Structure):  # bt709hip_ring_placement
     _fields_ = [("tries", C.c_int32), ("in_candidates", C.c_int32), ("out_candidates", C.c_int32),
                 ("chosen_in", C.c_int32), ("chosen_out", C.c_int32), ("probes", C.c_int32),
                 ("first_GBps", C.c_float), ("chosen_GBps", C.c_float), ("best_GBps", C.c_float), ("worst_GBps", C.c_float),
-                ("out_prescan_GBps", C.c_float * 18), ("out_kept", C.c_int32 * 18)]
+                ("out_prescan_GBps", C.c_float * 18), ("out_kept", C.c_int32 * 18),
+                ("hunt_ms", C.c_float), ("stopped_by", C.c_int32), ("peak_bytes", C.c_uint64), ("budget_bytes", C.c_uint64),
+                ("evicted", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RingOptions(C.Structure):  # bt709hip_ring_options
+    _fields_ = [("max_bytes", C.c_uint64), ("max_ms", C.c_uint32), ("frugal", C.c_int32)]
 
 
 class LaunchInfo(C.Structure):  # bt709hip_launch_info
@@ -61,7 +68,8 @@ class DeviceInfo(C.Structure):  # bt709hip_device_info
                 ("memory_clock_khz", C.c_int32), ("memory_bus_width_bits", C.c_int32),
                 ("l2_bytes", C.c_int32), ("clock_khz", C.c_int32),
                 ("total_memory_bytes", C.c_uint64),
-                ("name", C.c_char * 128), ("arch", C.c_char * 64)]
+                ("name", C.c_char * 128), ("arch", C.c_char * 64),
+                ("pci_bus_id", C.c_char * 32), ("uuid", C.c_char * 40)]
 
 
 # status codes (bt709hip_status)
@@ -130,7 +138,16 @@ SYMBOLS = {
     "bt709hip_decoder_flush": (_I, [_P, _P]),
     "bt709hip_decoder_flush_all": (_I, [_P]),
     "bt709hip_ring_create": (_I, [_P, _I, _I, _I, _I, _I, c_void_pp]),
+    "bt709hip_ring_create_ex": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(RingOptions), c_void_pp]),
     "bt709hip_ring_destroy": (_I, [_P]),
+    "bt709hip_ringset_create": (_I, [C.POINTER(C.c_int), _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(RingOptions), c_void_pp]),
+    "bt709hip_ringset_destroy": (_I, [_P]),
+    "bt709hip_ringset_lanes": (_I, [_P]),
+    "bt709hip_ringset_lane_context": (_P, [_P, _I]),
+    "bt709hip_ringset_lane_decoder": (_P, [_P, _I]),
+    "bt709hip_ringset_lane_ring": (_P, [_P, _I]),
+    "bt709hip_ringset_decode": (_I, [_P, _I, _I, _I]),
+    "bt709hip_ringset_synchronize": (_I, [_P]),
     "bt709hip_ring_frames": (_I, [_P]),
     "bt709hip_ring_frame": (_I, [_P, _I, _FP, _FP, _SP]),
     "bt709hip_ring_placement_info": (_I, [_P, C.POINTER(RingPlacement)]),

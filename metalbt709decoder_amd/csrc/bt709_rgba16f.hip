@@ -190,9 +190,12 @@ const char *launch_decode_rgba16f(const DecodeParams &p_in, const HalfParams &hp
 #ifndef BT709_RGBA16F_WG_PER_CU
 #define BT709_RGBA16F_WG_PER_CU 6
 #endif
+#ifndef BT709_RGBA16F_MAX_RPB
+#define BT709_RGBA16F_MAX_RPB 16
+#endif
   const uint64_t want = static_cast<uint64_t>(BT709_RGBA16F_WG_PER_CU) * (compute_units ? compute_units : 256u);
   uint32_t rpb = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * row_pairs * static_cast<uint32_t>(frames) / want);
-  rpb = rpb < 1 ? 1 : (rpb > 16 ? 16 : rpb);
+  rpb = rpb < 1 ? 1 : (rpb > BT709_RGBA16F_MAX_RPB ? BT709_RGBA16F_MAX_RPB : rpb);
   hp.row_pairs_per_block = rpb;
   hp.wide_store = out_align >= 16 ? 1 : 0;
   dim3 grid(tiles, (row_pairs + rpb - 1) / rpb, static_cast<uint32_t>(frames));

@@ -115,17 +115,39 @@ struct Prober {
   }
 };
 
-// `want` candidates of `bytes`, all alive (so they land in different places); fewer when memory runs short: the hunt goes
-// on among what there is, and always leaves kReserveBytes (plus `headroom`) of the device free.
-void allocate_candidates(bt709hip_context *ctx, size_t bytes, int want, size_t headroom, std::vector<void *> *got) {
-  for (int i = 0; i < want; ++i) {
+// One slab of the hunt.  `rate` = its probe under the reference partner (outputs: under input 0; inputs: under the best output).
+struct Slab {
+  void *p = nullptr;
+  float rate = 0.0f;
+  bool alive = false;
+};
+
+// Device memory the call holds, against its budget (bt709hip_ring_options): every candidate is alive until the choice is made
+// unless the budget says otherwise -- then the SLOWEST output seen so far goes first (the fast ones are what the pairing probes
+// need), down to one.
+struct Ledger {
+  bt709hip_context *ctx;
+  size_t budget = 0, held = 0, peak = 0;
+  int evicted = 0;
+
+  bool fits(size_t bytes) const {
+    if (held + bytes > budget) return false;
     size_t free_b = 0;
-    if (!got->empty() && (bt709hip_mem_info(ctx, &free_b, nullptr) != BT709HIP_OK || free_b < bytes + kReserveBytes + headroom)) break;
-    void *p = nullptr;
-    if (bt709hip_malloc(ctx, bytes, &p) != BT709HIP_OK || p == nullptr) break;
-    got->push_back(p);
+    return bt709hip_mem_info(ctx, &free_b, nullptr) == BT709HIP_OK && free_b >= bytes + kReserveBytes;
   }
-}
+  void *take(size_t bytes) {
+    void *p = nullptr;
+    if (bt709hip_malloc(ctx, bytes, &p) != BT709HIP_OK || p == nullptr) return nullptr;
+    held += bytes;
+    peak = std::max(peak, held);
+    return p;
+  }
+  void give(void *p, size_t bytes) {
+    if (p == nullptr) return;
+    (void)bt709hip_free(ctx, p);
+    held -= bytes;
+  }
+};
 
 }  // namespace
 
@@ -143,6 +165,11 @@ int bt709hip_ring_destroy(bt709hip_ring *r) {
 }
 
 int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frames, int half_scale, int tries, bt709hip_ring **out) {
+  return bt709hip_ring_create_ex(dec, width, height, frames, half_scale, tries, nullptr, out);
+}
+
+int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int frames, int half_scale, int tries,
+                            const bt709hip_ring_options *options, bt709hip_ring **out) {
   if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
   *out = nullptr;
   if (dec == nullptr || width <= 0 || height <= 0 || frames <= 0 || frames > 65535 || tries < 0) return BT709HIP_ERR_INVALID_ARG;
@@ -153,6 +180,7 @@ int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frame
   if (ctx == nullptr) return BT709HIP_ERR_NOT_SETUP;
   bt709hip_ring *r = new (std::nothrow) bt709hip_ring();
   if (r == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  const double t_start = now_s();
   r->dec = dec;
   r->ctx = ctx;
   r->width = width, r->height = height, r->frames = frames, r->half = half_scale ? 1 : 0;
@@ -174,50 +202,117 @@ int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frame
   if (tries == 0) tries = kMaxTries;
   tries = std::min(tries, kMaxTries);
   if (in_bytes + out_bytes < kHuntMinBytes) tries = 1;
-  pl.tries = tries;
 
-  std::vector<void *> ins, outs;
-  allocate_candidates(ctx, in_bytes, tries, out_bytes, &ins);
-  allocate_candidates(ctx, out_bytes, tries, 0, &outs);
-  auto free_all = [&](void *keep_in, void *keep_out) {
-    for (void *p : ins)
-      if (p != keep_in) (void)bt709hip_free(ctx, p);
-    for (void *p : outs)
-      if (p != keep_out) (void)bt709hip_free(ctx, p);
+  // THE BUDGET.  Default: half of what is free now (a second process on the device, or this one's next ring, still finds room
+  // while the hunt runs); frugal: the incumbent pair + one candidate pair.  A budget that cannot hold the ring and one more
+  // output slab leaves nothing to compare.
+  Ledger led{ctx};
+  {
+    size_t free_b = 0;
+    if (bt709hip_mem_info(ctx, &free_b, nullptr) != BT709HIP_OK) free_b = 0;
+    size_t budget = options != nullptr && options->max_bytes != 0 ? static_cast<size_t>(options->max_bytes) : free_b / 2;
+    if (options != nullptr && options->frugal) budget = 2 * (in_bytes + out_bytes);
+    if (tries > 1 && budget < in_bytes + 2 * out_bytes) {
+      tries = 1;
+      pl.stopped_by = 1;
+    }
+    led.budget = std::max(budget, in_bytes + out_bytes);  // the ring itself is not negotiable
+  }
+  const double max_s = options != nullptr && options->max_ms != 0 ? options->max_ms * 1e-3 : 0.0;
+  auto time_left = [&]() { return max_s == 0.0 || now_s() - t_start < max_s; };
+  pl.tries = tries;
+  pl.budget_bytes = led.budget;
+
+  // Inputs first (as round 4 did: they land in different places), all alive to the end -- they are the small slabs and move the
+  // rate by ~1 % -- but never more than a quarter of the budget, and always leaving room for two outputs.
+  std::vector<Slab> ins, outs;
+  {
+    int n_in = tries;
+    while (n_in > 1 && (static_cast<size_t>(n_in) * in_bytes > led.budget / 4 || static_cast<size_t>(n_in) * in_bytes + 2 * out_bytes > led.budget)) --n_in;
+    if (options != nullptr && options->frugal) n_in = std::min(n_in, 2);
+    for (int i = 0; i < n_in; ++i) {
+      if (i > 0 && !led.fits(in_bytes + out_bytes)) break;
+      void *p = led.take(in_bytes);
+      if (p == nullptr) break;
+      ins.push_back(Slab{p, 0.0f, true});
+    }
+  }
+  auto free_everything = [&]() {
+    for (Slab &s : ins)
+      if (s.alive) led.give(s.p, in_bytes), s.alive = false;
+    for (Slab &s : outs)
+      if (s.alive) led.give(s.p, out_bytes), s.alive = false;
   };
+  if (!ins.empty()) {
+    void *p = led.take(out_bytes);
+    if (p != nullptr) outs.push_back(Slab{p, 0.0f, true});
+  }
   if (ins.empty() || outs.empty()) {
-    free_all(nullptr, nullptr);
+    free_everything();
     delete r;
     return BT709HIP_ERR_HIP;  // out of device memory: bt709hip_last_hip_error
   }
+
   int bi = 0, bo = 0;
   Prober pr{r};
-  if (tries > 1 && (ins.size() > 1 || outs.size() > 1) && bt709hip_event_create(ctx, &pr.e0) == BT709HIP_OK &&
-      bt709hip_event_create(ctx, &pr.e1) == BT709HIP_OK) {
+  // the probes time the ring's OWN launch: a coalescing decoder would queue a short ring's frames instead (count < n)
+  int coalesce = 0;
+  (void)bt709hip_decoder_get_option(dec, BT709HIP_OPT_COALESCE, &coalesce);
+  if (tries > 1 && bt709hip_event_create(ctx, &pr.e0) == BT709HIP_OK && bt709hip_event_create(ctx, &pr.e1) == BT709HIP_OK) {
+    if (coalesce > 1) (void)bt709hip_decoder_set_option(dec, BT709HIP_OPT_COALESCE, 0);
     const double px_per_launch = static_cast<double>(width) * height * frames;
     pr.bytes_per_launch = (static_cast<double>(r->y_bytes + r->c_bytes + (r->has_alpha ? r->y_bytes : 0)) + static_cast<double>(ow) * oh * 4) * frames;
     // a probe = ~15 ms of the ring's own launches (3 launches resolved the top candidates to only +-1.5 %)
     const int reps = std::max(3, static_cast<int>((8.0 * 256 * 3840 * 2160 + px_per_launch - 1) / px_per_launch));
-    // Output slabs come in two regimes (~0.74 / ~0.80+ of the roofline for the 1:1 kernel); a process whose candidates all
-    // look alike under input 0 may hold `tries` slow ones (seen: 4 of 4, 6 of 8), so it allocates `tries` more -- always to
-    // twice `tries` (the fast regime itself spreads over 1 %), three times when they still look alike -- and the `tries`
-    // fastest go on to the pairing probes.
-    std::vector<float> prescan;
+    // PRESCAN: every output candidate under input 0, one after the other.  Output slabs come in two regimes (~0.74 / ~0.80+ of
+    // the roofline for the 1:1 kernel); a process whose candidates all look alike may hold `tries` slow ones (seen: 4 of 4,
+    // 6 of 8), so it goes on -- always to twice `tries` (the fast regime itself spreads over 1 %), three times when they still
+    // look alike.  When the budget has no room for the next candidate the slowest output alive is freed first.
+    auto alive_outs = [&]() { return static_cast<int>(std::count_if(outs.begin(), outs.end(), [](const Slab &s) { return s.alive; })); };
+    auto evict_slowest_out = [&]() {
+      int worst = -1;
+      for (size_t k = 0; k < outs.size(); ++k)
+        if (outs[k].alive && (worst < 0 || outs[k].rate < outs[static_cast<size_t>(worst)].rate)) worst = static_cast<int>(k);
+      if (worst < 0 || alive_outs() <= 1) return false;
+      led.give(outs[static_cast<size_t>(worst)].p, out_bytes);
+      outs[static_cast<size_t>(worst)].alive = false;
+      ++led.evicted;
+      return true;
+    };
+    outs[0].rate = pr.measure(ins[0].p, outs[0].p, reps, 0.15);
+    int target = tries;
     while (pr.rc == BT709HIP_OK) {
-      for (size_t o = prescan.size(); o < outs.size() && pr.rc == BT709HIP_OK; ++o)
-        prescan.push_back(pr.measure(ins[0], outs[o], reps, prescan.empty() ? 0.15 : 0.03));
-      const float hi = *std::max_element(prescan.begin(), prescan.end()), lo = *std::min_element(prescan.begin(), prescan.end());
+      bool stuck = false;
+      while (static_cast<int>(outs.size()) < target && pr.rc == BT709HIP_OK) {
+        if (!time_left()) {
+          pl.stopped_by = 2;
+          stuck = true;
+          break;
+        }
+        while (!led.fits(out_bytes) && evict_slowest_out()) pl.stopped_by = pl.stopped_by ? pl.stopped_by : 1;
+        void *p = led.fits(out_bytes) ? led.take(out_bytes) : nullptr;
+        if (p == nullptr) {
+          pl.stopped_by = pl.stopped_by ? pl.stopped_by : 1;
+          stuck = true;
+          break;
+        }
+        outs.push_back(Slab{p, 0.0f, true});
+        outs.back().rate = pr.measure(ins[0].p, p, reps, 0.03);
+      }
+      if (stuck || pr.rc != BT709HIP_OK) break;
+      float hi = 0.0f, lo = 1e30f;
+      for (const Slab &s : outs) hi = std::max(hi, s.rate), lo = std::min(lo, s.rate);
       const int n = static_cast<int>(outs.size());
       if (n >= 3 * tries || n >= kMaxOutCandidates || (n >= 2 * tries && (hi - lo) / hi >= 0.02f)) break;
-      const size_t before = outs.size();
-      allocate_candidates(ctx, out_bytes, std::min(tries, kMaxOutCandidates - n), 0, &outs);
-      if (outs.size() == before) break;
+      target = std::min(n + tries, kMaxOutCandidates);
     }
     pl.out_candidates = static_cast<int>(outs.size());
-    for (size_t o = 0; o < prescan.size() && o < static_cast<size_t>(kMaxOutCandidates); ++o) pl.out_prescan_GBps[o] = prescan[o];
-    std::vector<int> order(prescan.size());
-    for (size_t k = 0; k < order.size(); ++k) order[k] = static_cast<int>(k);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return prescan[static_cast<size_t>(x)] > prescan[static_cast<size_t>(y)]; });
+    for (size_t o = 0; o < outs.size() && o < static_cast<size_t>(kMaxOutCandidates); ++o) pl.out_prescan_GBps[o] = outs[o].rate;
+    // the `tries` fastest outputs still alive go on to the pairing probes
+    std::vector<int> order;
+    for (size_t k = 0; k < outs.size(); ++k)
+      if (outs[k].alive) order.push_back(static_cast<int>(k));
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return outs[static_cast<size_t>(x)].rate > outs[static_cast<size_t>(y)].rate; });
     std::vector<int> kept(order.begin(), order.begin() + std::min<size_t>(order.size(), static_cast<size_t>(tries)));
     std::sort(kept.begin(), kept.end());
     for (size_t k = 0; k < kept.size(); ++k) pl.out_kept[k] = kept[k];
@@ -226,16 +321,22 @@ int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frame
     for (size_t i = 0; i < ins.size() && pr.rc == BT709HIP_OK; ++i)
       for (int o : kept) {
         if (pr.rc != BT709HIP_OK) break;
-        probed[{static_cast<int>(i), o}] = (i == 0 && !prescan.empty()) ? prescan[static_cast<size_t>(o)] : pr.measure(ins[i], outs[static_cast<size_t>(o)], reps, 0.03);
+        if (i > 0 && !time_left()) {
+          pl.stopped_by = 2;
+          break;
+        }
+        probed[{static_cast<int>(i), o}] = i == 0 ? outs[static_cast<size_t>(o)].rate : pr.measure(ins[i].p, outs[static_cast<size_t>(o)].p, reps, 0.03);
       }
     pl.probes = static_cast<int>(probed.size());
     if (pr.rc == BT709HIP_OK && !probed.empty()) {
-      pl.first_GBps = prescan.empty() ? 0.0f : prescan[0];
+      pl.first_GBps = outs[0].rate;
       std::vector<std::pair<float, std::pair<int, int>>> ranked;
       for (const auto &kv : probed) ranked.push_back({kv.second, kv.first});
       std::sort(ranked.begin(), ranked.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
       pl.best_GBps = ranked.front().first;
       pl.worst_GBps = ranked.back().first;
+      bi = ranked.front().second.first, bo = ranked.front().second.second;
+      pl.chosen_GBps = ranked.front().first;
       // the three best -- and the first-allocated pairing, so that a hunt over candidates that are all alike never ends on a
       // pairing a noisy 15 ms probe preferred to the one a caller would have had anyway -- again, six times as long (~90 ms
       // each; 45 ms resolved the top three to +-0.3 %, as much as they differ): the choice is made on these
@@ -245,13 +346,19 @@ int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frame
       if (std::find(kept.begin(), kept.end(), 0) != kept.end() && std::find(finalists.begin(), finalists.end(), first_pair) == finalists.end())
         finalists.push_back(first_pair);
       float best = -1.0f;
-      for (const auto &io : finalists) {
-        if (pr.rc != BT709HIP_OK) break;
-        const float v = pr.measure(ins[static_cast<size_t>(io.first)], outs[static_cast<size_t>(io.second)], 6 * reps, 0.03);
-        if (v > best) best = v, bi = io.first, bo = io.second;
-      }
-      pl.chosen_GBps = best;
+      if (finalists.size() > 1)
+        for (const auto &io : finalists) {
+          if (pr.rc != BT709HIP_OK) break;
+          if (!time_left()) {  // out of time: the short probes decide
+            pl.stopped_by = 2;
+            break;
+          }
+          const float v = pr.measure(ins[static_cast<size_t>(io.first)].p, outs[static_cast<size_t>(io.second)].p, 6 * reps, 0.03);
+          if (v > best) best = v, bi = io.first, bo = io.second;
+        }
+      if (best > 0.0f) pl.chosen_GBps = best;
     }
+    if (coalesce > 1) (void)bt709hip_decoder_set_option(dec, BT709HIP_OPT_COALESCE, coalesce);
   }
   if (pr.e0) (void)bt709hip_event_destroy(ctx, pr.e0);
   if (pr.e1) (void)bt709hip_event_destroy(ctx, pr.e1);
@@ -259,8 +366,13 @@ int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frame
   if (pl.out_candidates == 0) pl.out_candidates = static_cast<int>(outs.size());
   pl.chosen_in = bi;
   pl.chosen_out = bo;
-  void *keep_in = ins[static_cast<size_t>(bi)], *keep_out = outs[static_cast<size_t>(bo)];
-  free_all(keep_in, keep_out);
+  pl.evicted = led.evicted;
+  void *keep_in = ins[static_cast<size_t>(bi)].p, *keep_out = outs[static_cast<size_t>(bo)].p;
+  ins[static_cast<size_t>(bi)].alive = false;  // not the hunt's any more
+  outs[static_cast<size_t>(bo)].alive = false;
+  pl.peak_bytes = led.peak;
+  free_everything();
+  if (pl.tries > 1) pl.hunt_ms = static_cast<float>((now_s() - t_start) * 1e3);
   if (pr.rc != BT709HIP_OK) {
     (void)bt709hip_free(ctx, keep_in);
     (void)bt709hip_free(ctx, keep_out);
@@ -296,6 +408,88 @@ int bt709hip_ring_decode(bt709hip_ring *r, int first, int count, void *stream, i
   if (r == nullptr || first < 0 || count < 0 || first + count > r->frames) return BT709HIP_ERR_INVALID_ARG;
   if (count == 0) return BT709HIP_OK;
   return launch(r, first, count, stream, wait_until_completed);
+}
+
+// ----------------------------------------------------------------- ring set
+// One process, several GPUs, device-resident frames (include/bt709hip.h "ring set"): a context + decoder + ring per lane, one
+// launch per lane per step issued from the calling thread.  Every C-ABI call binds its context's device, so the lanes need no
+// thread of their own: a launch call returns as soon as the kernel is enqueued.
+
+}  // extern "C"
+
+struct bt709hip_ringset {
+  struct Lane {
+    bt709hip_context *ctx = nullptr;
+    bt709hip_decoder *dec = nullptr;
+    bt709hip_ring *ring = nullptr;
+  };
+  std::vector<Lane> lanes;
+};
+
+extern "C" {
+
+int bt709hip_ringset_destroy(bt709hip_ringset *set) {
+  if (set == nullptr) return BT709HIP_OK;
+  for (auto &l : set->lanes) {
+    if (l.ring) (void)bt709hip_ring_destroy(l.ring);
+    if (l.dec) (void)bt709hip_decoder_destroy(l.dec);
+    if (l.ctx) (void)bt709hip_context_destroy(l.ctx);
+  }
+  delete set;
+  return BT709HIP_OK;
+}
+
+int bt709hip_ringset_create(const int *device_ordinals, int lanes, int gamma, int has_alpha, int width, int height, int frames,
+                            int half_scale, int tries, const bt709hip_ring_options *options, bt709hip_ringset **out) {
+  if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (device_ordinals == nullptr || lanes <= 0 || lanes > 64) return BT709HIP_ERR_INVALID_ARG;
+  bt709hip_ringset *set = new (std::nothrow) bt709hip_ringset();
+  if (set == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  set->lanes.resize(static_cast<size_t>(lanes));
+  int rc = BT709HIP_OK;
+  for (int i = 0; i < lanes && rc == BT709HIP_OK; ++i) {
+    bt709hip_ringset::Lane &l = set->lanes[static_cast<size_t>(i)];
+    rc = bt709hip_context_create(device_ordinals[i], &l.ctx);
+    if (rc == BT709HIP_OK) rc = bt709hip_decoder_create(l.ctx, gamma, has_alpha, &l.dec);
+    if (rc == BT709HIP_OK) rc = bt709hip_ring_create_ex(l.dec, width, height, frames, half_scale, tries, options, &l.ring);
+  }
+  if (rc != BT709HIP_OK) {
+    bt709hip_ringset_destroy(set);
+    return rc;
+  }
+  *out = set;
+  return BT709HIP_OK;
+}
+
+int bt709hip_ringset_lanes(const bt709hip_ringset *set) { return set ? static_cast<int>(set->lanes.size()) : BT709HIP_ERR_INVALID_ARG; }
+
+bt709hip_context *bt709hip_ringset_lane_context(bt709hip_ringset *set, int lane) {
+  return set != nullptr && lane >= 0 && static_cast<size_t>(lane) < set->lanes.size() ? set->lanes[static_cast<size_t>(lane)].ctx : nullptr;
+}
+
+bt709hip_decoder *bt709hip_ringset_lane_decoder(bt709hip_ringset *set, int lane) {
+  return set != nullptr && lane >= 0 && static_cast<size_t>(lane) < set->lanes.size() ? set->lanes[static_cast<size_t>(lane)].dec : nullptr;
+}
+
+bt709hip_ring *bt709hip_ringset_lane_ring(bt709hip_ringset *set, int lane) {
+  return set != nullptr && lane >= 0 && static_cast<size_t>(lane) < set->lanes.size() ? set->lanes[static_cast<size_t>(lane)].ring : nullptr;
+}
+
+int bt709hip_ringset_decode(bt709hip_ringset *set, int first, int count, int wait_until_completed) {
+  if (set == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  // every lane's launch is enqueued before any lane is waited for: the devices run concurrently
+  for (auto &l : set->lanes)
+    if (int rc = bt709hip_ring_decode(l.ring, first, count, nullptr, 0)) return rc;
+  return wait_until_completed ? bt709hip_ringset_synchronize(set) : BT709HIP_OK;
+}
+
+int bt709hip_ringset_synchronize(bt709hip_ringset *set) {
+  if (set == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  int rc = BT709HIP_OK;
+  for (auto &l : set->lanes)
+    if (int e = bt709hip_stream_synchronize(l.ctx, nullptr)) rc = rc ? rc : e;
+  return rc;
 }
 
 }  // extern "C"

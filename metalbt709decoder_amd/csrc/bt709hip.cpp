@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +60,7 @@ struct bt709hip_context {
 struct PendingQueue {
   hipStream_t stream = nullptr;
   bool with_alphas = false;  // the calls passed alpha descriptors
+  int64_t oldest_us = 0;     // steady-clock time at which the oldest frame it holds was queued (BT709HIP_OPT_COALESCE_MAX_AGE_US)
   std::vector<bt709hip_frame> frames, alphas;
   std::vector<bt709hip_surface> outs;
 };
@@ -74,6 +76,7 @@ struct bt709hip_decoder {
   int half_lds_kb = 0;      // BT709HIP_OPT_HALF_LDS_KB: 0 = all 160
   int xcd_bands = 1;        // BT709HIP_OPT_XCD_BANDS: XCD-aware work map of the batched 1:1 kernels (frames a multiple of 8)
   int coalesce = 0;         // BT709HIP_OPT_COALESCE: 0 off, else frames gathered per launch (2..32)
+  int coalesce_max_age_us = 0;  // BT709HIP_OPT_COALESCE_MAX_AGE_US: 0 = no age limit
   std::mutex queue_mutex;   // guards queues
   std::vector<PendingQueue> queues;  // one per stream that has (had) queued frames
   std::mutex setup_mutex;
@@ -346,27 +349,36 @@ int issue_queue(bt709hip_decoder *dec, PendingQueue &q) {
                           q.stream, 0);
 }
 
-// one decoder: the queue of stream `s`, or every queue (all = true)
-int flush_decoder(bt709hip_decoder *dec, hipStream_t s, bool all) {
+int64_t now_us() {
+  return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// one decoder: the queue of stream `s`, or every queue (all = true); aged_only: only queues older than the decoder's age limit
+int flush_decoder(bt709hip_decoder *dec, hipStream_t s, bool all, bool aged_only = false) {
   std::lock_guard<std::mutex> lock(dec->queue_mutex);
   int rc = BT709HIP_OK;
-  for (PendingQueue &q : dec->queues)
-    if (all || q.stream == s)
+  const int64_t limit = aged_only ? now_us() - dec->coalesce_max_age_us : 0;
+  for (PendingQueue &q : dec->queues) {
+    if (q.frames.empty()) continue;
+    const bool aged = dec->coalesce_max_age_us > 0 && q.oldest_us <= limit;
+    if (aged_only ? (aged || q.stream == s) : (all || q.stream == s))
       if (int e = issue_queue(dec, q)) rc = rc ? rc : e;
+  }
   return rc;
 }
 
-// every coalescing decoder of `ctx`: called by each entry point that takes a stream, before it touches the stream
-int flush_stream(bt709hip_context *ctx, hipStream_t s) {
-  if (ctx == nullptr || ctx->n_coalescing.load(std::memory_order_relaxed) == 0) return BT709HIP_OK;
-  std::vector<bt709hip_decoder *> decs;
-  {
-    std::lock_guard<std::mutex> lock(ctx->coalescing_mutex);
-    decs = ctx->coalescing;
-  }
+// Every coalescing decoder of `ctx` except `skip`: called by each entry point that takes a stream, before it touches the stream
+// -- the queue of THAT stream goes out (stream order), and so does any queue of any stream that has outlived its decoder's
+// BT709HIP_OPT_COALESCE_MAX_AGE_US (nothing here runs on a timer: an idle caller's frames wait for the context's next call).
+// coalescing_mutex is held across the loop (lock order: coalescing_mutex, then a decoder's queue_mutex): a decoder that is being
+// destroyed leaves the list under the same mutex (set_coalescing), so none of the pointers can dangle.
+int flush_stream(bt709hip_context *ctx, hipStream_t s, const bt709hip_decoder *skip = nullptr) {
+  if (ctx == nullptr || ctx->n_coalescing.load(std::memory_order_acquire) == 0) return BT709HIP_OK;
+  std::lock_guard<std::mutex> lock(ctx->coalescing_mutex);
   int rc = BT709HIP_OK;
-  for (bt709hip_decoder *d : decs)
-    if (int e = flush_decoder(d, s, false)) rc = rc ? rc : e;
+  for (bt709hip_decoder *d : ctx->coalescing)
+    if (d != skip)
+      if (int e = flush_decoder(d, s, false, true)) rc = rc ? rc : e;
   return rc;
 }
 
@@ -385,7 +397,7 @@ void set_coalescing(bt709hip_decoder *dec, int n) {
   auto it = std::find(ctx->coalescing.begin(), ctx->coalescing.end(), dec);
   if (now && it == ctx->coalescing.end()) ctx->coalescing.push_back(dec);
   if (!now && it != ctx->coalescing.end()) ctx->coalescing.erase(it);
-  ctx->n_coalescing.store(static_cast<int>(ctx->coalescing.size()), std::memory_order_relaxed);
+  ctx->n_coalescing.store(static_cast<int>(ctx->coalescing.size()), std::memory_order_release);
 }
 
 }  // namespace
@@ -493,6 +505,17 @@ int bt709hip_context_info(const bt709hip_context *ctx, bt709hip_device_info *inf
   info->total_memory_bytes = ctx->props.totalGlobalMem;
   std::snprintf(info->name, sizeof info->name, "%s", ctx->props.name);
   std::snprintf(info->arch, sizeof info->arch, "%s", ctx->props.gcnArchName);
+  // which physical device: the bus id as the runtime prints it, the UUID as 32 hex digits (both empty if the runtime has none)
+  if (hipDeviceGetPCIBusId(info->pci_bus_id, static_cast<int>(sizeof info->pci_bus_id), ctx->device) != hipSuccess) {
+    (void)hipGetLastError();
+    std::snprintf(info->pci_bus_id, sizeof info->pci_bus_id, "%04x:%02x:%02x.0", ctx->props.pciDomainID, ctx->props.pciBusID, ctx->props.pciDeviceID);
+  }
+  hipUUID uuid;
+  if (hipDeviceGetUuid(&uuid, ctx->device) == hipSuccess) {
+    for (int i = 0; i < 16; ++i) std::snprintf(info->uuid + 2 * i, 3, "%02x", static_cast<unsigned>(static_cast<unsigned char>(uuid.bytes[i])));
+  } else {
+    (void)hipGetLastError();
+  }
   return BT709HIP_OK;
 }
 
@@ -773,6 +796,7 @@ int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value) {
     case BT709HIP_OPT_HALF_LDS_KB: dec->half_lds_kb = clamp_int(value, 0, 160); return BT709HIP_OK;
     case BT709HIP_OPT_XCD_BANDS: dec->xcd_bands = clamp_int(value, 0, 2); return BT709HIP_OK;
     case BT709HIP_OPT_COALESCE: set_coalescing(dec, value <= 1 ? 0 : clamp_int(value, 2, kMaxBatch)); return BT709HIP_OK;
+    case BT709HIP_OPT_COALESCE_MAX_AGE_US: dec->coalesce_max_age_us = value < 0 ? 0 : value; return BT709HIP_OK;
     default: return BT709HIP_ERR_INVALID_ARG;
   }
 }
@@ -786,6 +810,7 @@ int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *va
     case BT709HIP_OPT_HALF_LDS_KB: *value = dec->half_lds_kb; return BT709HIP_OK;
     case BT709HIP_OPT_XCD_BANDS: *value = dec->xcd_bands; return BT709HIP_OK;
     case BT709HIP_OPT_COALESCE: *value = dec->coalesce; return BT709HIP_OK;
+    case BT709HIP_OPT_COALESCE_MAX_AGE_US: *value = dec->coalesce_max_age_us; return BT709HIP_OK;
     default: return BT709HIP_ERR_INVALID_ARG;
   }
 }
@@ -965,8 +990,18 @@ int coalescing_submit(bt709hip_decoder *dec, int count, const bt709hip_frame *fr
                       const bt709hip_surface *outs, void *stream, int wait_until_completed) {
   if (dec->ctx == nullptr) return decode_batch_now(dec, count, frames, alphas, outs, stream, wait_until_completed);
   hipStream_t s = pick(dec->ctx, stream);
+  // what the context's OTHER coalescing decoders have queued for this stream was submitted before this call: it goes first.
+  // Done before this decoder's own queue_mutex is taken (lock order: the context's coalescing_mutex, then a queue_mutex).
+  if (int rc = bind(dec->ctx)) return rc;
+  if (int rc = flush_stream(dec->ctx, s, dec)) return rc;
   std::lock_guard<std::mutex> lock(dec->queue_mutex);
   PendingQueue *q = nullptr;
+  if (dec->coalesce_max_age_us > 0) {  // this decoder's queues of OTHER streams that have waited too long
+    const int64_t limit = now_us() - dec->coalesce_max_age_us;
+    for (PendingQueue &c : dec->queues)
+      if (c.stream != s && !c.frames.empty() && c.oldest_us <= limit)
+        if (int rc = issue_queue(dec, c)) return rc;
+  }
   for (PendingQueue &c : dec->queues)
     if (c.stream == s) q = &c;
   const bool eligible = wait_until_completed == 0 && count >= 1 && count < dec->coalesce && frames != nullptr && outs != nullptr;
@@ -995,6 +1030,7 @@ int coalescing_submit(bt709hip_decoder *dec, int count, const bt709hip_frame *fr
       if (int rc = issue_queue(dec, *q)) return rc;
   }
   q->with_alphas = alphas != nullptr;
+  if (q->frames.empty()) q->oldest_us = now_us();
   q->frames.insert(q->frames.end(), frames, frames + count);
   if (alphas != nullptr) q->alphas.insert(q->alphas.end(), alphas, alphas + count);
   q->outs.insert(q->outs.end(), outs, outs + count);
@@ -1009,6 +1045,11 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame
                           const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
                           int wait_until_completed) {
   if (dec != nullptr && dec->coalesce > 1) return coalescing_submit(dec, count, frames, alphas, outs, stream, wait_until_completed);
+  // frames another (coalescing) decoder of the context queued on this stream were submitted first: they are issued first
+  if (dec != nullptr && dec->ctx != nullptr && dec->ctx->n_coalescing.load(std::memory_order_acquire) != 0) {
+    if (int rc = bind(dec->ctx)) return rc;
+    FLUSH_STREAM(dec->ctx, stream);
+  }
   return decode_batch_now(dec, count, frames, alphas, outs, stream, wait_until_completed);
 }
 

@@ -171,17 +171,24 @@ class FrameRing:
     reference's twin is its per-in-flight-frame CVPixelBuffers + render texture (AAPLRenderer.m:34, 530-862); unified
     memory has no placement to choose."""
 
-    def __init__(self, decoder, size, frames, halfScale=False, tries=0):
+    def __init__(self, decoder, size, frames, halfScale=False, tries=0, maxBytes=0, maxMilliseconds=0, frugal=False, _handle=None):
+        """maxBytes / maxMilliseconds / frugal: the hunt's budget (bt709hip_ring_options; 0 = half of the free device memory, no
+        time limit).  _handle: wrap a ring that somebody else owns (FrameRingSet's lanes)."""
         self.decoder, (self.width, self.height), self.frames = decoder, size, int(frames)
         self.ctx = decoder.metalRenderContext
         self.lib = self.ctx.lib
+        self.halfScale = bool(halfScale)
+        self._owned = _handle is None
+        if _handle is not None:
+            self.handle = C.c_void_p(_handle)
+            return
         if not decoder.setupMetal():
             raise RuntimeError("decoder setup failed: %s" % decoder.lastStatus)
         h = C.c_void_p()
-        _capi.check(self.lib.bt709hip_ring_create(decoder._handle, self.width, self.height, self.frames, int(bool(halfScale)),
-                                                  int(tries), C.byref(h)), "ring create")
+        opt = _capi.RingOptions(int(maxBytes), int(maxMilliseconds), int(bool(frugal)))
+        _capi.check(self.lib.bt709hip_ring_create_ex(decoder._handle, self.width, self.height, self.frames, int(bool(halfScale)),
+                                                     int(tries), C.byref(opt), C.byref(h)), "ring create")
         self.handle = h
-        self.halfScale = bool(halfScale)
 
     def pixelBuffer(self, i):
         """CVPixelBuffer view of input frame i (tagged for the decoder's gamma)."""
@@ -225,7 +232,68 @@ class FrameRing:
 
     def release(self):
         if self.handle:
-            self.lib.bt709hip_ring_destroy(self.handle)
+            if self._owned:
+                self.lib.bt709hip_ring_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class FrameRingSet:
+    """ONE process, several GPUs, frames resident in DEVICE memory (bt709hip_ringset_*): a FrameRing per lane, each with a
+    render context and a decoder of its own on devices[lane], all driven by the calling thread -- decode() issues one ring launch
+    per lane and returns; the devices run concurrently.  The reference's shape: one process that drives everything
+    (Renderer/AAPLRenderer.m:874-985).  Host frames: FrameSharder."""
+
+    def __init__(self, devices, size, frames, gamma=MetalBT709GammaApple, hasAlphaChannel=False, halfScale=False, tries=0, maxBytes=0,
+                 maxMilliseconds=0, frugal=False):
+        self.lib = _capi.load()
+        self.width, self.height = size
+        self.frames = int(frames)
+        arr = (C.c_int * len(devices))(*devices)
+        opt = _capi.RingOptions(int(maxBytes), int(maxMilliseconds), int(bool(frugal)))
+        h = C.c_void_p()
+        self.lastStatus = self.lib.bt709hip_ringset_create(arr, len(devices), int(gamma), int(bool(hasAlphaChannel)), self.width,
+                                                           self.height, self.frames, int(bool(halfScale)), int(tries), C.byref(opt),
+                                                           C.byref(h))
+        self.handle = h.value if self.lastStatus == _capi.OK else None
+        self.lanes = []
+        if not self.handle:
+            return
+        for lane in range(len(devices)):
+            ctx = MetalRenderContext(devices[lane])  # views of what the set owns: never released from here
+            ctx.lib, ctx.handle = self.lib, self.lib.bt709hip_ringset_lane_context(self.handle, lane)
+            ctx.commandQueue = CommandQueue(ctx)
+            dec = MetalBT709Decoder()
+            dec.metalRenderContext, dec._handle = ctx, self.lib.bt709hip_ringset_lane_decoder(self.handle, lane)
+            dec.hasAlphaChannel = bool(hasAlphaChannel)
+            dec.gamma = self.lib.bt709hip_decoder_get_gamma(dec._handle)
+            dec._borrowed = ctx._borrowed = True
+            ring = FrameRing(dec, size, frames, halfScale=halfScale, _handle=self.lib.bt709hip_ringset_lane_ring(self.handle, lane))
+            self.lanes.append(ring)
+
+    def decode(self, first=0, count=None, waitUntilCompleted=False):
+        """Frames [first, first + count) of EVERY lane's ring: one launch per lane, all enqueued before any is waited for."""
+        count = self.frames - first if count is None else count
+        self.lastStatus = self.lib.bt709hip_ringset_decode(self.handle, int(first), int(count), int(bool(waitUntilCompleted)))
+        return self.lastStatus == _capi.OK
+
+    def synchronize(self):
+        self.lastStatus = self.lib.bt709hip_ringset_synchronize(self.handle)
+        return self.lastStatus == _capi.OK
+
+    def release(self):
+        if self.handle:
+            for ring in self.lanes:
+                ring.handle = None
+                ring.decoder._handle = None
+                ring.ctx.handle = None
+            self.lanes = []
+            self.lib.bt709hip_ringset_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -444,7 +512,8 @@ class MetalRenderContext:
 
     def release(self):
         if self.handle:
-            self.lib.bt709hip_context_destroy(self.handle)
+            if not getattr(self, "_borrowed", False):  # a FrameRingSet lane's context belongs to the set
+                self.lib.bt709hip_context_destroy(self.handle)
             self.handle = None
 
     # -- texture helpers (MetalRenderContext.h:62-105)
@@ -794,7 +863,7 @@ class MetalBT709Decoder:
 
     def release(self):
         ctx = self.metalRenderContext
-        if self._handle and ctx is not None and ctx.handle:  # a destroyed context took the device with it
+        if self._handle and ctx is not None and ctx.handle and not getattr(self, "_borrowed", False):  # a destroyed context took the device with it; a FrameRingSet lane's decoder belongs to the set
             ctx.lib.bt709hip_decoder_destroy(self._handle)
         self._handle = None
 

@@ -553,6 +553,94 @@ def test_bench_plain_command_fails_when_a_rank_fails():
     assert r.returncode != 0 and r.stdout.strip() == "" and "no HIP device" in r.stderr
 
 
+def _plain_bench(n, extra=(), env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1", "--dry-run",
+                           *extra], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_every_rank_spot_checks_its_own_ring_and_reports_its_device(n):
+    """The one line an N-GPU run prints must verify and describe itself (the reference's test flow reads back what it decoded,
+    EmptyiOSTests/MetalBT709DecoderTests.m:189-277): every rank runs the parity spot check on its OWN ring, the line names each
+    rank's device (ordinal + PCI bus id through the C ABI) and n_gpus counts DISTINCT devices, per-rank clocks beside the MAX."""
+    r = _plain_bench(n)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.splitlines()[0])
+    assert res["parity_spot_check"] == "ok" and res["parity_spot_check_ranks"] == n
+    assert res["n_gpus"] == n and res["ranks"] == n and res["shared_devices"] is False
+    devs = res["config"]["devices"]
+    assert [d["rank"] for d in devs] == list(range(n)) and len({d["pci_bus_id"] for d in devs}) == n
+    assert [d["ordinal"] for d in devs] == list(range(n))
+    per = res["per_rank"]
+    assert [p["rank"] for p in per] == list(range(n)) and all(p["parity_spot_check"] == "ok" for p in per)
+    # value comes from the MAX over ranks: no rank's own clock is slower than the line's
+    assert max(p["ms_per_step"] for p in per) <= res["ms_per_step"] * 1.001
+    assert all(set(p["placement"]) >= {"chosen", "first_GBps", "chosen_GBps"} for p in per)
+
+
+def test_bench_a_mismatch_on_any_rank_fails_the_job():
+    """Rank 1's ring decodes wrong (forced on the dry-run path): value is null, the line says which rank, every rank exits 1."""
+    r = _plain_bench(2, env_extra={"BT709_BENCH_DRY_MISMATCH_RANK": "1"})
+    assert r.returncode != 0
+    res = json.loads(r.stdout.splitlines()[0])
+    assert res["value"] is None and res["parity_spot_check"].startswith("rank 1: MISMATCH") and res["parity_spot_check_ranks"] == 2
+    assert [p["parity_spot_check"] == "ok" for p in res["per_rank"]] == [True, False]
+    r = _plain_bench(8, env_extra={"BT709_BENCH_DRY_MISMATCH_RANK": "5"})
+    assert r.returncode != 0 and json.loads(r.stdout.splitlines()[0])["parity_spot_check"].startswith("rank 5: MISMATCH")
+
+
+def test_bench_refuses_ranks_that_wrap_onto_one_device():
+    """world > visible devices: refused (rc 2, no JSON line) unless --allow-shared-devices, and then labelled: n_gpus = the
+    DISTINCT devices, ranks = the processes (round 4 printed n_gpus 2 for two ranks on one GPU)."""
+    r = _plain_bench(2, env_extra={"BT709_BENCH_DRY_DEVICES": "1"})
+    assert r.returncode != 0 and r.stdout.strip() == "" and "--allow-shared-devices" in r.stderr
+    r = _plain_bench(2, extra=("--allow-shared-devices",), env_extra={"BT709_BENCH_DRY_DEVICES": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.splitlines()[0])
+    assert res["n_gpus"] == 1 and res["ranks"] == 2 and res["shared_devices"] is True and res["parity_spot_check_ranks"] == 2
+    assert len({d["pci_bus_id"] for d in res["config"]["devices"]}) == 1 and [d["ordinal"] for d in res["config"]["devices"]] == [0, 0]
+    r = _plain_bench(8, extra=("--allow-shared-devices",), env_extra={"BT709_BENCH_DRY_DEVICES": "4"})
+    res = json.loads(r.stdout.splitlines()[0])
+    assert res["n_gpus"] == 4 and res["ranks"] == 8 and res["shared_devices"] is True
+
+
+def test_bench_per_rank_clocks_show_a_straggler():
+    """Only the MAX over ranks makes `value`; the per-rank records tell a slow GPU from a launcher problem."""
+    r = _plain_bench(2, env_extra={"BT709_BENCH_DRY_SLOW_RANK": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.splitlines()[0])
+    fast, slow = res["per_rank"]
+    assert slow["ms_per_step"] > 1.3 * fast["ms_per_step"] and abs(res["ms_per_step"] - slow["ms_per_step"]) / res["ms_per_step"] < 0.05
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_one_process_driving_n_gpus_prints_the_same_line_shape(n):
+    """--launcher threads: ONE process, N devices (bt709hip_ringset_*; the reference's one-process shape,
+    Renderer/AAPLRenderer.m:874-985).  No ranks are started; the line has the keys of the process-per-GPU form, one per_rank /
+    config.devices record per LANE, n_gpus = the distinct devices."""
+    procs = json.loads(_plain_bench(n).stdout.splitlines()[0])
+    r = _plain_bench(n, extra=("--launcher", "threads"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.splitlines()) == 1
+    res = json.loads(r.stdout.splitlines()[0])
+    assert set(res) == set(procs) and set(res["config"]) == set(procs["config"]) and set(res["per_rank"][0]) == set(procs["per_rank"][0])
+    assert res["n_gpus"] == n and res["ranks"] == n and res["shared_devices"] is False and res["parity_spot_check_ranks"] == n
+    assert res["config"]["launcher"].startswith("threads (ONE process drives %d GPUs" % n)
+    assert [d["rank"] for d in res["config"]["devices"]] == list(range(n)) and len({d["pci_bus_id"] for d in res["config"]["devices"]}) == n
+    px = n * 5 * 256 * 3840 * 2160
+    assert abs(res["value"] - px / (res["ms_per_step"] * 5e-3) / 1e9) / res["value"] < 1e-3
+    # a lane that decodes wrong fails the job; lanes that wrap onto one device are refused unless asked for
+    r = _plain_bench(n, extra=("--launcher", "threads"), env_extra={"BT709_BENCH_DRY_MISMATCH_RANK": str(n - 1)})
+    assert r.returncode != 0 and json.loads(r.stdout.splitlines()[0])["parity_spot_check"].startswith("rank %d: MISMATCH" % (n - 1))
+    r = _plain_bench(n, extra=("--launcher", "threads"), env_extra={"BT709_BENCH_DRY_DEVICES": "1"})
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    r = _plain_bench(n, extra=("--launcher", "threads", "--allow-shared-devices"), env_extra={"BT709_BENCH_DRY_DEVICES": "1"})
+    res = json.loads(r.stdout.splitlines()[0])
+    assert res["n_gpus"] == 1 and res["ranks"] == n and res["shared_devices"] is True
+
+
 def test_bench_geometry():
     import bench
     g = bench.geometry("4k", 0, 65535)

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--out-shift", type=int, default=0, help="bytes the first output frame sits behind the start of its slab")
     ap.add_argument("--gamma", type=int, default=0, help="MetalBT709Gamma of every decoder: 0 Apple, 1 sRGB, 2 Linear, 3 ITU-709")
     ap.add_argument("--decoder-option", action="append", default=[], metavar="K=V")
+    ap.add_argument("--format", default="bgra8", choices=["bgra8", "rgba16f"], help="render target of the launches (rgba16f: 8 bytes per pixel, linear-light halves)")
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()
     W, H, RING = args.width, args.height, args.ring
@@ -68,7 +69,8 @@ def main():
         ctxs.append(h)
         decs.append(d)
     lib0, h0 = libs[0], ctxs[0]
-    yb, cb, ob = W * H, W * H // 2, W * H * 4
+    opx = 8 if args.format == "rgba16f" else 4  # bytes per output pixel
+    yb, cb, ob = W * H, W * H // 2, W * H * opx
     in_stride = (yb + cb + 255) // 256 * 256 + args.in_pad
     out_stride = ob + args.out_pad
     d_in, d_out = C.c_void_p(), C.c_void_p()
@@ -95,7 +97,7 @@ def main():
     for i in range(RING):
         b = d_in.value + i * in_stride
         frames[i] = Frame(b, W, b + yb, W, W, H, 1, {0: 1, 1: 2, 2: 3, 3: 1}[args.gamma])
-        surfs[i] = Surface(d_out.value + i * out_stride, W * 4, W, H)
+        surfs[i] = Surface(d_out.value + i * out_stride, W * opx, W, H, 1 if opx == 8 else 0, 0)
     per = args.per_launch
 
     def run(k, n):
@@ -120,7 +122,7 @@ def main():
             run(k, 1)
             lib.bt709hip_stream_synchronize(h, None)
         host = np.empty(ob, dtype=np.uint8)
-        ok(lib, lib.bt709hip_download(h, host.ctypes.data, W * 4, d_out.value + (RING - 1) * out_stride, W * 4, W * 4, H, None))
+        ok(lib, lib.bt709hip_download(h, host.ctypes.data, W * opx, d_out.value + (RING - 1) * out_stride, W * opx, W * opx, H, None))
         lib.bt709hip_stream_synchronize(h, None)
         sums.append(int(host.view(np.uint32).astype(np.uint64).sum()))
     print("output checksums equal:", len(set(sums)) == 1)
@@ -137,7 +139,7 @@ def main():
             table[k].append(args.steps * RING * W * H / (ms.value / 1e3) / 1e9)
     for p, r in zip(args.libs, table):
         med = sorted(r)[len(r) // 2]
-        print("%-52s %s  median %.1f Gpixel/s = %.4f" % (p if p.startswith("shipped") else os.path.basename(p), " ".join("%.1f" % x for x in r), med, med * 5.5 / 8000))
+        print("%-52s %s  median %.1f Gpixel/s = %.4f" % (p if p.startswith("shipped") else os.path.basename(p), " ".join("%.1f" % x for x in r), med, med * (1.5 + opx) / 8000))
 
 
 if __name__ == "__main__":

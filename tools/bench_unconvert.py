@@ -17,6 +17,8 @@ from metalbt709decoder_amd.decoder import DeviceBuffer  # noqa: E402
 
 ring = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+if len(sys.argv) > 3:  # a variant build of the library (tools/lab_variants.py); must be the first load of the process
+    _capi.load(os.path.abspath(sys.argv[3]))
 W, H = 3840, 2160
 ctx = gh.context(); lib, h = ctx.lib, ctx.handle
 dec = gh.make_decoder(mb.MetalBT709GammaApple)
