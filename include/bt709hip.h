@@ -278,8 +278,8 @@ int bt709hip_decode(bt709hip_decoder *dec,
  *   - by any bt709hip_* call that takes that stream (stream_synchronize, event_record, stream_wait_event, download, upload,
  *     memset, graph capture, copy_probe, a decode with wait_until_completed != 0, every other decode / encode / rescale
  *     entry point -- of THIS decoder or of any other decoder of the context, coalescing or not) -- so the stream keeps its
- *     order for everything issued through this API (tests/test_fake_hip.py enumerates this header's `void *stream` exports
- *     and checks each one),
+ *     order for everything issued through this API (a CPU test parses this header's `void *stream` exports and checks
+ *     each one of them),
  *   - by bt709hip_decoder_flush, and when the decoder is destroyed or the option is turned off.
  * There is no timer thread: a queue is only ever issued from inside a bt709hip_* call.  A caller that may go idle with frames
  * queued either flushes before it does, or sets BT709HIP_OPT_COALESCE_MAX_AGE_US, which bounds the wait by the time to the
@@ -405,8 +405,9 @@ int bt709hip_pool_release(bt709hip_pool *pool, int slot);
  * all look alike -- then every input with the `tries` fastest outputs, then the three best pairings and the first-allocated
  * one again, six times as long), keeps the fastest pairing and frees the rest.  TRANSIENT FOOTPRINT: every candidate is device
  * memory held until the choice is made -- unbounded that is up to 6 input + 18 output slabs (172 GB for a 256-frame 4K ring) --
- * so the hunt runs under a BUDGET (bt709hip_ring_options): by default it never holds more than HALF of the memory that was free
- * at the call (ring included) and always leaves 4 GiB of the device free; when a new candidate does not fit, the slowest slab
+ * so the hunt runs under a BUDGET (bt709hip_ring_options): by default it never holds more than FOUR TIMES the ring (47 GB for that
+ * ring; measured to choose as well as holding everything, profiles/r05_hunt_budget.txt) nor more than half of the memory that was
+ * free at the call, ring included, and always leaves 4 GiB of the device free; when a new candidate does not fit, the slowest slab
  * seen so far is freed first (the fastest ones stay for the pairing probes), down to the incumbent pair + one candidate.  The
  * duration and the peak footprint are reported (hunt_ms, peak_bytes).  Set-up cost: 1-2 s for a 12 GB ring.  half_scale != 0: outputs are (W/2) x (H/2) and the ring decodes
  * through bt709hip_decode_half_batch.  A decoder with an alpha channel gets an alpha plane per frame (third plane of the
@@ -432,8 +433,8 @@ typedef struct {
 } bt709hip_ring_placement;
 /* Budget of the placement hunt.  A zeroed struct (or NULL) = the defaults. */
 typedef struct {
-  uint64_t max_bytes;   /* most device memory the call may hold at once, the ring's two slabs included; 0 = half of the memory free
-                           at the call.  A budget that cannot hold the ring plus one more slab leaves nothing to compare: the ring
+  uint64_t max_bytes;   /* most device memory the call may hold at once, the ring's two slabs included; 0 = four times the ring,
+                           at most half of the memory free at the call.  A budget that cannot hold the ring plus one more slab leaves nothing to compare: the ring
                            is then allocated without a hunt */
   uint32_t max_ms;      /* wall-clock budget of the hunt in milliseconds (checked before every probe); 0 = none */
   int32_t frugal;       /* != 0: max_bytes = the ring + ONE candidate pair, whatever is free: the incumbent pair and the pair being

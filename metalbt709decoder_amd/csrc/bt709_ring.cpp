@@ -203,14 +203,18 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   tries = std::min(tries, kMaxTries);
   if (in_bytes + out_bytes < kHuntMinBytes) tries = 1;
 
-  // THE BUDGET.  Default: half of what is free now (a second process on the device, or this one's next ring, still finds room
-  // while the hunt runs); frugal: the incumbent pair + one candidate pair.  A budget that cannot hold the ring and one more
+  // THE BUDGET.  Default: four rings' worth, at most half of what is free now (a second process on the device, or this one's
+  // next ring, still finds room while the hunt runs); frugal: the incumbent pair + one candidate pair.  A budget that cannot hold the ring and one more
   // output slab leaves nothing to compare.
   Ledger led{ctx};
   {
     size_t free_b = 0;
     if (bt709hip_mem_info(ctx, &free_b, nullptr) != BT709HIP_OK) free_b = 0;
-    size_t budget = options != nullptr && options->max_bytes != 0 ? static_cast<size_t>(options->max_bytes) : free_b / 2;
+    // default: four times the ring, never more than half of what is free (round 5, profiles/r05_hunt_budget.txt: the 11.7 GB 4K
+    // ring hunted within 23 / 32 / 64 GB lands at 0.806-0.814 / 0.802-0.811 / 0.811-0.812 of the roofline, within 148 GB -- round
+    // 4's behaviour -- at 0.811: free + allocate hands out other physical pages, holding every candidate buys nothing)
+    size_t budget = options != nullptr && options->max_bytes != 0 ? static_cast<size_t>(options->max_bytes)
+                                                                   : std::min(free_b / 2, 4 * (in_bytes + out_bytes));
     if (options != nullptr && options->frugal) budget = 2 * (in_bytes + out_bytes);
     if (tries > 1 && budget < in_bytes + 2 * out_bytes) {
       tries = 1;
@@ -227,9 +231,9 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   // rate by ~1 % -- but never more than a quarter of the budget, and always leaving room for two outputs.
   std::vector<Slab> ins, outs;
   {
-    int n_in = tries;
-    while (n_in > 1 && (static_cast<size_t>(n_in) * in_bytes > led.budget / 4 || static_cast<size_t>(n_in) * in_bytes + 2 * out_bytes > led.budget)) --n_in;
-    if (options != nullptr && options->frugal) n_in = std::min(n_in, 2);
+    const bool frugal = options != nullptr && options->frugal;
+    int n_in = frugal ? std::min(tries, 2) : tries;
+    while (n_in > 1 && ((!frugal && static_cast<size_t>(n_in) * in_bytes > led.budget / 4) || static_cast<size_t>(n_in) * in_bytes + 2 * out_bytes > led.budget)) --n_in;
     for (int i = 0; i < n_in; ++i) {
       if (i > 0 && !led.fits(in_bytes + out_bytes)) break;
       void *p = led.take(in_bytes);

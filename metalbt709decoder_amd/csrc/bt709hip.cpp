@@ -69,18 +69,20 @@ struct bt709hip_decoder {
   bt709hip_context *ctx = nullptr;
   int gamma = BT709HIP_GAMMA_APPLE;
   int has_alpha = 0;
-  uint32_t alpha_fill = 0xFF;
-  bool nontemporal = true;  // BT709HIP_OPT_NONTEMPORAL
-  int half_rep = -1;        // BT709HIP_OPT_HALF_KERNEL: persistent conflict-free rescale kernel: -1 = when the launch is large enough, 0 never, 1 always
-  int half_workgroups = 0;  // BT709HIP_OPT_HALF_WORKGROUPS: 0 = one per compute unit
-  int half_lds_kb = 0;      // BT709HIP_OPT_HALF_LDS_KB: 0 = all 160
-  int xcd_bands = 1;        // BT709HIP_OPT_XCD_BANDS: XCD-aware work map of the batched 1:1 kernels (frames a multiple of 8)
-  int coalesce = 0;         // BT709HIP_OPT_COALESCE: 0 off, else frames gathered per launch (2..32)
-  int coalesce_max_age_us = 0;  // BT709HIP_OPT_COALESCE_MAX_AGE_US: 0 = no age limit
+  // Options: atomics, because a thread may change one while others are inside a decode (tests/native/shim_stress.cpp does, under
+  // TSan); a call reads each option once and runs with what it read.
+  std::atomic<uint32_t> alpha_fill{0xFF};
+  std::atomic<bool> nontemporal{true};  // BT709HIP_OPT_NONTEMPORAL
+  std::atomic<int> half_rep{-1};        // BT709HIP_OPT_HALF_KERNEL: persistent conflict-free rescale kernel: -1 = when the launch is large enough, 0 never, 1 always
+  std::atomic<int> half_workgroups{0};  // BT709HIP_OPT_HALF_WORKGROUPS: 0 = one per compute unit
+  std::atomic<int> half_lds_kb{0};      // BT709HIP_OPT_HALF_LDS_KB: 0 = all 160
+  std::atomic<int> xcd_bands{1};        // BT709HIP_OPT_XCD_BANDS: XCD-aware work map of the batched 1:1 kernels (frames a multiple of 8)
+  std::atomic<int> coalesce{0};         // BT709HIP_OPT_COALESCE: 0 off, else frames gathered per launch (2..32)
+  std::atomic<int> coalesce_max_age_us{0};  // BT709HIP_OPT_COALESCE_MAX_AGE_US: 0 = no age limit
   std::mutex queue_mutex;   // guards queues
   std::vector<PendingQueue> queues;  // one per stream that has (had) queued frames
   std::mutex setup_mutex;
-  bool ready = false;
+  std::atomic<bool> ready{false};  // release-stored after the tables below are published, acquire-loaded by every decode
   // device copies (transfer_tables.h)
   uint32_t table_n = 0;            // bucket count N of the decoder's gamma
   void *d_table_unit = nullptr;    // TransferBucket[N + 1] (decode kernels)
@@ -95,7 +97,7 @@ struct bt709hip_decoder {
   uint32_t encode_u_bytes = 0, encode_u_n = 0;
   // RGBA16F targets: threshold table of the half-float composite (transfer_tables.h HalfTable), built on
   // first use under setup_mutex; half.table_bytes == 0 with half_ready: the gamma has no curve
-  bool half_ready = false;
+  bool half_ready = false;  // under setup_mutex
   HalfParams half = {};
 };
 
@@ -214,7 +216,7 @@ bool capturing(hipStream_t s) {
 // -decodeBT709 calls -setupMetal first (.m:228-231).  The first setup allocates and copies, which a
 // recording stream must not see: set the decoder up before bt709hip_graph_begin_capture.
 int ensure_setup(bt709hip_decoder *dec, void *stream) {
-  if (dec->ready) return BT709HIP_OK;  // benign race: setup itself is serialised by its mutex
+  if (dec->ready.load(std::memory_order_acquire)) return BT709HIP_OK;  // setup itself is serialised by its mutex
   if (dec->ctx != nullptr && capturing(static_cast<hipStream_t>(stream))) return BT709HIP_ERR_NOT_SETUP;
   return bt709hip_decoder_setup(dec);
 }
@@ -388,16 +390,34 @@ int flush_stream(bt709hip_context *ctx, hipStream_t s, const bt709hip_decoder *s
       if (int _rc = flush_stream((ctx), pick((ctx), (stream)))) return _rc;              \
   } while (0)
 
-void set_coalescing(bt709hip_decoder *dec, int n) {
+// Turns the coalescing submit of `dec` on (n > 1), off (0) or changes its count.  Order matters when other threads are inside a
+// decode: ON registers the decoder with its context BEFORE the count becomes visible (a frame queued from then on is seen by
+// every flush_stream), OFF issues what is queued and clears the count under the queue_mutex -- a submit that is waiting for that
+// mutex re-reads the count behind it and launches instead of queueing -- and only then leaves the context's list.  Lock order:
+// the context's coalescing_mutex and a decoder's queue_mutex are never held together here.  Returns the flush's status.
+int set_coalescing(bt709hip_decoder *dec, int n) {
   bt709hip_context *ctx = dec->ctx;
-  const bool was = dec->coalesce > 1, now = n > 1;
-  dec->coalesce = n;
-  if (ctx == nullptr || was == now) return;
-  std::lock_guard<std::mutex> lock(ctx->coalescing_mutex);
-  auto it = std::find(ctx->coalescing.begin(), ctx->coalescing.end(), dec);
-  if (now && it == ctx->coalescing.end()) ctx->coalescing.push_back(dec);
-  if (!now && it != ctx->coalescing.end()) ctx->coalescing.erase(it);
-  ctx->n_coalescing.store(static_cast<int>(ctx->coalescing.size()), std::memory_order_release);
+  const bool now = n > 1;
+  if (now && ctx != nullptr) {
+    std::lock_guard<std::mutex> lock(ctx->coalescing_mutex);
+    if (std::find(ctx->coalescing.begin(), ctx->coalescing.end(), dec) == ctx->coalescing.end()) ctx->coalescing.push_back(dec);
+    ctx->n_coalescing.store(static_cast<int>(ctx->coalescing.size()), std::memory_order_release);
+  }
+  int rc = BT709HIP_OK;
+  {
+    std::lock_guard<std::mutex> lock(dec->queue_mutex);
+    if (!now)  // off: nothing may stay queued behind the switch
+      for (PendingQueue &q : dec->queues)
+        if (int e = issue_queue(dec, q)) rc = rc ? rc : e;
+    dec->coalesce.store(now ? n : 0);
+  }
+  if (!now && ctx != nullptr) {
+    std::lock_guard<std::mutex> lock(ctx->coalescing_mutex);
+    auto it = std::find(ctx->coalescing.begin(), ctx->coalescing.end(), dec);
+    if (it != ctx->coalescing.end()) ctx->coalescing.erase(it);
+    ctx->n_coalescing.store(static_cast<int>(ctx->coalescing.size()), std::memory_order_release);
+  }
+  return rc;
 }
 
 }  // namespace
@@ -731,10 +751,10 @@ int bt709hip_decoder_create(bt709hip_context *ctx, int gamma, int has_alpha, bt7
 
 int bt709hip_decoder_destroy(bt709hip_decoder *dec) {
   if (dec == nullptr) return BT709HIP_OK;
-  if (dec->coalesce > 1) {  // queued frames go out; the context forgets the decoder
-    if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) (void)flush_decoder(dec, nullptr, true);
-    set_coalescing(dec, 0);
-  }
+  // queued frames go out; the context forgets the decoder (under its coalescing_mutex: a flush_stream that is walking the list
+  // right now finishes first)
+  if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) != hipSuccess) (void)hipGetLastError();
+  (void)set_coalescing(dec, 0);
   if (dec->ctx != nullptr && hipSetDevice(dec->ctx->device) == hipSuccess) {
     if (dec->d_table_unit) (void)hipFree(dec->d_table_unit);
     if (dec->d_table_linear) (void)hipFree(dec->d_table_linear);
@@ -751,9 +771,9 @@ int bt709hip_decoder_set_context(bt709hip_decoder *dec, bt709hip_context *ctx) {
   std::lock_guard<std::mutex> lock(dec->setup_mutex);
   if (dec->ready) return dec->ctx == ctx ? BT709HIP_OK : BT709HIP_ERR_INVALID_ARG;
   const int n = dec->coalesce;
-  set_coalescing(dec, 0);  // registered with the context it belongs to
+  (void)set_coalescing(dec, 0);  // registered with the context it belongs to
   dec->ctx = ctx;
-  set_coalescing(dec, n);
+  (void)set_coalescing(dec, n);
   return BT709HIP_OK;
 }
 
@@ -774,14 +794,14 @@ bt709hip_context *bt709hip_decoder_context(const bt709hip_decoder *dec) { return
 
 int bt709hip_decoder_flush(bt709hip_decoder *dec, void *stream) {
   if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
-  if (dec->coalesce <= 1 || dec->ctx == nullptr) return BT709HIP_OK;
+  if (dec->ctx == nullptr) return BT709HIP_OK;  // never had a stream to queue on
   if (int rc = bind(dec->ctx)) return rc;
   return flush_decoder(dec, pick(dec->ctx, stream), false);
 }
 
 int bt709hip_decoder_flush_all(bt709hip_decoder *dec) {
   if (dec == nullptr) return BT709HIP_ERR_INVALID_ARG;
-  if (dec->coalesce <= 1 || dec->ctx == nullptr) return BT709HIP_OK;
+  if (dec->ctx == nullptr) return BT709HIP_OK;
   if (int rc = bind(dec->ctx)) return rc;
   return flush_decoder(dec, nullptr, true);
 }
@@ -795,7 +815,7 @@ int bt709hip_decoder_set_option(bt709hip_decoder *dec, int option, int value) {
     case BT709HIP_OPT_HALF_WORKGROUPS: dec->half_workgroups = clamp_int(value, 0, 1 << 20); return BT709HIP_OK;
     case BT709HIP_OPT_HALF_LDS_KB: dec->half_lds_kb = clamp_int(value, 0, 160); return BT709HIP_OK;
     case BT709HIP_OPT_XCD_BANDS: dec->xcd_bands = clamp_int(value, 0, 2); return BT709HIP_OK;
-    case BT709HIP_OPT_COALESCE: set_coalescing(dec, value <= 1 ? 0 : clamp_int(value, 2, kMaxBatch)); return BT709HIP_OK;
+    case BT709HIP_OPT_COALESCE: return set_coalescing(dec, value <= 1 ? 0 : clamp_int(value, 2, kMaxBatch));
     case BT709HIP_OPT_COALESCE_MAX_AGE_US: dec->coalesce_max_age_us = value < 0 ? 0 : value; return BT709HIP_OK;
     default: return BT709HIP_ERR_INVALID_ARG;
   }
@@ -854,10 +874,11 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   dec->d_table_unit = d_unit;
   dec->d_table_linear = d_linear;
   dec->d_encode = d_enc;
-  dec->ready = true;
+  dec->ready.store(true, std::memory_order_release);
   return BT709HIP_OK;
 }
 
+extern "C++" {  // helpers with C++ linkage inside the C-ABI block
 namespace {
 
 enum class OutShape { kSame, kHalf, kAny };  // output size relative to the frame: pass 1 / exact 2:1 / view-fit
@@ -953,7 +974,9 @@ int finish_launch(hipStream_t s, int wait_until_completed) {
 }
 
 }  // namespace
+}  // extern "C++"
 
+extern "C++" {  // helpers with C++ linkage inside the C-ABI block
 namespace {
 
 // the launch itself (no queueing)
@@ -1004,7 +1027,8 @@ int coalescing_submit(bt709hip_decoder *dec, int count, const bt709hip_frame *fr
   }
   for (PendingQueue &c : dec->queues)
     if (c.stream == s) q = &c;
-  const bool eligible = wait_until_completed == 0 && count >= 1 && count < dec->coalesce && frames != nullptr && outs != nullptr;
+  const int n = dec->coalesce.load();  // read ONCE, behind the mutex: set_coalescing changes it under the same mutex
+  const bool eligible = n > 1 && wait_until_completed == 0 && count >= 1 && count < n && frames != nullptr && outs != nullptr;
   if (!eligible) {  // in stream order: what is queued goes first
     if (q != nullptr)
       if (int rc = issue_queue(dec, *q)) return rc;
@@ -1022,7 +1046,7 @@ int coalescing_submit(bt709hip_decoder *dec, int count, const bt709hip_frame *fr
     q->stream = s;
   }
   if (!q->frames.empty()) {
-    const bool fits = q->frames.size() + static_cast<size_t>(count) <= static_cast<size_t>(dec->coalesce) &&
+    const bool fits = q->frames.size() + static_cast<size_t>(count) <= static_cast<size_t>(n) &&
                       same_shape(q->frames[0], frames[0]) && q->frames[0].transfer == frames[0].transfer &&
                       q->outs[0].stride == outs[0].stride && q->outs[0].format == outs[0].format &&
                       q->with_alphas == (alphas != nullptr) && (alphas == nullptr || q->alphas[0].y_stride == alphas[0].y_stride);
@@ -1035,11 +1059,12 @@ int coalescing_submit(bt709hip_decoder *dec, int count, const bt709hip_frame *fr
   if (alphas != nullptr) q->alphas.insert(q->alphas.end(), alphas, alphas + count);
   q->outs.insert(q->outs.end(), outs, outs + count);
   tl_kernel_name = "(queued: coalescing submit)";
-  if (q->frames.size() >= static_cast<size_t>(dec->coalesce)) return issue_queue(dec, *q);
+  if (q->frames.size() >= static_cast<size_t>(n)) return issue_queue(dec, *q);
   return BT709HIP_OK;
 }
 
 }  // namespace
+}  // extern "C++"
 
 int bt709hip_decode_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,
                           const bt709hip_frame *alphas, const bt709hip_surface *outs, void *stream,
@@ -1161,6 +1186,7 @@ int bt709hip_decoder_prepare_format(bt709hip_decoder *dec, int format) {
   return ensure_half_table(dec, nullptr);
 }
 
+extern "C++" {  // helpers with C++ linkage inside the C-ABI block
 namespace {
 
 // Tables of the stand-alone pass 2, built once per context: the two-resolution sRGB-encode buckets
@@ -1192,6 +1218,7 @@ int render_tables(bt709hip_context *ctx, hipStream_t s) {
 }
 
 }  // namespace
+}  // extern "C++"
 
 int bt709hip_render_scaled_prepare(bt709hip_context *ctx) {
   if (int rc = bind(ctx)) return rc;
@@ -1291,6 +1318,7 @@ int bt709hip_pool_destroy(bt709hip_pool *pool) {
   return BT709HIP_OK;
 }
 
+extern "C++" {  // helpers with C++ linkage inside the C-ABI block
 namespace {
 // Device buffers the library allocates for itself (in-flight pool slots, hence the sharder's lanes): anything of 256 MB or
 // more streams from HBM, where placement matters, and goes through the placement-aware allocator with the
@@ -1307,6 +1335,7 @@ hipError_t alloc_pool_buffer(bt709hip_context *ctx, size_t bytes, uint8_t **out)
   return hipMalloc(reinterpret_cast<void **>(out), bytes);
 }
 }  // namespace
+}  // extern "C++"
 
 int bt709hip_pool_create(bt709hip_decoder *dec, int width, int height, int depth, bt709hip_pool **out) {
   if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
@@ -1856,6 +1885,7 @@ int bt709hip_gamma_lookup(int gamma, float x, int *bucket_count, int *bucket_ind
   return static_cast<int>(b.base + (x >= b.edge ? 1u : 0u));
 }
 
+extern "C++" {  // helpers with C++ linkage inside the C-ABI block
 namespace {
 const HalfTable *host_half_table(int gamma) {
   static std::mutex mutex;
@@ -1870,6 +1900,7 @@ const HalfTable *host_half_table(int gamma) {
   return &tables[gamma];
 }
 }  // namespace
+}  // extern "C++"
 
 int bt709hip_half_thresholds(int gamma, float *thresholds, int capacity) {
   const HalfTable *t = host_half_table(gamma);
