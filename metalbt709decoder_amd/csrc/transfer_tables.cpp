@@ -248,14 +248,20 @@ bool build_half_table(int gamma, HalfTable *out) {
   }
   out->thresholds.push_back(inf);  // T[h_max + 1]
   while (out->thresholds.size() % 4 != 0) out->thresholds.push_back(inf);
-  // candidate tangents (transfer_tables.h): in double from the curve's constants, biased down by 2^-20, rounded to float
+  // candidate tangents (transfer_tables.h), slope / intercept form: p(x) = slope * x + intercept is the tangent of the curve at
+  // x_q scaled by `keep` = 1 - 2^-19.  Computed in double from the curve's constants; both floats are then moved one step
+  // toward a SMALLER p (the slope is positive and x > 0: down; the intercept: down), so that neither their rounding, nor the
+  // fma's own, nor the reference's float steps can lift p above the true value (tests/native/half_candidate_sweep.cpp checks
+  // every float from the split to 1.0).
   out->cand.clear();
-  const double a = out->pre_add, s = out->pre_scale, g = out->exponent, keep = 1.0 - 1.0 / 1048576.0;
+  const double a = out->pre_add, s = out->pre_scale, g = out->exponent, keep = 1.0 - 1.0 / 524288.0;
+  const float ninf = -std::numeric_limits<float>::infinity();
   for (uint32_t k = kHalfCandFirst; k < kHalfCandFirst + kHalfCandCount; ++k) {
     const double xq = from_bits(k << 16);
     const double base = (xq + a) * s;
-    out->cand.push_back(static_cast<float>(std::pow(base, g) * keep));
-    out->cand.push_back(static_cast<float>(g * s * std::pow(base, g - 1.0) * keep));
+    const double value = std::pow(base, g) * keep, slope = g * s * std::pow(base, g - 1.0) * keep;
+    out->cand.push_back(std::nextafter(static_cast<float>(value - slope * xq), ninf));
+    out->cand.push_back(std::nextafter(static_cast<float>(slope), ninf));
   }
   return true;
 }
@@ -263,8 +269,7 @@ bool build_half_table(int gamma, HalfTable *out) {
 float half_candidate(const HalfTable &t, float x) {
   const uint32_t xb = to_bits(x), k = xb >> 16;
   if (t.cand.empty() || k < kHalfCandFirst || k >= kHalfCandFirst + kHalfCandCount) return 0.0f;
-  volatile float dx = x - from_bits(xb & 0xffff0000u);  // exact
-  volatile float p = std::fmaf(dx, t.cand[2 * (k - kHalfCandFirst) + 1], t.cand[2 * (k - kHalfCandFirst)]);
+  volatile float p = std::fmaf(x, t.cand[2 * (k - kHalfCandFirst) + 1], t.cand[2 * (k - kHalfCandFirst)]);  // the kernel's one v_fma_f32
   return p;
 }
 

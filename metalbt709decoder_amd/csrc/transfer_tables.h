@@ -148,12 +148,13 @@ bool build_uniform_table(int kind, uint32_t n_min, UniformTable *out);
 // T is indexed by the OUTPUT code, so it holds exactly one entry per step (8-9 k entries, ~34 KiB).
 // The candidate (round 4; rounds 2-3 took it from v_log_f32 / v_exp_f32, two quarter-rate instructions per channel):
 // the TANGENT of the curve at the start of x's bucket, buckets = the floats that share x's exponent and top 7 mantissa
-// bits (index = bits(x) >> 16, kHalfCandFirst .. bits(1.0f) >> 16: 641 entries {value, slope} from 2^-5 to 1.0):
-//     p = value + (x - x_q) * slope,   x_q = x with the low 16 bits cleared (the subtraction is exact)
+// bits (index = bits(x) >> 16, kHalfCandFirst .. bits(1.0f) >> 16: 641 entries {intercept, slope} from 2^-5 to 1.0):
+//     p = slope * x + intercept = value(x_q) + (x - x_q) * slope,   x_q = x with the low 16 bits cleared; ONE fma (round 5;
+//     round 4 subtracted x_q first)
 // The curves are convex powers, so the tangent lies BELOW the curve, by at most g(g-1)/2 * 2^-14 = 1.0e-4 of the value
-// (g <= 2.4) at the far end of a bucket -- a fifth of a half's spacing (2^-11 of the value) -- and value and slope carry a
-// further factor 1 - 2^-20 so that neither their rounding nor the reference's own float steps can lift p above the true
-// value: half(p) is H or H - 1, never H + 1.
+// (g <= 2.4) at the far end of a bucket -- a fifth of a half's spacing (2^-11 of the value) -- and intercept and slope carry a
+// further factor 1 - 2^-19 and are rounded toward a smaller p, so that neither their rounding, the fma's, nor the reference's
+// own float steps can lift p above the true value: half(p) is H or H - 1, never H + 1.
 struct HalfTable {
   int gamma = 0;
   float split = 0.0f;      // x < split: H(x) = half(x * low_scale) (exact product); kGammaLinear: split = 2 (always)
@@ -163,7 +164,7 @@ struct HalfTable {
   uint32_t h_min = 0;      // H(split): first code the table covers
   // T[i] = smallest x with H(x) >= h_min + i (T[0] may lie below the split); one +inf entry past H(1.0); padded to 16 bytes
   std::vector<float> thresholds;
-  // candidate tangents: {value, slope} of bucket k = kHalfCandFirst + i (x_q = the float with bits k << 16); empty without a curve
+  // candidate tangents: {intercept, slope} of bucket k = kHalfCandFirst + i (x_q = the float with bits k << 16); empty without a curve
   std::vector<float> cand;
 };
 constexpr uint32_t kHalfCandFirst = 0x3d00u;                     // bits(2^-5) >> 16: below every curve's split point

@@ -310,11 +310,16 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
     for kernel in ("17decode_nv12_quads", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
                    "18decode_nv12_scaled", "19decode_nv12_rgba16fILi0E", "19decode_nv12_rgba16fILi1E", "13render_scaled"):
         # RGBA16F curve variant: the half CANDIDATE (bt709_rgba16f.hip half_code; not reference arithmetic -- the threshold
-        # table settles it, and tests/test_rgba16f.py sweeps it over every float) is the tangent value + (x - x_q) * slope:
-        # one fma with three REGISTER operands per channel, 4 pixels x 3 channels, nothing else.  Round 4 took the
-        # quarter-rate v_log_f32 / v_exp_f32 out of the kernel.
-        candidate_fmas = {"19decode_nv12_rgba16fILi1E": 12}.get(kernel, 0)
+        # table settles it, and tests/test_rgba16f.py sweeps it over every float) is the tangent slope * x + intercept:
+        # one fma with three REGISTER operands per channel, 4 pixels x 3 channels per 2x2 block, NB x RP blocks per lane
+        # (round 5: the two shipped shapes, template arguments 4 and 5), nothing else.  Round 4 took the quarter-rate
+        # v_log_f32 / v_exp_f32 out of the kernel.
         for body in _kernel_bodies(asm, kernel):
+            candidate_fmas = 0
+            if kernel == "19decode_nv12_rgba16fILi1E":
+                nb, rp = map(int, re.search(r"19decode_nv12_rgba16fILi1ELb[01]ELb[01]ELi(\d+)ELi(\d+)EE", body).groups())
+                assert (nb, rp) in ((4, 2), (2, 3))
+                candidate_fmas = 12 * nb * rp
             candidate = 0
             for line in re.findall(r"^\s*(v_(?:pk_)?(?:fma|fmac|fmamk|fmaak|mad|mac|madmk|madak)_(?:f32|f16|legacy|mix)\w*\s[^\n]*)", body, flags=re.M):
                 if candidate_fmas and re.match(r"v_fmac_f32_e32 v\d+, v\d+, v\d+$|v_fma_f32 v\d+, v\d+, v\d+, v\d+$", line.strip()):
@@ -328,7 +333,7 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
             assert candidate == candidate_fmas, (kernel, candidate)
             assert not re.search(r"\bv_(log|exp)_f32", body), kernel  # no transcendental left in any decode kernel
             n += 1
-    assert n == 35  # every instantiation the launchers can pick (round 4: the RGBA16F kernel has one curve form, not two)
+    assert n == 43  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in two shapes)
     assert fused > 300
 
 

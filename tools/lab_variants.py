@@ -26,7 +26,6 @@ Gates (macro -> what it does; profiles/ file it produced):
   BT709_LAB_HALF_TABLE    2:1 kernel, WRONG OUTPUT: half-size decode-side table                     r03_ab_half_table.txt
   BT709_LAB_F16_NO_ARITH  RGBA16F kernel, WRONG OUTPUT: loads + stores, no lookups (_NO_TABLE: no staging)   r05_ab_rgba16f_ceiling.txt
   BT709_LAB_F16_CVT_ONLY  RGBA16F kernel, WRONG OUTPUT: matrix + conversion, no candidate / settlement      r05_ab_rgba16f_ceiling.txt
-  BT709_LAB_F16_NO_SETTLE RGBA16F kernel, WRONG OUTPUT: the candidate's half, no threshold read             r05_ab_rgba16f_ceiling.txt
   BT709_LAB_ENC_NO_ARITH  encoder, WRONG OUTPUT: loads + stores only                                         r05_ab_encode_ceiling.txt
   BT709_LAB_UNC_NO_ARITH  +unconvert: kernel, WRONG OUTPUT: loads + stores only                              r05_ab_unconvert_ceiling.txt
 """
@@ -214,40 +213,43 @@ constexpr bool kRepUniformEncode = true;
   const uint64_t kRepLdsBytes ="""),
     # ---- round 5: traffic-pattern ceilings of the kernels that claim to be memory-bound below 0.75 (VERDICT r4, Missing 4)
     ("bt709_rgba16f.hip",
-     """  if (HAS_TABLE) stage_table(lds_raw, hp.table, hp.table_bytes);  // the device copy starts with the guard entry T[h_min - 1]
+     """    stage_table(lds_raw, hp.table, hp.table_bytes);  // after the tile's loads are in flight; the device copy starts with the guard entry T[h_min - 1]
 """,
      """#if !defined(BT709_LAB_F16_NO_TABLE)  // with BT709_LAB_F16_NO_ARITH / _CVT_ONLY: without the per-workgroup table staging too
-  if (HAS_TABLE) stage_table(lds_raw, hp.table, hp.table_bytes);
+    stage_table(lds_raw, hp.table, hp.table_bytes);
 #endif
 """),
     ("bt709_rgba16f.hip",
-     """  if (!HAS_TABLE) return half_bits(lowv);
+     """  if (!HAS_TABLE) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) h[i] = half_code<false>(t, x[i]);
+    return;
+  }
 """,
      """#if defined(BT709_LAB_F16_CVT_ONLY)  // WRONG OUTPUT: the conversion alone, no candidate, no settlement (matrix + v_cvt_f16_f32)
-  return half_bits(lowv);
-#endif
-  if (!HAS_TABLE) return half_bits(lowv);
-"""),
-    ("bt709_rgba16f.hip",
-     """  return h0 + (x >= e[1] ? 1u : 0u);
-}
-""",
-     """#if defined(BT709_LAB_F16_NO_SETTLE)  // WRONG OUTPUT: the candidate's half as it is, no threshold read
-  return h0 + (e == nullptr ? 1u : 0u);
+  if (true) {
 #else
-  return h0 + (x >= e[1] ? 1u : 0u);
+  if (!HAS_TABLE) {
 #endif
-}
+#pragma unroll
+    for (int i = 0; i < N; ++i) h[i] = half_code<false>(t, x[i]);
+    return;
+  }
 """),
     ("bt709_rgba16f.hip",
-     """      const uint32_t hr = half_code<HAS_TABLE>(t, r), hg = half_code<HAS_TABLE>(t, g), hb = half_code<HAS_TABLE>(t, b);
-""",
+     """      if constexpr (kF16Batch >= 12) {
+        half_codes<HAS_TABLE, 12>(t, x, hc);
+      } else {""",
      """#if defined(BT709_LAB_F16_NO_ARITH)  // WRONG OUTPUT: the launch's loads and stores with (almost) no arithmetic
-      const uint32_t hr = __float_as_uint(r) & 0xffffu, hg = __float_as_uint(yv[px]) & 0xffffu, hb = __float_as_uint(cb) & 0xffffu;
+      if constexpr (true) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) hc[i] = __float_as_uint(x[i]) & 0xffffu;
+      } else if constexpr (kF16Batch >= 12) {
 #else
-      const uint32_t hr = half_code<HAS_TABLE>(t, r), hg = half_code<HAS_TABLE>(t, g), hb = half_code<HAS_TABLE>(t, b);
+      if constexpr (kF16Batch >= 12) {
 #endif
-"""),
+        half_codes<HAS_TABLE, 12>(t, x, hc);
+      } else {"""),
     ("bt709_encode.hip",
      """    uint32_t ytop, ybot, cbcr;
     quantize_quad(va, vb, ytop, ybot, cbcr);
@@ -303,7 +305,7 @@ constexpr bool kRepUniformEncode = true;
 MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT709_LAB_NO_TABLE", "BT709_NO_FMA_CENTRE",
           "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
           "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE", "BT709_LAB_F16_NO_ARITH", "BT709_LAB_F16_NO_TABLE",
-          "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_SETTLE", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH"]
+          "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH"]
 
 
 def make_lab_sources(dst=LAB_SRC):
