@@ -383,6 +383,14 @@ class MetalBT709Decoder {
     return rc == BT709HIP_OK ? ok() : fail(rc);
   }
 
+  // The coalescing submit (include/bt709hip.h BT709HIP_OPT_COALESCE): keep the reference's one-decodeBT709-call-per-frame cadence
+  // on device-resident frames and let `frames` (2..32; 0 = off) queued calls go out as one launch; maxAgeMicroseconds > 0: a queue
+  // older than that is issued by the context's next call on ANY stream (BT709HIP_OPT_COALESCE_MAX_AGE_US), so an idle caller's
+  // frames do not wait for ever.
+  bool setCoalescing(int frames, int maxAgeMicroseconds = 0) {
+    return setOption(BT709HIP_OPT_COALESCE_MAX_AGE_US, maxAgeMicroseconds) && setOption(BT709HIP_OPT_COALESCE, frames);
+  }
+
   bt709hip_decoder *handle() const { return dec_; }
 
  private:

@@ -196,7 +196,7 @@ static int run_ring_vectors(MetalBT709Decoder &metalDecoder, int argc, char **ar
   if (!ring.decode(0, n, true)) return 3;
   check_all("one launch");
   if (!ring.clearOutputs()) return 3;  // the second pass must write every pixel again
-  if (!metalDecoder.setOption(BT709HIP_OPT_COALESCE, 4)) return 3;
+  if (!metalDecoder.setCoalescing(4, 500)) return 3;
   for (int v = 0; v < n; ++v)
     if (!ring.decodeFrame(v, false)) ++failures;
   check_all("coalesced one-frame calls");

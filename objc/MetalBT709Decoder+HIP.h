@@ -11,6 +11,15 @@
 // (3, AAPLRenderer.m:34) frames stay in flight on their own HIP streams; the caller invokes -finishHIPFrames before
 // [commandBuffer commit].
 @property (nonatomic, assign) BOOL hipDeferredCompletion;
+// The coalescing submit of the HIP decoder (include/bt709hip.h BT709HIP_OPT_COALESCE / _COALESCE_MAX_AGE_US), for a caller that
+// hands this decoder DEVICE-resident frames through its bt709hip handle (hipDecoderHandle) at the reference's one-call-per-frame
+// cadence: n = 2..32 frames gathered per launch (0 = off, the default), and the age in microseconds after which a queue is issued
+// by the context's next call on any stream (0 = no limit).  Host-memory frames -- this class's own selector -- gain nothing: each
+// goes through an in-flight pool slot with a stream of its own and is PCIe-bound.  Set before -setupMetal or at any time after.
+@property (nonatomic, assign) int hipCoalesceFrames;
+@property (nonatomic, assign) int hipCoalesceMaxAgeMicroseconds;
+// The bt709hip_decoder behind this object (NULL before -setupMetal), as a void * so that this header needs no bt709hip.h.
+- (void *) hipDecoderHandle;
 // Completes every frame still in flight: their pixels are copied into the textures passed with them.  Same thread
 // as -decodeBT709:... (the in-flight pool is single-threaded).
 - (BOOL) finishHIPFrames;

@@ -10,7 +10,7 @@
 // bodies of Renderer/MetalBT709Decoder.m (it is compiled instead of that file's -setupMetal / -decodeBT709:
 // implementations on a machine whose GPU is an MI355X).  Which reference call sites work unchanged: INTEGRATION.md 2.
 #import "MetalBT709Decoder.h"
-#import "MetalBT709Decoder+HIP.h"   // hipDeferredCompletion, -finishHIPFrames (class extension)
+#import "MetalBT709Decoder+HIP.h"   // hipDeferredCompletion, -finishHIPFrames, hipCoalesceFrames (class extension)
 #import "MetalRenderContext.h"
 #import <CoreVideo/CoreVideo.h>
 #include "bt709hip.h"
@@ -28,6 +28,7 @@ enum { BT709HIPMaxInFlight = 3 };  // MaxBuffersInFlight, AAPLRenderer.m:34
   int _nextSlot;                   // the slot bt709hip_pool_acquire hands out next (follows every acquire)
 }
 - (BOOL) finishHIPSlot:(int)slot;
+- (void) applyHIPCoalescing;
 @end
 
 static int32_t BT709HIPMatrixTag(CVPixelBufferRef pb) {
@@ -66,8 +67,19 @@ static void BT709HIPCopyPlane(void *dst, size_t dstStride, CVPixelBufferRef pb, 
   if (bt709hip_decoder_create(_hipContext, (int)self.gamma, self.hasAlphaChannel, &_hipDecoder) != BT709HIP_OK) return FALSE;
   if (bt709hip_decoder_setup(_hipDecoder) != BT709HIP_OK) return FALSE;
   self.gamma = (MetalBT709Gamma)bt709hip_decoder_get_gamma(_hipDecoder);   // hasAlphaChannel forces sRGB (.m:165-169)
+  [self applyHIPCoalescing];
   return TRUE;
 }
+
+// hipCoalesceFrames / hipCoalesceMaxAgeMicroseconds (class extension): applied at setup and whenever they change
+- (void) applyHIPCoalescing {
+  if (_hipDecoder == NULL) return;
+  bt709hip_decoder_set_option(_hipDecoder, BT709HIP_OPT_COALESCE, self.hipCoalesceFrames);
+  bt709hip_decoder_set_option(_hipDecoder, BT709HIP_OPT_COALESCE_MAX_AGE_US, self.hipCoalesceMaxAgeMicroseconds);
+}
+- (void) setHipCoalesceFrames:(int)n { _hipCoalesceFrames = n; [self applyHIPCoalescing]; }
+- (void) setHipCoalesceMaxAgeMicroseconds:(int)us { _hipCoalesceMaxAgeMicroseconds = us; [self applyHIPCoalescing]; }
+- (void *) hipDecoderHandle { return _hipDecoder; }
 
 // Copies a finished slot's pinned BGRA rows into the texture the caller passed for that frame: its top-left
 // frame-sized region (the whole texture for bgraSRGBTexture; the viewport for a larger drawable, .m:575-599).

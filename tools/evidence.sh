@@ -1,7 +1,7 @@
 #!/bin/bash
 # One-call evidence run on the GPU box: tests, every bench line, rocprof + PMC summaries.
-# usage (through gpurun, from the repo root): tools/evidence.sh r04
-R=${1:-r04}
+# usage (through gpurun, from the repo root): tools/evidence.sh r05
+R=${1:-r05}
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/$R; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log
@@ -15,10 +15,16 @@ python bench.py --workload 4k-batch8 --share 1 --streams 2 --no-cpu-baseline --s
 python bench.py --workload 4k-batch8 --share 1 --graph --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_graph.json 2>/dev/null
 # round 4: the reference's cadence (one frame per call, one stream) with the coalescing submit; the plain multi-rank command on one GPU
 for c in 8 32; do python bench.py --workload 4k-batch8 --share 1 --streams 1 --coalesce $c --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_1stream_coalesce$c.json 2>/dev/null; done
-python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_4k_plain_command_2ranks_one_gpu.json 2> $O/bench_4k_plain_command_2ranks_one_gpu.err
-python bench.py --gpus 4 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_4k_plain_command_4ranks_one_gpu.json 2> $O/bench_4k_plain_command_4ranks_one_gpu.err
+# round 5: ranks that outnumber the visible GPUs are REFUSED (rc 2, no line) ...
+python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_4k_plain_command_2ranks_refused.json 2> $O/bench_4k_plain_command_2ranks_refused.txt; echo "rc=$?" >> $O/bench_4k_plain_command_2ranks_refused.txt
+# ... unless asked for: the functional N > 1 run on this one-GPU box (shared_devices: true, n_gpus 1, every rank spot-checked)
+python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --allow-shared-devices > $O/bench_4k_plain_command_2ranks_one_gpu.json 2> $O/bench_4k_plain_command_2ranks_one_gpu.err
+python bench.py --gpus 4 --steps 20 --warmup 5 --no-cpu-baseline --allow-shared-devices > $O/bench_4k_plain_command_4ranks_one_gpu.json 2> $O/bench_4k_plain_command_4ranks_one_gpu.err
+# ONE process driving N GPUs (bt709hip_ringset_*): two and four lanes wrapped onto this GPU
+python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --allow-shared-devices --launcher threads > $O/bench_4k_threads_2lanes_one_gpu.json 2> $O/bench_4k_threads_2lanes_one_gpu.err
+python bench.py --gpus 4 --steps 20 --warmup 5 --no-cpu-baseline --allow-shared-devices --launcher threads --ring 64 > $O/bench_4k_threads_4lanes_one_gpu.json 2> $O/bench_4k_threads_4lanes_one_gpu.err
 # and the driver's launcher line, 2 ranks wrapped onto this one GPU
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_4k_torchrun_2ranks_one_gpu.json 2> $O/bench_4k_torchrun_2ranks_one_gpu.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --allow-shared-devices > $O/bench_4k_torchrun_2ranks_one_gpu.json 2> $O/bench_4k_torchrun_2ranks_one_gpu.err
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py --workload 8k-half --content flat --no-cpu-baseline > $O/bench_8k-half_flat.json 2>/dev/null
 { tools/ab_batch8.sh; echo "# two frames per step"; SHARE=2 STREAMS="1 2 3 4" tools/ab_batch8.sh; } > $O/batch8_streams.txt 2>&1
@@ -39,7 +45,7 @@ tools/profile_gpu.sh 8k-half --workload 8k-half > /dev/null 2>&1
 grep '^{' gpurun_out/prof_8k-half/trace.log | tail -1 > $O/profiled_run_8k-half.json
 PROFILE_PROG=tools/bench_encode.py tools/profile_gpu.sh encode --frames-per-launch 32 > /dev/null 2>&1
 PROFILE_PROG=tools/bench_scaled.py tools/profile_gpu.sh scaled --path scaled --frames-per-launch 8 > /dev/null 2>&1
-PROFILE_PROG=tools/bench_scaled.py tools/profile_gpu.sh rgba16f --path rgba16f --frames-per-launch 16 > /dev/null 2>&1
+PROFILE_PROG=tools/bench_scaled.py tools/profile_gpu.sh rgba16f --path rgba16f --ring 128 --frames-per-launch 128 > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/prof_4k $R 4k > /dev/null
 python tools/pmc_summary.py gpurun_out/prof_1080p $R 1080p > /dev/null
 cp gpurun_out/prof_alpha11/trace/trace_kernel_stats.csv profiles/${R}_alpha11_kernel_stats.csv 2>/dev/null
