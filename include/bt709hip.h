@@ -140,7 +140,8 @@ typedef struct {
   char arch[64];
   /* Which physical device this is, for callers that must prove N contexts sit on N GPUs (bench.py's per-rank records; device
    * ordinals are per process and say nothing once HIP_VISIBLE_DEVICES differs between ranks): hipDeviceGetPCIBusId
-   * ("0000:c1:00.0") and the 16 bytes of hipDeviceGetUuid as 32 hex digits.  MTLDevice has registryID for this
+   * ("0000:c1:00.0") and the 16 bytes of hipDeviceGetUuid -- as they are when they are printable text (ROCm: the 16 characters
+   * rocm-smi shows as the unique id), as 32 hex digits otherwise.  MTLDevice has registryID for this
    * (the reference keeps one device, Renderer/MetalRenderContext.m:59-63, and never needs it). */
   char pci_bus_id[32];
   char uuid[40];

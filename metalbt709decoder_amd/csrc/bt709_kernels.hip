@@ -98,11 +98,12 @@ __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[
 // alpha pointers and strides 4-byte aligned; output pointer and stride 16-byte
 // aligned.  grid = (tiles, H/2, frames); a tile is blockDim * kQuadsPerLane quads.
 // ---------------------------------------------------------------------------
-template <bool HAS_ALPHA, bool NT, bool QUANT>
-__global__ void __launch_bounds__(kMaxBlockThreads)
-decode_nv12_quads(const DecodeParams p) {
+// RP: consecutive row pairs a workgroup covers, all of them loaded before the table is staged (RP = 1: the shipped shape of every
+// mode whose table is small; RP = 2: the LINEAR mode, whose 33 KiB table is then paid for by twice the pixels -- round 5,
+// decode_nv12_quads_rows below).
+template <bool HAS_ALPHA, bool NT, bool QUANT, int RP>
+__device__ __forceinline__ void quads_body(const DecodeParams &p, unsigned char *lds_raw) {
   constexpr int UNROLL = kQuadsPerLane;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
   // XCD-AWARE WORK MAP (p.xcd_bands; launches of 64 frames or more, in multiples of 8: launch_decode).  Workgroups are dealt round-robin
   // over the 8 XCDs in dispatch order, so with the plain map (tile, row pair, frame) XCD k owns the tile rows = k mod 8 of
@@ -123,33 +124,33 @@ decode_nv12_quads(const DecodeParams p) {
   // waves, so threadIdx.y is the same in every lane of a wave: taking it from the first lane
   // makes the row pointers scalar (SGPR base + per-lane offset addressing, no 64-bit VALU
   // address arithmetic).
-  const uint32_t rp_raw = blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const uint32_t rp = min(rp_raw, row_pairs - 1);
+  const uint32_t rp_first = (blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RP;
   // quad u of this lane: consecutive lanes own consecutive quads (a store instruction must fill whole
   // lines: a lane owning ADJACENT quads measured 3x slower, tools/lab_quads_variants.hip)
   const uint32_t q0 = tile * (blockDim.x * UNROLL) + threadIdx.x;
-
-  const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
-  const uint8_t *y1 = y0 + p.y_stride;
-  const uint8_t *cc = f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride;
-  const uint8_t *a0 = HAS_ALPHA ? f.alpha + static_cast<size_t>(2 * rp) * p.alpha_stride : nullptr;
-  uint8_t *o0 = f.out + static_cast<size_t>(2 * rp) * p.out_stride;
-  uint8_t *o1 = o0 + p.out_stride;
 
   // Straight-line code: lanes past the row's end load a clamped (valid) quad and only their
   // stores are predicated.  A divergent `if (q < quads)` around the arithmetic made hipcc put
   // s_waitcnt vmcnt(0) at the join, i.e. each wave waited for the write acknowledgement of its
   // first quad's stores before touching its second quad.
-  uint32_t ya[UNROLL], yb[UNROLL], cw[UNROLL], aa[UNROLL], ab[UNROLL];
+  uint32_t ya[RP][UNROLL], yb[RP][UNROLL], cw[RP][UNROLL], aa[RP][UNROLL], ab[RP][UNROLL];
 #pragma unroll
-  for (int u = 0; u < UNROLL; ++u) {
-    const uint32_t q = min((q0 + u * blockDim.x), quads - 1);
-    ya[u] = load32<NT>(y0 + 4 * q);
-    yb[u] = load32<NT>(y1 + 4 * q);
-    cw[u] = load32<NT>(cc + 4 * q);
-    if (HAS_ALPHA) {
-      aa[u] = load32<NT>(a0 + 4 * q);
-      ab[u] = load32<NT>(a0 + p.alpha_stride + 4 * q);
+  for (int r = 0; r < RP; ++r) {
+    const uint32_t rp = min(rp_first + r, row_pairs - 1);
+    const uint8_t *y0 = f.y + static_cast<size_t>(2 * rp) * p.y_stride;
+    const uint8_t *y1 = y0 + p.y_stride;
+    const uint8_t *cc = f.cbcr + static_cast<size_t>(rp) * p.cbcr_stride;
+    const uint8_t *a0 = HAS_ALPHA ? f.alpha + static_cast<size_t>(2 * rp) * p.alpha_stride : nullptr;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t q = min((q0 + u * blockDim.x), quads - 1);
+      ya[r][u] = load32<NT>(y0 + 4 * q);
+      yb[r][u] = load32<NT>(y1 + 4 * q);
+      cw[r][u] = load32<NT>(cc + 4 * q);
+      if (HAS_ALPHA) {
+        aa[r][u] = load32<NT>(a0 + 4 * q);
+        ab[r][u] = load32<NT>(a0 + p.alpha_stride + 4 * q);
+      }
     }
   }
   if (!QUANT) {  // the sRGB mode needs no table (decode_quad)
@@ -160,23 +161,57 @@ decode_nv12_quads(const DecodeParams p) {
   // store is issued, instead of emitting s_waitcnt vmcnt(0) between the first quad's stores and
   // the second quad's arithmetic (which would wait for the stores' write acknowledgements).
 #pragma unroll
-  for (int u = 0; u < UNROLL; ++u) {
-    asm volatile("" : "+v"(ya[u]), "+v"(yb[u]), "+v"(cw[u]));
-    if (HAS_ALPHA) asm volatile("" : "+v"(aa[u]), "+v"(ab[u]));
-  }
+  for (int r = 0; r < RP; ++r)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      asm volatile("" : "+v"(ya[r][u]), "+v"(yb[r][u]), "+v"(cw[r][u]));
+      if (HAS_ALPHA) asm volatile("" : "+v"(aa[r][u]), "+v"(ab[r][u]));
+    }
 
   const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
 #pragma unroll
-  for (int u = 0; u < UNROLL; ++u) {
-    const uint32_t q = (q0 + u * blockDim.x);
-    u32x4 top, bot;
-    decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
-                           bot);
-    if (q < quads && rp_raw < row_pairs) {
-      store16<NT>(o0 + 16 * q, top);
-      store16<NT>(o1 + 16 * q, bot);
+  for (int r = 0; r < RP; ++r) {
+    const uint32_t rp_raw = rp_first + r;
+    uint8_t *o0 = f.out + static_cast<size_t>(2 * min(rp_raw, row_pairs - 1)) * p.out_stride;
+    uint8_t *o1 = o0 + p.out_stride;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t q = (q0 + u * blockDim.x);
+      u32x4 top, bot;
+      decode_quad<HAS_ALPHA, QUANT>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
+                             bot);
+      if (q < quads && rp_raw < row_pairs) {
+        store16<NT>(o0 + 16 * q, top);
+        store16<NT>(o1 + 16 * q, bot);
+      }
     }
   }
+}
+
+template <bool HAS_ALPHA, bool NT, bool QUANT>
+__global__ void __launch_bounds__(kMaxBlockThreads)
+decode_nv12_quads(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  quads_body<HAS_ALPHA, NT, QUANT, 1>(p, lds_raw);
+}
+
+// The same kernel over RP row pairs per workgroup, for decoders whose table is large (LINEAR: 4 096 buckets = 33 KiB staged per
+// workgroup): grid.y = ceil(row pairs / (blockDim.y * RP)).  Round 5, one process, one ring, LINEAR mode, 4K (profiles/r05_ab_linear_rows.txt):
+// 256 frames per launch RP = 1 / 2 / 3 / 4: 0.706 / 0.759 / 0.765 / 0.777; 32 per launch: 0.714 / 0.713 / 0.667 / 0.652.  So: 4 under
+// the XCD-aware map (64 frames and more), 2 for launches of 8 frames and more, the plain kernel below that.  (Round 4 had tried two
+// row pairs as a 1 024-lane workgroup, blockDim.y = 2, and lost 1 %: more lanes, not more pixels per lane.)
+#ifndef BT709_QUADS_BIG_TABLE_BYTES
+#define BT709_QUADS_BIG_TABLE_BYTES (16u << 10)
+#endif
+#ifndef BT709_QUADS_BIG_TABLE_RP_BANDED
+#define BT709_QUADS_BIG_TABLE_RP_BANDED 4
+#endif
+constexpr uint32_t kBigTableBytes = BT709_QUADS_BIG_TABLE_BYTES;  // tables above this use decode_nv12_quads_rows
+template <bool NT, int RP>
+__global__ void __launch_bounds__(kMaxBlockThreads)
+decode_nv12_quads_rows(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  quads_body<false, NT, false, RP>(p, lds_raw);
 }
 
 // ---------------------------------------------------------------------------
@@ -380,6 +415,21 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
       else hipLaunchKernelGGL((decode_nv12_quads<false, false, true>), grid, block, lds, stream, p);
       return nontemporal ? "decode_nv12_quads<nt,quantiser>" : "decode_nv12_quads<quantiser>";
     }
+    const uint32_t big_rp = p_in.table_unit_bytes <= kBigTableBytes ? 1u : (banded.xcd_bands ? static_cast<uint32_t>(BT709_QUADS_BIG_TABLE_RP_BANDED) : (frames >= 8 ? 2u : 1u));
+    if (big_rp > 1) {  // the LINEAR mode: several row pairs per workgroup share the 33 KiB table
+      dim3 g2 = grid;
+      g2.y = (grid.y + big_rp - 1) / big_rp;
+      if (big_rp == 4) {
+        if (nontemporal) hipLaunchKernelGGL((decode_nv12_quads_rows<true, 4>), g2, block, lds, stream, p);
+        else hipLaunchKernelGGL((decode_nv12_quads_rows<false, 4>), g2, block, lds, stream, p);
+      } else {
+        if (nontemporal) hipLaunchKernelGGL((decode_nv12_quads_rows<true, 2>), g2, block, lds, stream, p);
+        else hipLaunchKernelGGL((decode_nv12_quads_rows<false, 2>), g2, block, lds, stream, p);
+      }
+      LaunchShape &sh = last_launch_shape();
+      if (sh.launches == 1) sh.grid[1] = g2.y;
+      return nontemporal ? "decode_nv12_quads_rows<nt>" : "decode_nv12_quads_rows";
+    }
     if (nontemporal) {
       hipLaunchKernelGGL((decode_nv12_quads<false, true, false>), grid, block, lds, stream, p);
       return "decode_nv12_quads<nt>";
@@ -417,6 +467,10 @@ hipError_t prepare_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false, true>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, true, false>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false, false>),
+      reinterpret_cast<const void *>(&decode_nv12_quads_rows<true, 2>),
+      reinterpret_cast<const void *>(&decode_nv12_quads_rows<false, 2>),
+      reinterpret_cast<const void *>(&decode_nv12_quads_rows<true, 4>),
+      reinterpret_cast<const void *>(&decode_nv12_quads_rows<false, 4>),
       reinterpret_cast<const void *>(&unconvert_packed444<true, false>),
       reinterpret_cast<const void *>(&unconvert_packed444<false, false>),
       reinterpret_cast<const void *>(&decode_nv12_blocks<true, true>),

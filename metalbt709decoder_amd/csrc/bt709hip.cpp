@@ -532,7 +532,13 @@ int bt709hip_context_info(const bt709hip_context *ctx, bt709hip_device_info *inf
   }
   hipUUID uuid;
   if (hipDeviceGetUuid(&uuid, ctx->device) == hipSuccess) {
-    for (int i = 0; i < 16; ++i) std::snprintf(info->uuid + 2 * i, 3, "%02x", static_cast<unsigned>(static_cast<unsigned char>(uuid.bytes[i])));
+    // ROCm hands out 16 ASCII characters ("4a6a3df9d3b4a52e", what rocm-smi prints as the unique id); anything else: 32 hex digits
+    bool text = true;
+    for (int i = 0; i < 16; ++i) text = text && uuid.bytes[i] >= 0x21 && uuid.bytes[i] <= 0x7e;
+    for (int i = 0; i < 16; ++i) {
+      if (text) info->uuid[i] = uuid.bytes[i], info->uuid[i + 1] = 0;
+      else std::snprintf(info->uuid + 2 * i, 3, "%02x", static_cast<unsigned>(static_cast<unsigned char>(uuid.bytes[i])));
+    }
   } else {
     (void)hipGetLastError();
   }

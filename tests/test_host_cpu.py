@@ -307,7 +307,7 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
     instruction has 1/255f (0x3b808081) as its multiplier, and a multiply fused with the float -> half
     conversion (v_fma_mix*: one rounding instead of two) appears nowhere."""
     n = fused = 0
-    for kernel in ("17decode_nv12_quads", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
+    for kernel in ("17decode_nv12_quads", "22decode_nv12_quads_rows", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
                    "18decode_nv12_scaled", "19decode_nv12_rgba16fILi0E", "19decode_nv12_rgba16fILi1E", "13render_scaled"):
         # RGBA16F curve variant: the half CANDIDATE (bt709_rgba16f.hip half_code; not reference arithmetic -- the threshold
         # table settles it, and tests/test_rgba16f.py sweeps it over every float) is the tangent slope * x + intercept:
@@ -333,7 +333,7 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
             assert candidate == candidate_fmas, (kernel, candidate)
             assert not re.search(r"\bv_(log|exp)_f32", body), kernel  # no transcendental left in any decode kernel
             n += 1
-    assert n == 43  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in two shapes)
+    assert n == 47  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in two shapes, the 1:1 kernel's big-table form)
     assert fused > 300
 
 

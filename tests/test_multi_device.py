@@ -53,7 +53,7 @@ def test_device_identity_through_the_c_abi(gh):
         assert a.device_ordinal == d and a.pci_bus_id == b.pci_bus_id and a.uuid == b.uuid
         bus = a.pci_bus_id.decode()
         assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-7]", bus), bus
-        assert a.uuid.decode() == "" or re.fullmatch(r"[0-9a-f]{32}", a.uuid.decode())
+        assert a.uuid.decode() == "" or re.fullmatch(r"[0-9a-f]{32}|[\x21-\x7e]{16}", a.uuid.decode())
         assert bus not in seen, "devices %d and %d report the same PCI bus id" % (seen.get(bus, -1), d)
         seen[bus] = d
         for c in ctxs:

@@ -42,16 +42,16 @@ LAB_SRC = os.path.join(ROOT, "tools", "bin", "lab_src")
 # (file, product text, lab text).  Every product text must occur exactly once.
 GATES = [
     ("bt709_kernels.hip",
-     """    ya[u] = load32<NT>(y0 + 4 * q);
-    yb[u] = load32<NT>(y1 + 4 * q);
-    cw[u] = load32<NT>(cc + 4 * q);
+     """      ya[r][u] = load32<NT>(y0 + 4 * q);
+      yb[r][u] = load32<NT>(y1 + 4 * q);
+      cw[r][u] = load32<NT>(cc + 4 * q);
 """,
      """#if defined(BT709_LAB_NO_LOADS)  // with BT709_LAB_NO_ARITH: the launch's stores alone
-    ya[u] = q * 3u, yb[u] = q * 5u, cw[u] = q * 7u + rp;
+      ya[r][u] = q * 3u, yb[r][u] = q * 5u, cw[r][u] = q * 7u + rp;
 #else
-    ya[u] = load32<NT>(y0 + 4 * q);
-    yb[u] = load32<NT>(y1 + 4 * q);
-    cw[u] = load32<NT>(cc + 4 * q);
+      ya[r][u] = load32<NT>(y0 + 4 * q);
+      yb[r][u] = load32<NT>(y1 + 4 * q);
+      cw[r][u] = load32<NT>(cc + 4 * q);
 #endif
 """),
     ("bt709_kernels.hip",
@@ -68,21 +68,21 @@ GATES = [
 #endif
 """),
     ("bt709_kernels.hip",
-     """    decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
-                           bot);
-    if (q < quads && rp_raw < row_pairs) {
+     """      decode_quad<HAS_ALPHA, QUANT>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
+                             bot);
+      if (q < quads && rp_raw < row_pairs) {
 """,
      """#if defined(BT709_LAB_NO_ARITH)  // WRONG OUTPUT: the launch's loads and stores with (almost) no arithmetic
-    top = u32x4{ya[u], yb[u], cw[u], ya[u] ^ cw[u]};
-    bot = u32x4{yb[u], cw[u], ya[u], yb[u] ^ cw[u]};
+      top = u32x4{ya[r][u], yb[r][u], cw[r][u], ya[r][u] ^ cw[r][u]};
+      bot = u32x4{yb[r][u], cw[r][u], ya[r][u], yb[r][u] ^ cw[r][u]};
 #else
-    decode_quad<HAS_ALPHA, QUANT>(ul, ya[u], yb[u], cw[u], HAS_ALPHA ? aa[u] : 0u, HAS_ALPHA ? ab[u] : 0u, p.alpha_word, top,
-                           bot);
+      decode_quad<HAS_ALPHA, QUANT>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
+                             bot);
 #endif
 #if defined(BT709_LAB_NO_STORES)  // with BT709_LAB_NO_ARITH: the loads alone (a store about once in 2^32 quads keeps them alive)
-    if (q < quads && rp_raw < row_pairs && (top.w ^ bot.w) == 0x9e3779b9u) {
+      if (q < quads && rp_raw < row_pairs && (top.w ^ bot.w) == 0x9e3779b9u) {
 #else
-    if (q < quads && rp_raw < row_pairs) {
+      if (q < quads && rp_raw < row_pairs) {
 #endif
 """),
     ("bt709_device.h",
