@@ -551,11 +551,12 @@ int bt709hip_deinterleave_cbcr(bt709hip_context *ctx, const void *cbcr, size_t c
  * non-temporal loads and stores, one launch: the bandwidth a plain copy reaches on this device, for
  * benchmarks that want to report a kernel against the same box's copy rate (no reference twin). */
 int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_t bytes, void *stream);
-/* Placement-aware allocation of ONE streaming slab.  Allocates `tries` candidates of `bytes` (all alive until the choice is
- * made), times a streaming copy (lower half onto upper half) plus a fill of the whole slab over each, keeps the fastest and
- * frees the rest; the slab kept has been overwritten by the probe (zero-filled) whenever a probe ran, and is NOT cleared
- * otherwise (tries = 1, a slab under 2 MiB, a single candidate).  rates_GBps (optional, `tries` floats; always fully
- * written: 0 where no probe ran) receives the probe rates, *chosen (optional) the index kept.  tries = 1 is bt709hip_malloc.
+/* Placement-aware allocation of ONE streaming slab.  Takes up to `tries` candidates of `bytes` ONE AT A TIME against the incumbent
+ * (at most two slabs are alive at any moment; freeing and allocating again hands out other physical pages, so holding them all
+ * buys nothing), times a streaming copy (lower half onto upper half) plus a fill of the whole slab over each and keeps the fastest;
+ * the slab kept has been overwritten by the probe (zero-filled) whenever a probe ran, and is NOT cleared otherwise (tries = 1, a slab
+ * under 2 MiB).  rates_GBps (optional, `tries` floats; always fully written: 0 where no probe ran) receives the probe rates,
+ * *chosen (optional) the index kept.  tries = 1 is bt709hip_malloc.
  * This is the WEAKER, cheaper probe: it ranks a slab by itself, with a generic kernel.  A frame ring should use
  * bt709hip_ring_create, which probes with the decoder's own launch and chooses the input x output PAIRING (worth a further
  * 1-2 %, profiles/r03_placement_cross.txt).  No reference twin (unified memory has no placement to choose). */

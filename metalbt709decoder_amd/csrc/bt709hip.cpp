@@ -1785,50 +1785,55 @@ int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, vo
   if (rates_GBps)
     for (int i = 0; i < tries; ++i) rates_GBps[i] = 0.0f;  // fully written whatever path is taken below
   if (int rc = bind(ctx)) return rc;
-  std::vector<void *> cand;
-  for (int i = 0; i < tries; ++i) {  // every candidate stays alive until the choice is made: they land in different places
-    void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      break;  // out of memory: choose among what there is
-    }
-    cand.push_back(p);
-  }
-  if (cand.empty()) return hip_fail(hipErrorOutOfMemory);
-  int best = 0;
-  float best_rate = -1.0f;
+  // Candidates are taken ONE AT A TIME against the incumbent (round 5): at most two slabs are alive at any moment -- round 4 held
+  // all `tries` of them, 34 GB for a 4K ring's output slab -- and the diversity does not suffer: hipFree + hipMalloc of a slab this
+  // size hands out other physical pages (profiles/r05_hunt_budget.txt).
   const size_t half = (bytes / 2) & ~static_cast<size_t>(4095);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t s = ctx->default_stream;
-  if (cand.size() > 1 && half >= (1u << 20) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-    for (size_t i = 0; i < cand.size(); ++i) {
-      uint8_t *p = static_cast<uint8_t *>(cand[i]);
-      // a streaming copy (lower half onto upper half) and a fill of the whole slab per round: the fill separates the
-      // placements more clearly (6.3 against 6.5-6.7 TB/s where the copy shows 5.95 against 6.13, tools/placement_probes.py),
-      // and a frame ring is mostly written
-      for (int w = 0; w < 2; ++w) {  // warm (clocks, page tables)
-        launch_copy_probe(p + half, p, half, s);
-        (void)hipMemsetAsync(p, 0, bytes, s);
-      }
-      (void)hipEventRecord(e0, s);
-      for (int r = 0; r < 4; ++r) {
-        launch_copy_probe(p + half, p, half, s);
-        (void)hipMemsetAsync(p, 0, bytes, s);
-      }
-      (void)hipEventRecord(e1, s);
-      float ms = 0.0f;
-      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.0f) ms = 1e9f;
-      const float rate = static_cast<float>(4.0 * (2.0 * static_cast<double>(half) + static_cast<double>(bytes)) / (ms * 1e-3) / 1e9);
-      if (rates_GBps) rates_GBps[i] = rate;
-      if (rate > best_rate) best_rate = rate, best = static_cast<int>(i);
+  const bool probing = tries > 1 && half >= (1u << 20) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  auto probe = [&](void *slab) -> float {
+    uint8_t *p = static_cast<uint8_t *>(slab);
+    // a streaming copy (lower half onto upper half) and a fill of the whole slab per round: the fill separates the
+    // placements more clearly (6.3 against 6.5-6.7 TB/s where the copy shows 5.95 against 6.13, tools/placement_probes.py),
+    // and a frame ring is mostly written
+    for (int w = 0; w < 2; ++w) {  // warm (clocks, page tables)
+      launch_copy_probe(p + half, p, half, s);
+      (void)hipMemsetAsync(p, 0, bytes, s);
+    }
+    (void)hipEventRecord(e0, s);
+    for (int r = 0; r < 4; ++r) {
+      launch_copy_probe(p + half, p, half, s);
+      (void)hipMemsetAsync(p, 0, bytes, s);
+    }
+    (void)hipEventRecord(e1, s);
+    float ms = 0.0f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.0f) ms = 1e9f;
+    return static_cast<float>(4.0 * (2.0 * static_cast<double>(half) + static_cast<double>(bytes)) / (ms * 1e-3) / 1e9);
+  };
+  void *best_p = nullptr;
+  int best = -1;
+  float best_rate = -1.0f;
+  for (int i = 0; i < (probing ? tries : 1); ++i) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      break;  // out of memory: the incumbent (if any) stays
+    }
+    const float rate = probing ? probe(p) : 0.0f;
+    if (rates_GBps) rates_GBps[i] = rate;
+    if (best_p == nullptr || rate > best_rate) {
+      if (best_p != nullptr) (void)hipFree(best_p);
+      best_p = p, best = i, best_rate = rate;
+    } else {
+      (void)hipFree(p);
     }
   }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
-  for (size_t i = 0; i < cand.size(); ++i)
-    if (static_cast<int>(i) != best) (void)hipFree(cand[i]);
   (void)hipGetLastError();
-  *dptr = cand[static_cast<size_t>(best)];
+  if (best_p == nullptr) return hip_fail(hipErrorOutOfMemory);
+  *dptr = best_p;
   if (chosen) *chosen = best;
   return BT709HIP_OK;
 }

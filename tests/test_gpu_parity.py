@@ -349,7 +349,11 @@ def test_frame_sharder_four_lanes_on_one_device(gh, oracle):
 
 @pytest.mark.parametrize("case", [((3840, 8), 64, False), ((7680, 4), 72, False), ((1920, 12), 80, False), ((328, 10), 64, False),
                                   ((640, 6), 64, True), ((640, 6), 64, False, "sRGB"), ((644, 6), 72, False, "Linear"),
-                                  ((1280, 4), 64, False, "ITU709"), ((640, 6), 70, False), ((328, 6), 77, True)])
+                                  ((1280, 4), 64, False, "ITU709"), ((640, 6), 70, False), ((328, 6), 77, True),
+                                  # the LINEAR mode's big-table kernel (decode_nv12_quads_rows): 4 row pairs per workgroup under the map,
+                                  # 2 for launches of 8-63 frames; ragged last groups (5 and 6 row pairs), stacked row pairs (1920 wide)
+                                  ((644, 10), 72, False, "Linear"), ((1920, 12), 80, False, "Linear"), ((644, 10), 12, False, "Linear"),
+                                  ((1920, 12), 9, False, "Linear"), ((3840, 6), 3, False, "Linear")])
 def test_xcd_band_work_map(gh, oracle, case):
     """Launches of a multiple of 8 frames, 64 or more, use the XCD-aware work map (a longer launch of any other count: the map over the multiple
     of 8 and the plain map over the rest, two launches) (grid.x = 8 x tiles; each XCD class owns a

@@ -211,13 +211,16 @@ def test_gpu_rgba16f_batch_4k(gh, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [(128, 8), (252, 62)])
 @pytest.mark.parametrize("n", [72, 77])
-def test_gpu_rgba16f_xcd_band_work_map(gh, oracle, n):
+def test_gpu_rgba16f_xcd_band_work_map(gh, oracle, n, size):
     """72 evenly spaced frames in one launch (a multiple of 8, past the threshold), and 77 (72 under the map + 5 plain): the
-    XCD-aware work map of the RGBA16Float kernel against the plain order and the oracle."""
+    XCD-aware work map of the RGBA16Float kernel against the plain order and the oracle.  128 x 8: few workgroups, the small
+    shape (2 blocks x 3 row pairs per lane); 252 x 62: >= 4 workgroups per CU, the large shape (4 x 2), with a ragged last tile
+    (126 blocks on 4 x 64 lanes) and a ragged last row-pair group (31 row pairs in groups of 2)."""
     from metalbt709decoder_amd.decoder import DeviceBuffer
     ctx = gh.context()
-    w, h = 128, 8
+    w, h = size
     in_pitch, out_pitch = w * h * 3 // 2, w * h * 8
     slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
     frames = [_frame(w, h, 500 + i) for i in range(n)]
