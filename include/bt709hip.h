@@ -315,6 +315,12 @@ int bt709hip_decode_batch(bt709hip_decoder *dec, int count,
  * an alpha channel -> BT709HIP_ERR_UNSUPPORTED. */
 int bt709hip_unconvert(bt709hip_decoder *dec, const void *ycbcr_words, size_t in_stride, int width, int height,
                        const bt709hip_surface *out, void *stream, int wait_until_completed);
+/* The same over `count` frames of one geometry (same width, height and strides) in ONE launch (grid.z = frame), like
+ * bt709hip_decode_batch: up to BT709HIP_MAX_BATCH arbitrary buffers, or any number up to 65535 when frame i sits at frame 0 +
+ * i * (frame 1 - frame 0) on both sides.  No reference twin (+unconvert: takes one frame); one 4K frame per call runs at 0.58 of
+ * the roofline on one stream -- a launch boundary per 14 us kernel -- a batch does not pay it. */
+int bt709hip_unconvert_batch(bt709hip_decoder *dec, int count, const void *const *ycbcr_words, size_t in_stride, int width, int height,
+                             const bt709hip_surface *outs, void *stream, int wait_until_completed);
 
 /* Pass 1 + pass 2 (MetalScaleRenderContext -renderScaled:, bilinear) fused for the
  * exact 2:1 ratio: out is (W/2) x (H/2).  Frame W,H must be multiples of 4.

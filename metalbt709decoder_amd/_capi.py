@@ -170,6 +170,7 @@ SYMBOLS = {
     "bt709hip_decode": (_I, [_P, _FP, _FP, _SP, _I, _I, _P, _I]),
     "bt709hip_decode_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
     "bt709hip_unconvert": (_I, [_P, _P, _Z, _I, _I, _SP, _P, _I]),
+    "bt709hip_unconvert_batch": (_I, [_P, _I, C.POINTER(C.c_void_p), _Z, _I, _I, _SP, _P, _I]),
     "bt709hip_decode_half": (_I, [_P, _FP, _FP, _SP, _P, _I]),
     "bt709hip_decode_half_batch": (_I, [_P, _I, _FP, _FP, _SP, _P, _I]),
     "bt709hip_decode_scaled": (_I, [_P, _FP, _FP, _SP, _P, _I]),

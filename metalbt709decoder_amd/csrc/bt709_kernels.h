@@ -191,8 +191,16 @@ LaunchShape &last_launch_shape();  // thread-local (bt709_kernels.hip)
 // xcd_bands: use the XCD-aware work map when the launch allows it (fast path, frames a multiple of 8)
 const char *launch_decode(const DecodeParams &p, int frames, int variant, bool has_alpha, bool quantiser, bool nontemporal,
                           int xcd_bands, uint32_t grid_x, uint32_t block_threads, hipStream_t stream);
-// +unconvert: on packed 4:4:4 words (bt709_kernels.hip unconvert_packed444); `tables` supplies table_unit*, unit_magic, alpha_word
-const char *launch_unconvert(const DecodeParams &tables, const void *in, size_t in_stride, void *out, size_t out_stride, uint32_t width,
+// +unconvert: on packed 4:4:4 words (bt709_kernels.hip unconvert_packed444); `tables` supplies table_unit*, unit_magic, alpha_word.
+// `count` frames of one geometry in one launch (grid.z): evenly spaced (in[0] + i * in_step), or through a pointer table of up to kMaxBatch
+struct UnconvertBatch {
+  int count;
+  bool uniform;
+  const void *const *in;  // count input pointers (uniform: only in[0] is read)
+  void *const *out;
+  int64_t in_step, out_step;
+};
+const char *launch_unconvert(const DecodeParams &tables, const UnconvertBatch &batch, size_t in_stride, size_t out_stride, uint32_t width,
                              uint32_t height, bool vec, bool quantiser, hipStream_t stream);
 // half: grid = (grid_x, H/2 output rows, frames) x block_threads.
 const char *launch_decode_half(const DecodeParams &p, int frames, bool wide, bool has_alpha, bool nontemporal,

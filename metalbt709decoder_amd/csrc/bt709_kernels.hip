@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 
 #include "bt709_device.h"
 
@@ -270,8 +271,12 @@ decode_nv12_blocks(const DecodeParams p) {
 // (16-byte load and store); otherwise one pixel per lane.  grid = (tiles, rows).
 // ---------------------------------------------------------------------------
 struct UnconvertParams {
-  const uint8_t *in;   // packed words
+  const uint8_t *in;   // packed words (frame blockIdx.z: in + z * in_step, or ins[z] when the table is used)
   uint8_t *out;        // BGRA words
+  int64_t in_step, out_step;  // evenly spaced frames (bt709hip_unconvert_batch)
+  const uint8_t *ins[kMaxBatch];
+  uint8_t *outs[kMaxBatch];
+  uint32_t use_table;
   uint32_t in_stride, out_stride, width, height;
   const void *table_unit;
   uint32_t table_unit_bytes;
@@ -290,12 +295,14 @@ unconvert_packed444(const UnconvertParams p) {
   constexpr uint32_t N = VEC ? 4 : 1, ROWS = VEC ? 2 : 1;
   const uint32_t row0 = blockIdx.y * ROWS;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // group of N pixels
+  const uint8_t *frame_in = p.use_table ? p.ins[blockIdx.z] : p.in + static_cast<int64_t>(blockIdx.z) * p.in_step;
+  uint8_t *frame_out = p.use_table ? p.outs[blockIdx.z] : p.out + static_cast<int64_t>(blockIdx.z) * p.out_step;
   const bool live = i * N < p.width;
   const uint32_t ic = live ? i : 0u;  // lanes past the row's end load a valid group and do not store (every lane stages the table)
   uint32_t w[ROWS][N];
 #pragma unroll
   for (uint32_t r = 0; r < ROWS; ++r) {
-    const uint8_t *in = p.in + static_cast<size_t>(row0 + r) * p.in_stride;
+    const uint8_t *in = frame_in + static_cast<size_t>(row0 + r) * p.in_stride;
     if (VEC) {
       const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in + 16 * ic));
       w[r][0] = v.x, w[r][N > 1 ? 1 : 0] = v.y, w[r][N > 2 ? 2 : 0] = v.z, w[r][N > 3 ? 3 : 0] = v.w;
@@ -326,7 +333,7 @@ unconvert_packed444(const UnconvertParams p) {
         b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)));
       o[k] = pack_bgra(b[0], b[1], b[2], p.alpha_word);
     }
-    uint8_t *out = p.out + static_cast<size_t>(row0 + r) * p.out_stride;
+    uint8_t *out = frame_out + static_cast<size_t>(row0 + r) * p.out_stride;
     if (VEC) {
       u32x4 v;
       v.x = o[0], v.y = o[N > 1 ? 1 : 0], v.z = o[N > 2 ? 2 : 0], v.w = o[N > 3 ? 3 : 0];
@@ -337,11 +344,17 @@ unconvert_packed444(const UnconvertParams p) {
   }
 }
 
-const char *launch_unconvert(const DecodeParams &t, const void *in, size_t in_stride, void *out, size_t out_stride, uint32_t width,
-                             uint32_t height, bool vec, bool quantiser, hipStream_t stream) {
+const char *launch_unconvert(const DecodeParams &t, const UnconvertBatch &b, size_t in_stride, size_t out_stride, uint32_t width, uint32_t height,
+                             bool vec, bool quantiser, hipStream_t stream) {
   UnconvertParams p;
-  p.in = static_cast<const uint8_t *>(in);
-  p.out = static_cast<uint8_t *>(out);
+  std::memset(&p, 0, sizeof p);
+  p.in = static_cast<const uint8_t *>(b.in[0]);
+  p.out = static_cast<uint8_t *>(b.out[0]);
+  p.in_step = b.in_step;
+  p.out_step = b.out_step;
+  p.use_table = b.uniform ? 0u : 1u;
+  if (!b.uniform)
+    for (int i = 0; i < b.count && i < kMaxBatch; ++i) p.ins[i] = static_cast<const uint8_t *>(b.in[i]), p.outs[i] = static_cast<uint8_t *>(b.out[i]);
   p.in_stride = static_cast<uint32_t>(in_stride);
   p.out_stride = static_cast<uint32_t>(out_stride);
   p.width = width;
@@ -351,7 +364,7 @@ const char *launch_unconvert(const DecodeParams &t, const void *in, size_t in_st
   p.unit_magic = t.unit_magic;
   p.alpha_word = t.alpha_word;
   const uint32_t groups = vec ? width / 4 : width;
-  const dim3 grid((groups + kBlockThreads - 1) / kBlockThreads, vec ? height / 2 : height, 1);  // vec: two rows per workgroup row
+  const dim3 grid((groups + kBlockThreads - 1) / kBlockThreads, vec ? height / 2 : height, static_cast<uint32_t>(b.count));  // vec: two rows per workgroup row
   const size_t lds = quantiser ? 0 : t.table_unit_bytes;
   if (vec) {
     if (quantiser) hipLaunchKernelGGL((unconvert_packed444<true, true>), grid, dim3(kBlockThreads), lds, stream, p);

@@ -1096,32 +1096,59 @@ int bt709hip_decode(bt709hip_decoder *dec, const bt709hip_frame *frame, const bt
   return bt709hip_decode_batch(dec, 1, frame, alpha, out, stream, wait_until_completed);
 }
 
-int bt709hip_unconvert(bt709hip_decoder *dec, const void *ycbcr_words, size_t in_stride, int width, int height,
-                       const bt709hip_surface *out, void *stream, int wait_until_completed) {
-  if (dec == nullptr || out == nullptr || width < 0 || height < 0) return BT709HIP_ERR_INVALID_ARG;
+int bt709hip_unconvert_batch(bt709hip_decoder *dec, int count, const void *const *ycbcr_words, size_t in_stride, int width, int height,
+                             const bt709hip_surface *outs, void *stream, int wait_until_completed) {
+  if (dec == nullptr || outs == nullptr || ycbcr_words == nullptr || width < 0 || height < 0 || count < 0) return BT709HIP_ERR_INVALID_ARG;
   if (int rc = ensure_setup(dec, stream)) return rc;
   FLUSH_STREAM(dec->ctx, stream);
   if (dec->has_alpha) return BT709HIP_ERR_UNSUPPORTED;  // the packed words carry no alpha sample
-  if (out->width != width || out->height != height) return BT709HIP_ERR_SIZE_MISMATCH;
-  if ((width & 1) || (height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;  // BGRAToBT709Converter.m:69-74
-  if (out->format != BT709HIP_FORMAT_BGRA8_SRGB || out->reserved != 0) return BT709HIP_ERR_UNSUPPORTED;
-  if (width == 0 || height == 0) return BT709HIP_OK;
-  if (ycbcr_words == nullptr || out->bgra == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  if (count == 0) return BT709HIP_OK;
   const size_t row = static_cast<size_t>(width) * 4;
-  if (in_stride < row || (in_stride & 3) || !aligned(ycbcr_words, 4) || out->stride < row || (out->stride & 3) || !aligned(out->bgra, 4) ||
-      in_stride > 0xffffffffu || out->stride > 0xffffffffu)
-    return BT709HIP_ERR_STRIDE;
+  bool vec = (width % 4) == 0 && (in_stride % 16) == 0;
+  bool uniform = count > 1;
+  std::vector<void *> out_ptrs(static_cast<size_t>(count));
+  for (int i = 0; i < count; ++i) {
+    const bt709hip_surface &o = outs[i];
+    if (o.width != width || o.height != height) return BT709HIP_ERR_SIZE_MISMATCH;
+    if ((width & 1) || (height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;  // BGRAToBT709Converter.m:69-74
+    if (o.format != BT709HIP_FORMAT_BGRA8_SRGB || o.reserved != 0) return BT709HIP_ERR_UNSUPPORTED;
+    if (o.stride != outs[0].stride) return BT709HIP_ERR_SIZE_MISMATCH;
+    if (width == 0 || height == 0) continue;
+    if (ycbcr_words[i] == nullptr || o.bgra == nullptr) return BT709HIP_ERR_INVALID_ARG;
+    if (in_stride < row || (in_stride & 3) || !aligned(ycbcr_words[i], 4) || o.stride < row || (o.stride & 3) || !aligned(o.bgra, 4) ||
+        in_stride > 0xffffffffu || o.stride > 0xffffffffu)
+      return BT709HIP_ERR_STRIDE;
+    vec = vec && (o.stride % 16) == 0 && aligned(ycbcr_words[i], 16) && aligned(o.bgra, 16);
+    out_ptrs[static_cast<size_t>(i)] = o.bgra;
+    if (i >= 2)
+      uniform = uniform && byte_step(ycbcr_words[0], ycbcr_words[i]) == byte_step(ycbcr_words[0], ycbcr_words[1]) * i &&
+                byte_step(outs[0].bgra, o.bgra) == byte_step(outs[0].bgra, outs[1].bgra) * i;
+  }
+  if (width == 0 || height == 0) return BT709HIP_OK;
+  if (count > (uniform ? kMaxUniformBatch : kMaxBatch)) return BT709HIP_ERR_UNSUPPORTED;
   if (height > kMaxGridYZ) return BT709HIP_ERR_UNSUPPORTED;
   if (int rc = bind(dec->ctx)) return rc;
   DecodeParams t;
   std::memset(&t, 0, sizeof t);
   set_tables(&t, dec);
   t.alpha_word = dec->alpha_fill << 24;
-  const bool vec = (width % 4) == 0 && (in_stride % 16) == 0 && (out->stride % 16) == 0 && aligned(ycbcr_words, 16) && aligned(out->bgra, 16);
+  UnconvertBatch batch;
+  batch.count = count;
+  batch.uniform = uniform;
+  batch.in = ycbcr_words;
+  batch.out = out_ptrs.data();
+  batch.in_step = uniform ? byte_step(ycbcr_words[0], ycbcr_words[1]) : 0;
+  batch.out_step = uniform ? byte_step(outs[0].bgra, outs[1].bgra) : 0;
   hipStream_t s = pick(dec->ctx, stream);
-  tl_kernel_name = launch_unconvert(t, ycbcr_words, in_stride, out->bgra, out->stride, static_cast<uint32_t>(width),
-                                    static_cast<uint32_t>(height), vec, dec->gamma == kGammaSRGB, s);
+  tl_kernel_name = launch_unconvert(t, batch, in_stride, outs[0].stride, static_cast<uint32_t>(width), static_cast<uint32_t>(height), vec,
+                                    dec->gamma == kGammaSRGB, s);
   return finish_launch(s, wait_until_completed);
+}
+
+int bt709hip_unconvert(bt709hip_decoder *dec, const void *ycbcr_words, size_t in_stride, int width, int height,
+                       const bt709hip_surface *out, void *stream, int wait_until_completed) {
+  if (out == nullptr) return BT709HIP_ERR_INVALID_ARG;
+  return bt709hip_unconvert_batch(dec, 1, &ycbcr_words, in_stride, width, height, out, stream, wait_until_completed);
 }
 
 int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_frame *frames,

@@ -689,6 +689,31 @@ class BGRAToBT709Converter:
         return True
 
     @staticmethod
+    def unconvertBatch(decoder, inBT709PixelsList, outBGRATextures, width, height, commandBuffer=None):
+        """+unconvert: over several frames of one size in ONE launch (bt709hip_unconvert_batch; no reference twin -- the reference
+        converts a frame per call): the packed 4:4:4 word arrays are uploaded into one slab (evenly spaced), the outputs are the
+        given textures (up to 32 arbitrary ones, or any number carved evenly from one allocation)."""
+        if not decoder.setupMetal():
+            return False
+        ctx = decoder.metalRenderContext
+        n = len(inBT709PixelsList)
+        stride = int(width) * 4
+        scratch = DeviceBuffer(ctx, max(n * stride * int(height), 4), placement_tries=1)
+        ptrs = (C.c_void_p * n)()
+        for i, words in enumerate(inBT709PixelsList):
+            w32 = np.ascontiguousarray(words, dtype=np.uint32).reshape(int(height), int(width))
+            ptrs[i] = scratch.ptr + i * stride * int(height)
+            ctx._upload(ptrs[i], stride, w32.view(np.uint8).reshape(int(height), stride), commandBuffer)
+        surfs = (Surface * n)(*[t.surface() for t in outBGRATextures])
+        stream = commandBuffer.stream if commandBuffer is not None else None
+        rc = ctx.lib.bt709hip_unconvert_batch(decoder._handle, n, ptrs, stride, int(width), int(height), surfs, stream, 1)
+        scratch.free()
+        if rc != _capi.OK:
+            return decoder._fail(rc, "unconvertBatch")
+        decoder.lastStatus = _capi.OK
+        return True
+
+    @staticmethod
     def copyBT709ToCoreVideo(inBT709Pixels, cvPixelBuffer):
         """Packed (Cr<<16)|(Cb<<8)|Y words -> NV12 planes (BGRAToBT709Converter.m:1042-1099):
         Y of every pixel; CbCr of every even column, every row writing into row/2, so the

@@ -518,9 +518,9 @@ const char *launch_decode(const DecodeParams &p, int frames, int variant, bool h
 const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &, int frames, bool, uint32_t, uint32_t, uint32_t, bool, hipStream_t stream) {
   return launch(stream, "decode_nv12_rgba16f", frames, p.frames[0].y, p.frames[0].out, frames * frame_bytes(p, 8.0));
 }
-const char *launch_unconvert(const DecodeParams &, const void *in, size_t, void *out, size_t, uint32_t width, uint32_t height, bool, bool,
+const char *launch_unconvert(const DecodeParams &, const UnconvertBatch &b, size_t, size_t, uint32_t width, uint32_t height, bool, bool,
                              hipStream_t stream) {
-  return launch(stream, "unconvert_packed444", 1, in, out, 8.0 * width * height);
+  return launch(stream, "unconvert_packed444", b.count, b.in[0], b.out[0], 8.0 * width * height * b.count);
 }
 const char *launch_decode_half(const DecodeParams &p, int frames, bool, bool, bool, uint32_t, uint32_t, hipStream_t stream) {
   return launch(stream, "decode_nv12_half", frames, p.frames[0].y, p.frames[0].out, frames * frame_bytes(p, 4.0));

@@ -153,6 +153,8 @@ def test_every_stream_taking_export_issues_the_queued_frames_first(fake):
         "bt709hip_decoder_flush": lambda S: lib.bt709hip_decoder_flush(A, S),
         "bt709hip_decode_batch": lambda S: lib.bt709hip_decode_batch(B, 4, fb, None, sb, S, 0),
         "bt709hip_unconvert": lambda S: lib.bt709hip_unconvert(B, mem["in_b"], w * 4, w, h // 2, C.byref(surf(mem["out_b"], 0, w, h // 2)), S, 0),
+        "bt709hip_unconvert_batch": lambda S: lib.bt709hip_unconvert_batch(B, 2, (C.c_void_p * 2)(mem["in_b"], mem["in_b"] + w * (h // 2) * 4), w * 4, w, h // 2,
+                                                                            (_capi.Surface * 2)(surf(mem["out_b"], 0, w, h // 2), surf(mem["out_b"], 1, w, h // 2)), S, 0),
         "bt709hip_decode_half": lambda S: lib.bt709hip_decode_half(B, fb, None, half, S, 0),
         "bt709hip_decode_half_batch": lambda S: lib.bt709hip_decode_half_batch(B, 4, fb, None, half, S, 0),
         "bt709hip_decode_scaled": lambda S: lib.bt709hip_decode_scaled(B, fb, None, half, S, 0),
@@ -167,7 +169,7 @@ def test_every_stream_taking_export_issues_the_queued_frames_first(fake):
         "bt709hip_copy_probe": lambda S: lib.bt709hip_copy_probe(ctx, mem["aux"] + 8192, mem["aux"], 4096, S),
     }
     exports = stream_exports()
-    assert len(exports) >= 26, exports
+    assert len(exports) >= 27, exports
     assert sorted(recipes) == exports, "include/bt709hip.h and this test disagree about the stream-taking exports: %s" % sorted(set(recipes) ^ set(exports))
 
     for name in exports:

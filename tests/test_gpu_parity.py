@@ -834,6 +834,51 @@ def test_unconvert_packed_444_words(gh, oracle, vectors, gamma):
         assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
 
 
+def test_unconvert_batch(gh, oracle):
+    """bt709hip_unconvert_batch: several frames of one size in ONE launch (grid.z = frame) -- through the pointer table (separately
+    allocated textures) and as evenly spaced frames (one slab, more than the table holds) -- every frame compared with the oracle,
+    the vectorised and the per-pixel layout; geometry and format errors as the single-frame entry point reports them."""
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    ctx = gh.context()
+    lib = ctx.lib
+    dec = gh.make_decoder(mb.MetalBT709GammaApple, alpha_fill=0)
+    rng = np.random.default_rng(77)
+    for (w, h), n in (((64, 8), 5), ((30, 6), 3), ((1028, 4), 7)):
+        frames = [rng.integers(0, 1 << 24, (h, w), dtype=np.uint32) for _ in range(n)]
+        texs = [ctx.makeBGRATexture((w, h)) for _ in range(n)]
+        assert mb.BGRAToBT709Converter.unconvertBatch(dec, frames, texs, w, h), dec.lastStatus
+        assert (b"<vec>" in lib.bt709hip_last_kernel_name()) == (w % 4 == 0)
+        for words, tex in zip(frames, texs):
+            assert np.array_equal(ctx.getBGRATexturePixels(tex).reshape(-1), oracle.unconvert_packed(0, words, w, h))
+    # evenly spaced: 40 frames (> BT709HIP_MAX_BATCH) carved from two slabs
+    w, h, n = 256, 4, 40
+    frames = [rng.integers(0, 1 << 24, (h, w), dtype=np.uint32) for _ in range(n)]
+    slab_in, slab_out = DeviceBuffer(ctx, n * w * h * 4), DeviceBuffer(ctx, n * w * h * 4)
+    for i, words in enumerate(frames):
+        ctx._upload(slab_in.ptr + i * w * h * 4, w * 4, words.view(np.uint8).reshape(h, w * 4), None)
+    ctx._sync(None)
+    ptrs = (C.c_void_p * n)(*[slab_in.ptr + i * w * h * 4 for i in range(n)])
+    surfs = (_capi.Surface * n)(*[_capi.Surface(slab_out.ptr + i * w * h * 4, w * 4, w, h, 0, 0) for i in range(n)])
+    assert lib.bt709hip_unconvert_batch(dec._handle, n, ptrs, w * 4, w, h, surfs, None, 1) == _capi.OK
+    got = np.empty((n * h, w * 4), np.uint8)
+    _capi.check(lib.bt709hip_download(ctx.handle, got.ctypes.data, w * 4, slab_out.ptr, w * 4, w * 4, n * h, None))
+    ctx._sync(None)
+    for i, words in enumerate(frames):
+        assert np.array_equal(got[i * h:(i + 1) * h].view(np.uint32).reshape(-1), oracle.unconvert_packed(0, words, w, h)), i
+    # 40 frames that are NOT evenly spaced exceed the pointer table; mixed sizes / formats / alpha decoders are refused
+    ptrs[1], ptrs[2] = ptrs[2], ptrs[1]
+    assert lib.bt709hip_unconvert_batch(dec._handle, n, ptrs, w * 4, w, h, surfs, None, 1) == _capi.ERR_UNSUPPORTED
+    surfs[3].width = w - 2
+    assert lib.bt709hip_unconvert_batch(dec._handle, 8, ptrs, w * 4, w, h, surfs, None, 1) == _capi.ERR_SIZE_MISMATCH
+    surfs[3].width = w
+    surfs[5].format = _capi.FORMAT_RGBA16F
+    assert lib.bt709hip_unconvert_batch(dec._handle, 8, ptrs, w * 4, w, h, surfs, None, 1) == _capi.ERR_UNSUPPORTED
+    adec = gh.make_decoder(mb.MetalBT709GammaSRGB, has_alpha=True)
+    assert lib.bt709hip_unconvert_batch(adec._handle, 2, ptrs, w * 4, w, h, surfs, None, 1) == _capi.ERR_UNSUPPORTED
+    assert lib.bt709hip_unconvert_batch(dec._handle, 0, ptrs, w * 4, w, h, surfs, None, 1) == _capi.OK
+    assert lib.bt709hip_unconvert_batch(dec._handle, 2, None, w * 4, w, h, surfs, None, 1) == _capi.ERR_INVALID_ARG
+
+
 def test_one_pass_route_nil_texture_and_render_pass_descriptor(gh, oracle):
     """AAPLRenderer.m:927-934: -decodeBT709: with bgraSRGBTexture:nil and the view's render pass descriptor -- the
     decoder renders into colorAttachments[0].texture (MetalBT709Decoder.m:272-281, 462-466).  Here the drawable is

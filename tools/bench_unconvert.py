@@ -56,3 +56,27 @@ for nstreams in (1, 2, 3):
     us = ms.value * 1e3 / steps
     print("unconvert 4K, ring %d, one frame per call, %d stream(s): %.2f us per frame  %.1f Gpixel/s  %.3f of 8 TB/s (8 B per pixel)  %s"
           % (ring, nstreams, us, W * H / us / 1e3, 8 * W * H / us / 1e3 / 8000, lib.bt709hip_last_kernel_name().decode()))
+
+# round 5: bt709hip_unconvert_batch -- the same frames, `per` of them per launch (evenly spaced), one stream
+for per in (8, 32):
+    n = ring - ring % per
+    ptrs = (C.c_void_p * ring)(*[src.ptr + i * pitch for i in range(ring)])
+    sarr = (_capi.Surface * ring)(*surfs)
+
+    def run_batch(launches):
+        for k in range(launches):
+            first = (k * per) % n
+            pp = C.cast(C.byref(ptrs, first * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p))
+            sp = C.cast(C.byref(sarr, first * C.sizeof(_capi.Surface)), C.POINTER(_capi.Surface))
+            _capi.check(lib.bt709hip_unconvert_batch(dec._handle, per, pp, W * 4, W, H, sp, None, 0))
+    run_batch(8)
+    lib.bt709hip_stream_synchronize(h, None)
+    launches = max(8, steps // per)
+    lib.bt709hip_event_record(h, e0, None)
+    run_batch(launches)
+    lib.bt709hip_event_record(h, e1, None)
+    lib.bt709hip_stream_synchronize(h, None)
+    ms = C.c_float(); lib.bt709hip_event_elapsed_ms(h, e0, e1, C.byref(ms))
+    us = ms.value * 1e3 / (launches * per)
+    print("unconvert 4K, ring %d, %d frames per call (bt709hip_unconvert_batch), 1 stream: %.2f us per frame  %.1f Gpixel/s  %.3f of 8 TB/s (8 B per pixel)  %s"
+          % (ring, per, us, W * H / us / 1e3, 8 * W * H / us / 1e3 / 8000, lib.bt709hip_last_kernel_name().decode()))
