@@ -13,6 +13,8 @@
 //                  time budgets, a launch that fails inside a probe; nothing leaks on any path
 //   ring set       lanes on 2 devices, one launch per lane per step
 //   destroy        a decoder destroyed with frames queued; contexts, streams and events all accounted for at exit
+//   fuzz           30 000 calls of the decode / rescale / encode / plane entry points with random geometry, pitches, alignments,
+//                  tags, formats, NULLs and counts: no crash, no out-of-bounds read of a descriptor array, always a status of the enum
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -402,6 +404,88 @@ static void test_graphs_and_misc() {
   OK(bt709hip_context_destroy(ctx));
 }
 
+// Argument fuzz: every decode / rescale / encode / plane entry point with random geometry, pitches, alignments, tags, formats,
+// NULLs and counts.  On the fake runtime a launch touches nothing, so whatever the shim lets through is harmless here -- the point
+// is the shim's OWN reads (descriptor arrays, alpha arrays, per-frame loops) under ASan / UBSan, and that every call returns a
+// status of the enum.
+static void test_argument_fuzz() {
+  fake_hip_reset();
+  bt709hip_context *ctx = nullptr;
+  OK(bt709hip_context_create(0, &ctx));
+  bt709hip_decoder *decs[3] = {nullptr, nullptr, nullptr};
+  OK(bt709hip_decoder_create(ctx, BT709HIP_GAMMA_APPLE, 0, &decs[0]));
+  OK(bt709hip_decoder_create(ctx, BT709HIP_GAMMA_LINEAR, 0, &decs[1]));
+  OK(bt709hip_decoder_create(ctx, BT709HIP_GAMMA_SRGB, 1, &decs[2]));
+  OK(bt709hip_decoder_set_option(decs[1], BT709HIP_OPT_COALESCE, 5));
+  void *mem = nullptr, *s = nullptr;
+  OK(bt709hip_malloc(ctx, 8u << 20, &mem));
+  OK(bt709hip_stream_create(ctx, &s));
+  uint8_t *base = static_cast<uint8_t *>(mem);
+  uint32_t x = 0x709u;
+  auto rnd = [&](uint32_t n) { x = x * 1664525u + 1013904223u; return (x >> 8) % n; };
+  const int dims[] = {0, 1, 2, 3, 4, 6, 8, 16, 30, 64, 66, 250, 640, 1920};
+  int statuses[16] = {0};
+  for (int it = 0; it < 30000; ++it) {
+    const int count = static_cast<int>(rnd(40)) - 2;  // -2 .. 37: negative, zero, beyond the pointer table
+    const int w = dims[rnd(14)], h = dims[rnd(12)];
+    bt709hip_frame f[40], a[40];
+    bt709hip_surface o[40], in[40];
+    const int n = count < 0 ? 0 : count;
+    const bool uniform = rnd(2) == 0;
+    for (int i = 0; i < n && i < 40; ++i) {
+      const size_t off = uniform ? static_cast<size_t>(i) * 4096 : rnd(1 << 20);
+      f[i] = frame_at(base + (rnd(8) ? off & ~size_t(15) : off | 1), w + static_cast<int>(rnd(3)) * 4, h, static_cast<int>(rnd(4)));
+      f[i].width = w, f[i].height = h;
+      if (rnd(16) == 0) f[i].y = nullptr;
+      if (rnd(16) == 0) f[i].matrix = static_cast<int>(rnd(4));
+      if (rnd(8) == 0) f[i].width = dims[rnd(14)];
+      a[i] = f[i];
+      a[i].transfer = rnd(4) ? BT709HIP_TRANSFER_LINEAR : BT709HIP_TRANSFER_SRGB;
+      const int ow = rnd(4) ? w : dims[rnd(14)], oh = rnd(4) ? h : dims[rnd(12)];
+      o[i] = surface_at(base + (4u << 20) + (off & ~size_t(rnd(4) ? 15 : 3)), ow, oh);
+      o[i].format = rnd(6) == 0 ? static_cast<int>(rnd(3)) : 0;
+      if (o[i].format == BT709HIP_FORMAT_RGBA16F) o[i].stride *= 2;
+      if (rnd(10) == 0) o[i].stride = rnd(2) ? 0 : o[i].stride + 2;
+      if (rnd(20) == 0) o[i].reserved = 1;
+      in[i] = o[i];
+      in[i].bgra = base + (off & ~size_t(15));
+    }
+    bt709hip_decoder *dec = rnd(12) ? decs[rnd(3)] : nullptr;
+    const bt709hip_frame *fp = rnd(20) ? f : nullptr, *ap = rnd(2) ? a : nullptr;
+    const bt709hip_surface *op = rnd(20) ? o : nullptr;
+    void *st = rnd(3) ? s : nullptr;
+    int rc = 0;
+    switch (rnd(12)) {
+      case 0: rc = bt709hip_decode_batch(dec, count, fp, ap, op, st, static_cast<int>(rnd(2))); break;
+      case 1: rc = bt709hip_decode(dec, n ? fp : nullptr, n ? ap : nullptr, n ? op : nullptr, w, h, st, 0); break;
+      case 2: rc = bt709hip_decode_half_batch(dec, count, fp, ap, op, st, 0); break;
+      case 3: rc = bt709hip_decode_scaled_batch(dec, count, fp, ap, op, st, 0); break;
+      case 4: rc = bt709hip_render_scaled_batch(ctx, count, rnd(20) ? in : nullptr, op, st, 0); break;
+      case 5: rc = bt709hip_render_scaled(ctx, n ? in : nullptr, n ? op : nullptr, st, 0); break;
+      case 6: rc = bt709hip_encode_batch(ctx, count, rnd(20) ? in : nullptr, fp, static_cast<int>(rnd(4)) - 1 + 1, static_cast<int>(rnd(4)), st, 0); break;
+      case 7: rc = bt709hip_unconvert(dec, n ? f[0].y : nullptr, static_cast<size_t>(w) * 4 + rnd(3) * 2, w, h, n ? op : nullptr, st, 0); break;
+      case 8: {
+        const void *ptrs[40];
+        for (int i = 0; i < n && i < 40; ++i) ptrs[i] = f[i].y;
+        rc = bt709hip_unconvert_batch(dec, count, rnd(20) ? ptrs : nullptr, static_cast<size_t>(w) * 4, w, h, op, st, 0);
+        break;
+      }
+      case 9: rc = bt709hip_interleave_cbcr(ctx, base, rnd(4) ? w : 1, base + 65536, w, base + 131072, 2 * static_cast<size_t>(w) + rnd(2), w, h, st, 0); break;
+      case 10: rc = bt709hip_deinterleave_cbcr(ctx, base + 131072, 2 * static_cast<size_t>(w), rnd(8) ? base : nullptr, w, base + 65536, w, w, h, st, 0); break;
+      default: rc = bt709hip_copy_probe(ctx, base + rnd(64), base + (1 << 20), rnd(4096) * (rnd(2) ? 16 : 1), st); break;
+    }
+    CHECK(rc <= 0 && rc >= BT709HIP_ERR_UNSUPPORTED);
+    if (rc <= 0 && rc >= -15) ++statuses[-rc];
+    if (it % 997 == 0) OK(bt709hip_stream_synchronize(ctx, st));
+  }
+  CHECK(statuses[0] > 1000 && statuses[-BT709HIP_ERR_INVALID_ARG] > 100 && statuses[-BT709HIP_ERR_SIZE_MISMATCH] > 100 &&
+        statuses[-BT709HIP_ERR_STRIDE] > 100 && statuses[-BT709HIP_ERR_ODD_DIMENSIONS] > 100 && statuses[-BT709HIP_ERR_UNSUPPORTED] > 50);
+  for (bt709hip_decoder *d : decs) OK(bt709hip_decoder_destroy(d));
+  OK(bt709hip_stream_destroy(ctx, s));
+  OK(bt709hip_free(ctx, mem));
+  OK(bt709hip_context_destroy(ctx));
+}
+
 int main(int argc, char **argv) {
   fake_hip_set_device_count(2);
   const std::string only = argc > 1 ? argv[1] : "";
@@ -409,7 +493,8 @@ int main(int argc, char **argv) {
     const char *name;
     void (*fn)();
   } tests[] = {{"coalescing", test_coalescing_threads}, {"two_decoders", test_two_decoders_one_stream_and_age}, {"pool_sharder", test_pool_and_sharder},
-               {"ring", test_ring_hunts},               {"ring_set", test_ring_set},                             {"graphs", test_graphs_and_misc}};
+               {"ring", test_ring_hunts},               {"ring_set", test_ring_set},                             {"graphs", test_graphs_and_misc},
+               {"fuzz", test_argument_fuzz}};
   for (auto &t : tests) {
     if (!only.empty() && only != t.name) continue;
     const int before = failures;
