@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/r04b; mkdir -p $O
 timeout 900 tools/placement_pmc_r04.sh > $O/placement_pmc.txt 2>&1; tail -40 $O/placement_pmc.txt
-timeout 900 tools/r04_half_clock.sh > $O/half_clock.txt 2>&1; cat $O/half_clock.txt
+timeout 900 tools/rounds/r04_half_clock.sh > $O/half_clock.txt 2>&1; cat $O/half_clock.txt
 for t in 4k 1080p 8k-half; do
   if [ $t = 4k ]; then timeout 900 tools/profile_gpu.sh $t > /dev/null 2>&1; else timeout 900 tools/profile_gpu.sh $t --workload $t > /dev/null 2>&1; fi
   grep '^{' gpurun_out/prof_$t/trace.log | tail -1 > $O/profiled_run_$t.json
