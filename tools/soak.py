@@ -2,7 +2,8 @@
     python tools/soak.py [seed] [cases]
 decode (opaque / alpha, 8-bit and RGBA16Float targets), exact 2:1 (both kernels, with alpha), any-ratio
 (with alpha), the reference's two passes through both intermediate formats, the encoder, the frame ring and the
-coalescing submit (round 4).
+coalescing submit (round 4); round 5: ring sets on every visible device, batched RGBA16Float launches of both kernel
+shapes, +unconvert: batches, the LINEAR mode's big-table kernel at batch sizes on both sides of its row-pair switch.
 Fresh seeds every time it is used; the committed tests hold the fixed-seed fuzz."""
 import os
 import sys
@@ -18,7 +19,7 @@ ctx = gh.context()
 scale = mb.MetalScaleRenderContext(); assert scale.setupRenderPipelines(ctx)
 bad, counts = 0, {}
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
-    kind = int(rng.integers(0, 8))
+    kind = int(rng.integers(0, 12))
     counts[kind] = counts.get(kind, 0) + 1
     gamma = int(rng.integers(0, 4))
     w = 4 * int(rng.integers(1, 600)); h = 4 * int(rng.integers(1, 40))
@@ -80,6 +81,55 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
             assert dec.decodeBT709(b, abuf, t, None, None, w, h, False)
         got = np.concatenate([ctx.getBGRATexturePixels(t).view(np.uint8).reshape(-1) for t in reversed(texs)])
         want = np.concatenate([oracle.decode_nv12(g, fy, fc, alpha=a).reshape(-1) for fy, fc in reversed(frs)])
+    elif kind == 8:  # round 5: a ring set over every visible device (twice around), a random sub-range, one launch per lane
+        ndev = mb.load_library().bt709hip_device_count()
+        devices = list(range(ndev)) * 2
+        n, half = int(rng.integers(1, 9)), bool(rng.integers(0, 3) == 0)
+        rs = mb.FrameRingSet(devices, (w, h), n, gamma=g, hasAlphaChannel=a is not None, halfScale=half, tries=1)
+        assert rs.handle, rs.lastStatus
+        frs = {}
+        for lane, ring in enumerate(rs.lanes):
+            for i in range(n):
+                frs[lane, i] = gh.random_nv12(w, h, seed=int(rng.integers(0, 1 << 30)))
+                ring.pixelBuffer(i).upload_planes(*frs[lane, i])
+                if a is not None:
+                    ab = ring.alphaPixelBuffer(i); ring.ctx._upload(ab.y_ptr, ab.y_stride, a, None); ring.ctx._sync(None)
+        first = int(rng.integers(0, n)); count = int(rng.integers(1, n - first + 1))
+        assert rs.decode(first, count) and rs.synchronize()
+        got = np.concatenate([ring.ctx.getBGRATexturePixels(ring.texture(i)).view(np.uint8).reshape(-1)
+                              for ring in rs.lanes for i in range(first, first + count)])
+        want = np.concatenate([(oracle.decode_nv12_half(g, *frs[lane, i], alpha=a) if half else oracle.decode_nv12(g, *frs[lane, i], alpha=a)).reshape(-1)
+                               for lane in range(len(devices)) for i in range(first, first + count)])
+        rs.release()
+    elif kind == 9:  # round 5: batched RGBA16Float launches (small frames: the small shape; many frames: the large one)
+        n = int(rng.integers(1, 33))
+        hh = min(h, 24)
+        dec = gh.make_decoder(g)
+        frs = [gh.random_nv12(w, hh, seed=int(rng.integers(0, 1 << 30))) for _ in range(n)]
+        bufs = [gh.make_buffer(fy, fc, dec.gamma) for fy, fc in frs]
+        texs = [ctx.makeBGRATexture((w, hh), pixelFormat=mb.MTLPixelFormatRGBA16Float) for _ in range(n)]
+        assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True), dec.lastStatus
+        got = np.concatenate([ctx.getBGRATexturePixels(t).view(np.uint16).reshape(-1) for t in texs])
+        want = np.concatenate([oracle.decode_nv12_rgba16f(g, fy, fc).view(np.uint16).reshape(-1) for fy, fc in frs])
+    elif kind == 10:  # round 5: +unconvert: over a batch of packed 4:4:4 frames
+        n = int(rng.integers(1, 33))
+        ww, hh = (w if rng.integers(0, 2) else w + 2), min(h, 16)
+        dec = gh.make_decoder(g, alpha_fill=int(rng.integers(0, 256)))
+        frs = [rng.integers(0, 1 << 24, (hh, ww), dtype=np.uint32) for _ in range(n)]
+        texs = [ctx.makeBGRATexture((ww, hh)) for _ in range(n)]
+        assert mb.BGRAToBT709Converter.unconvertBatch(dec, frs, texs, ww, hh), dec.lastStatus
+        got = np.concatenate([ctx.getBGRATexturePixels(t).reshape(-1) for t in texs])
+        want = np.concatenate([oracle.unconvert_packed(g, f, ww, hh) | np.uint32(dec.alphaFill << 24) for f in frs])
+    elif kind == 11:  # round 5: the LINEAR mode through decode_nv12_quads_rows (2 row pairs per workgroup from 8 frames on), ragged heights
+        n = int(rng.integers(1, 24))
+        hh = 2 * int(rng.integers(1, 12))
+        dec = gh.make_decoder(mb.MetalBT709GammaLinear)
+        frs = [gh.random_nv12(w, hh, seed=int(rng.integers(0, 1 << 30))) for _ in range(n)]
+        bufs = [gh.make_buffer(fy, fc, dec.gamma) for fy, fc in frs]
+        texs = [ctx.makeBGRATexture((w, hh)) for _ in range(n)]
+        assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True), dec.lastStatus
+        got = np.concatenate([ctx.getBGRATexturePixels(t).view(np.uint8).reshape(-1) for t in texs])
+        want = np.concatenate([oracle.decode_nv12(2, fy, fc).reshape(-1) for fy, fc in frs])
     else:  # encoder: BGRA -> NV12, then compare planes
         ig, og = [(1, 0), (1, 1), (2, 2), (0, 0), (1, 2)][int(rng.integers(0, 5))]
         bgra = rng.integers(0, 1 << 32, w * h, dtype=np.uint32)
