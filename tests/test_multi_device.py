@@ -291,3 +291,38 @@ def test_hunt_probes_do_not_queue_on_a_coalescing_decoder(gh, oracle):
     _capi.check(ring.lib.bt709hip_decoder_get_option(dec._handle, _capi.OPT_COALESCE, C.byref(v)))
     assert v.value == 32
     ring.release()
+
+
+def _bench(args, timeout=900):
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[0]) if len(lines) == 1 else None)
+
+
+@pytest.mark.parametrize("launcher", ["processes", "threads"])
+def test_bench_n_greater_than_one_on_the_gpu(gh, launcher):
+    """bench.py --gpus N end to end on hardware, both launchers: N = twice the visible devices with --allow-shared-devices (on a
+    one-GPU box two ranks / lanes on it; on the 8-GPU node sixteen over eight) -- refused without the flag -- and, when more
+    than one device is visible, N = the device count without it.  The line counts the distinct devices, spot-checks every
+    rank's own ring and names every rank's device."""
+    ndev = visible()
+    common = ["--ring", "48", "--steps", "3", "--warmup", "1", "--placement-tries", "1", "--no-cpu-baseline", "--launcher", launcher]
+    r, d = _bench(["--gpus", str(2 * ndev)] + common)
+    assert r.returncode == 2 and d is None and "--allow-shared-devices" in r.stderr
+    r, d = _bench(["--gpus", str(2 * ndev), "--allow-shared-devices"] + common)
+    assert r.returncode == 0 and d is not None, r.stderr[-2000:]
+    assert d["n_gpus"] == ndev and d["ranks"] == 2 * ndev and d["shared_devices"] is True
+    assert d["parity_spot_check"] == "ok" and d["parity_spot_check_ranks"] == 2 * ndev and d["value"] > 100.0
+    assert [x["rank"] for x in d["config"]["devices"]] == list(range(2 * ndev))
+    assert len({x["pci_bus_id"] for x in d["config"]["devices"]}) == ndev
+    assert all(p["parity_spot_check"] == "ok" and p["avg_launch_us"] > 0 for p in d["per_rank"])
+    assert ("threads (ONE process" in d["config"]["launcher"]) == (launcher == "threads")
+    if ndev > 1:
+        r, d = _bench(["--gpus", str(ndev)] + common)
+        assert r.returncode == 0 and d is not None, r.stderr[-2000:]
+        assert d["n_gpus"] == ndev and d["ranks"] == ndev and d["shared_devices"] is False and d["parity_spot_check_ranks"] == ndev
