@@ -207,7 +207,11 @@ int bt709hip_graph_destroy(bt709hip_context *ctx, void *graph);
 /* Device memory ~ make*Texture / fill* / get*TexturePixels
  * (MetalRenderContext.h:62-105).  upload/download are asynchronous on `stream`
  * (hipMemcpy2DAsync); host memory should be pinned for true overlap
- * (bt709hip_host_alloc).  Pitches are bytes; `row_bytes` x `rows` is copied. */
+ * (bt709hip_host_alloc).  The host buffer must stay allocated and unchanged until the
+ * stream has passed the copy (bt709hip_stream_synchronize, an event, or a later call
+ * with wait_until_completed on the same stream): freeing pageable memory under a copy
+ * in flight is a GPU memory access fault, not an error code.  Pitches are bytes;
+ * `row_bytes` x `rows` is copied. */
 int bt709hip_malloc(bt709hip_context *ctx, size_t bytes, void **dptr);
 int bt709hip_free(bt709hip_context *ctx, void *dptr);
 /* Free and total device memory of the context's GPU right now (hipMemGetInfo), for callers that size rings or a placement
@@ -594,7 +598,7 @@ int bt709hip_half_thresholds(int gamma, float *thresholds, int capacity);
 int bt709hip_half_lookup(int gamma, float x, int candidate_offset, int *table_entries);
 /* Name of the kernel the last decode on this thread launched (for profiling). */
 const char *bt709hip_last_kernel_name(void);
-/* Launch shape of the last bt709hip_decode / _decode_batch (1:1, BGRA8 target) this thread issued: grid and block of its
+/* Launch shape of the last bt709hip_decode / _decode_batch (1:1, BGRA8 or RGBA16F target) this thread issued: grid and block of its
  * first kernel launch, the number of launches it took (2: the XCD-aware map over a multiple of 8 frames plus the plain map
  * over the rest) and the work map of the first (bt709hip_decoder_option BT709HIP_OPT_XCD_BANDS value actually used; 0 plain). */
 typedef struct {

@@ -88,14 +88,20 @@ struct DecodeParams {
 // Pass 1 into an RGBA16Float target (bt709_rgba16f.hip): the threshold table of transfer_tables.h
 // HalfTable and the constants of the candidate.  Travels beside DecodeParams (frames, pitches).
 struct HalfParams {
-  const void *table;     // float T[]: T[i] = smallest x with H(x) >= h_min + i, then the candidate tangents; nullptr: no curve (LINEAR)
+  const void *table;     // float T[]: T[i] = smallest x with H(x) >= h_min + i, then the candidate entries; nullptr: no curve (LINEAR)
   uint32_t table_bytes;  // 0 without a table; else thresholds + candidates
-  uint32_t cand_offset;  // byte offset of the candidate tangents {value, slope} (transfer_tables.h HalfTable::cand) in `table`
+  uint32_t cand_offset;  // byte offset of the candidate entries {intercept, slope} (transfer_tables.h HalfTable::cand) in `table` = bytes of the thresholds
   uint32_t h_min, h_max; // codes the table covers
-  float split, low_scale, pre_add, pre_scale, exponent;
+  float split, low_scale;
+  float index_scale;     // HalfTable::index_scale: the split point lands on the bucket boundary 2^-4
   uint32_t row_pairs_per_block;  // filled by the launcher
   uint32_t wide_store;           // 16-byte stores (target 16-byte aligned), else 8-byte
 };
+// LDS plan of decode_nv12_rgba16f: the thresholds from byte 0, the candidate entries from this FIXED byte on -- so that the
+// address of a bucket's entry is its binary16 bits plus a compile-time constant (the ds_read's immediate offset).  Above the
+// largest threshold image (sRGB: 8 602 floats), and low enough that thresholds + candidates stay under 40 KiB: four
+// workgroups per CU.
+constexpr uint32_t kHalfCandLds = 34560;
 const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp, int frames, bool has_alpha,
                                   uint32_t in_align, uint32_t out_align, uint32_t compute_units, bool xcd_bands, hipStream_t stream);
 hipError_t prepare_rgba16f_kernels();  // bt709_rgba16f.hip

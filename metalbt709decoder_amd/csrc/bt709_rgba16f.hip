@@ -6,15 +6,18 @@
 // for IO bound shader" (:157).  Per channel that is
 //       H(x) = half(curve_to_linear(x)),   x = the saturated non-linear value of bt709_device.h
 // with the reference's double-precision pow inside the curve.  No GPU pow is bit-identical to libm's, so:
-//   * below the curve's split point the reference multiplies by a constant: one exact float multiply
-//     and the hardware conversion (v_cvt_f16_f32, round to nearest even) give H directly;
-//   * above it, a CANDIDATE whose half h0 is H or H - 1 is settled exactly by the one threshold above h0:
-//     H = h0 + (x >= T[h0 + 1])   (transfer_tables.h HalfTable).  The candidate is the tangent of the curve at the
-//     start of x's bucket (641 buckets {intercept, slope}: the floats sharing an exponent and 7 mantissa bits), ONE
-//     fma: it lies below the convex curve by at most 1.0e-4 of the value, a fifth of a half's spacing.  (Rounds
-//     2-3: exp2(g * log2(base)) from v_log_f32 / v_exp_f32, two quarter-rate instructions per channel -- 36 to 40
-//     issue cycles per channel; round 4: x - x_q and an fma, 18; now 14.)
-// T is indexed by the OUTPUT code: one entry per step of H, 24-34 KiB in LDS, plus 5 KiB of tangents, staged once
+//   * a CANDIDATE whose half h0 is H or H - 1 is settled exactly by the one threshold above h0:
+//     H = h0 + (x >= T[h0 + 1])   (transfer_tables.h HalfTable).  The candidate is ONE fma over the entry {intercept, slope} of
+//     x's bucket: above the curve's split point the tangent of the curve at the start of the bucket (it lies below the convex
+//     curve by at most 1.0e-4 of the value, a fifth of a half's spacing); below it -- bucket 0 -- {0, low_scale}: the
+//     reference's exact product, whose half IS H.  The bucket is the round-toward-zero binary16 of x * index_scale shifted
+//     right by 3, held at a floor; index_scale puts the split point ON a bucket boundary, so no comparison with the split is
+//     left in the kernel.  Channels go in PAIRS through the packed instructions: v_pk_mul_f32, v_cvt_pkrtz_f16_f32,
+//     v_pk_max_u16 for the bucket; v_cvt_pk_f16_f32 and v_pk_sub_u16 (saturating) for h0 and its index into T; the pair (R, G)
+//     and the pair (B, A) of a pixel come out of the conversion already packed as the two words of the texel.
+//     (Rounds 2-3: exp2(g * log2(base)) from v_log_f32 / v_exp_f32, two quarter-rate instructions per channel -- 36 to 40
+//     issue cycles per channel; round 4: x - x_q and an fma, 18; round 5: 12 instructions; this form: 7.)
+// T is indexed by the OUTPUT code: one entry per step of H, 24-34 KiB in LDS, plus 4-5 KiB of candidate entries, staged once
 // per workgroup -- which is why a workgroup covers 4 blocks x 2 row pairs per lane (below), where the 8-bit kernel with its
 // 4 KiB table covers one tile of one row pair.
 //
@@ -32,77 +35,116 @@
 namespace bt709 {
 namespace {
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
+
 struct HalfLookup {
-  float split, low_scale;
-  uint32_t h_below;    // h_min - 1
-  uint32_t table_off;  // LDS address of T[h_min] - 4 * h_min
-  uint32_t cand_off;   // LDS address of the candidate tangents - 8 * kHalfCandFirst's low 10 bits (see half_code)
+  float index_scale;  // HalfTable::index_scale
+  uint32_t below2;    // (h_min - 1) in both halves: the saturating subtraction that indexes T
 };
+// LDS address of a bucket's entry = its (masked) binary16 bits + this: the ds_read_b64's immediate offset.  ABSOLUTE LDS
+// addresses: the dynamic allocation is the kernel's only LDS and starts at byte 0 (no __shared__ variable in this file; a CPU
+// test reads .group_segment_fixed_size = 0 from the code object's metadata).
+constexpr uint32_t kCandBias = kHalfCandLds - kHalfCandFloor;
+static_assert((kHalfCandFloor & 7u) == 0 && (kHalfCandLds & 15u) == 0 && kHalfCandLds - kHalfCandFloor + 0x3ff8u < 0x10000u, "candidate entries: aligned, and the offset fits the instruction");
 
-__device__ __forceinline__ uint32_t half_bits(float v) {
-  const _Float16 h = static_cast<_Float16>(v);  // v_cvt_f16_f32, round to nearest even
-  return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h));
-}
-
-// H(x) for a saturated x in [0, 1]
-template <bool HAS_TABLE>
-__device__ __forceinline__ uint32_t half_code(const HalfLookup &t, float x) {
-  // The product is rounded to binary32 first, THEN to binary16, as on the CPU: the empty asm keeps hipcc
-  // from fusing multiply and conversion into v_fma_mixlo_f16 (one rounding instead of two).
-  float lowv = __fmul_rn(x, t.low_scale);  // exact below the split for 1/16; x itself when there is no curve
-  asm("" : "+v"(lowv));
-  if (!HAS_TABLE) return half_bits(lowv);
-  // Above the split: the tangent of the curve at the start of x's bucket (transfer_tables.h), in slope / intercept form:
-  // p = x * slope + intercept, ONE fma (round 4 formed x - x_q first: two more instructions per channel).  Bucket = bits(x) >> 16;
-  // its low 10 bits index the table (v_bfe_u32 + v_lshl_add_u32: cand_off already holds "- 8 * (kHalfCandFirst & 0x3ff)"); an x
-  // below 2^-5 reads some bytes in front of or behind the 641 real entries instead -- inside the LDS allocation, which covers all
-  // 1 024 values of the index, and unused: such an x is below every split and takes the exact product.  The fma belongs to the
-  // CANDIDATE, not to the reference's arithmetic -- any value in (true * (1 - 4.8e-4), true] gives the same H (the host proves it
-  // for every float: tests/native/half_candidate_sweep.cpp).
-  // Below the split the exact product takes the candidate's place before the one conversion; its half IS H,
-  // and it goes through the same settlement: the index is held at h_min - 1 from below, T[h_min] is the
-  // smallest x of the WHOLE curve that reaches h_min, so nothing is added (and a value of the low piece that
-  // already rounds to h_min is compared with T[h_min + 1] > split).  No clamp of x, no second conversion.
-  const uint32_t xb = __float_as_uint(x);
-  const u32x2 c = *reinterpret_cast<LdsPairPtr>((((xb >> 16) & 0x3ffu) << 3) + t.cand_off);  // {intercept, slope}
-  const float p = __builtin_fmaf(x, __uint_as_float(c.y), __uint_as_float(c.x));
-  const uint32_t h0 = half_bits(x < t.split ? lowv : p);
-  typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
-  const LdsFloatPtr e = reinterpret_cast<LdsFloatPtr>((max(h0, t.h_below) << 2) + t.table_off);
-  return h0 + (x >= e[1] ? 1u : 0u);
-}
-
-// The same settlement for N values at once, the LDS reads BATCHED: all N tangent reads are issued, then waited for once; all N
-// threshold reads are issued, then waited for once.  Written one value at a time (half_code above) hipcc puts an s_waitcnt
-// behind every read -- 108 waits for the 96 reads of a lane's four blocks -- and each wave sits out the LDS latency 96 times.
-// Same float operations per value in the same order: the bytes cannot differ (the exhaustive sweeps run on this form).
-template <bool HAS_TABLE, int N>
-__device__ __forceinline__ void half_codes(const HalfLookup &t, const float *x, uint32_t *h) {
-  if (!HAS_TABLE) {
+// The table image of a launch (thresholds, then candidate entries) -> LDS: the thresholds to byte 0, the entries to
+// kHalfCandLds.  Every load of a lane is issued before its first write (bt709_device.h stage_table: a round of the loop is an
+// L2 round trip inside the workgroup's lifetime): at most 40 KiB = 2 560 sixteen-byte words, 10 per lane of the smallest
+// workgroup (256 lanes), 5 of a 512-lane one.
+__device__ __forceinline__ void stage_half_tables(unsigned char *lds, const void *src, uint32_t cand_offset, uint32_t bytes) {
+  const u32x4 *s = reinterpret_cast<const u32x4 *>(src);
+  const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+  const uint32_t n = bytes / 16, n_thresholds = cand_offset / 16, gap = (kHalfCandLds - cand_offset) / 16;
+  u32x4 *d = reinterpret_cast<u32x4 *>(lds);
+  constexpr int kBatch = 5;
+  for (uint32_t base = tid; base < n; base += nthreads * kBatch) {
+    u32x4 v[kBatch];
 #pragma unroll
-    for (int i = 0; i < N; ++i) h[i] = half_code<false>(t, x[i]);
+    for (int k = 0; k < kBatch; ++k) {
+      const uint32_t i = base + static_cast<uint32_t>(k) * nthreads;
+      if (i < n) v[k] = s[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const uint32_t i = base + static_cast<uint32_t>(k) * nthreads;
+      if (i < n) d[i < n_thresholds ? i : i + gap] = v[k];
+    }
+  }
+}
+
+// two values -> their binary16 codes in one word (v_cvt_pk_f16_f32, round to nearest even: the same conversion as
+// v_cvt_f16_f32, two at a time)
+__device__ __forceinline__ uint32_t half_bits2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+
+// The twelve channels of a 2x2 block (x = R, G, B of its four pixels, saturated) and the pixels' alpha values (1.0f without an
+// alpha plane) -> the texels' words {R | G << 16, B | A << 16}.  The LDS reads are BATCHED: all twelve entry reads are issued,
+// then waited for once; all twelve threshold reads are issued, then waited for once (written one value at a time hipcc puts an
+// s_waitcnt behind every read and each wave sits out the LDS latency 24 times per block).
+template <bool HAS_TABLE>
+__device__ __forceinline__ void half_texels(const HalfLookup &t, const float *x, const float *alpha, uint32_t *w) {
+  if (!HAS_TABLE) {  // no curve: the conversion alone
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      w[2 * px] = half_bits2(x[3 * px], x[3 * px + 1]);
+      w[2 * px + 1] = half_bits2(x[3 * px + 2], alpha[px]);
+    }
     return;
   }
-  u32x2 c[N];
+  // buckets, two channels per instruction; the floor holds everything below the split point (and anything the conversion
+  // makes of a binary16 subnormal) in bucket 0
+  u32x2 c[12];
+  const u16x2 floor2 = {static_cast<uint16_t>(kHalfCandFloor), static_cast<uint16_t>(kHalfCandFloor)};
 #pragma unroll
-  for (int i = 0; i < N; ++i) c[i] = *reinterpret_cast<LdsPairPtr>((((__float_as_uint(x[i]) >> 16) & 0x3ffu) << 3) + t.cand_off);  // {intercept, slope}
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(c[i]));  // one wait for the batch
-  typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
-  uint32_t h0[N];
-  float e[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    float lowv = __fmul_rn(x[i], t.low_scale);
-    asm("" : "+v"(lowv));  // the product is rounded to binary32 first, then to binary16 (see half_code)
-    const float p = __builtin_fmaf(x[i], __uint_as_float(c[i].y), __uint_as_float(c[i].x));
-    h0[i] = half_bits(x[i] < t.split ? lowv : p);
-    e[i] = reinterpret_cast<LdsFloatPtr>((max(h0[i], t.h_below) << 2) + t.table_off)[1];
+  for (int i = 0; i < 6; ++i) {
+    const f32x2 u = f32x2{x[2 * i], x[2 * i + 1]} * t.index_scale;  // binary32 products (v_pk_mul_f32; -ffp-contract=off)
+    u16x2 hb = __builtin_bit_cast(u16x2, __builtin_amdgcn_cvt_pkrtz(u.x, u.y));
+    hb = __builtin_elementwise_max(hb, floor2);
+    const uint32_t pk = __builtin_bit_cast(uint32_t, hb);
+    c[2 * i] = *reinterpret_cast<LdsPairPtr>((pk & 0xfff8u) + kCandBias);  // {intercept, slope}
+    c[2 * i + 1] = *reinterpret_cast<LdsPairPtr>(((pk >> 16) & 0xfff8u) + kCandBias);
   }
 #pragma unroll
-  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(e[i]));  // one wait for the batch
+  for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(c[i]));  // one wait for the batch
+  // candidates -> h0 of (R, G) and (B, A) -> index into T.  The fma belongs to the CANDIDATE, not to the reference's
+  // arithmetic -- any value in (true * (1 - 4.8e-4), true] gives the same H (the host proves it for every float:
+  // tests/native/half_candidate_sweep.cpp) -- except in bucket 0, where it is the reference's product x * low_scale, rounded
+  // to binary32 first and THEN to binary16, as on the CPU: the empty asm keeps hipcc from fusing it with the conversion
+  // into v_fma_mixlo_f16 (one rounding instead of two).
+  float e[12];
 #pragma unroll
-  for (int i = 0; i < N; ++i) h[i] = h0[i] + (x[i] >= e[i] ? 1u : 0u);
+  for (int px = 0; px < 4; ++px) {
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p[k] = __builtin_fmaf(x[3 * px + k], __uint_as_float(c[3 * px + k].y), __uint_as_float(c[3 * px + k].x));
+      asm("" : "+v"(p[k]));
+    }
+    w[2 * px] = half_bits2(p[0], p[1]);
+    w[2 * px + 1] = half_bits2(p[2], alpha[px]);
+    // T[h0 + 1] at LDS byte 4 * (h0 - (h_min - 1)) + 4; the subtraction saturates at 0: a code below the table (the piece
+    // below the split) is compared with T[h_min], the smallest x of the WHOLE curve that reaches h_min, and nothing is added
+    const u16x2 below = __builtin_bit_cast(u16x2, t.below2);
+    const uint32_t drg = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, w[2 * px]), below));
+    const uint32_t db = __builtin_elementwise_sub_sat(static_cast<uint16_t>(w[2 * px + 1]), static_cast<uint16_t>(t.below2));  // B alone: v_sub_u16, upper half zero
+    e[3 * px] = *reinterpret_cast<LdsFloatPtr>(((drg & 0xffffu) << 2) + 4u);
+    e[3 * px + 1] = *reinterpret_cast<LdsFloatPtr>(((drg >> 16) << 2) + 4u);
+    e[3 * px + 2] = *reinterpret_cast<LdsFloatPtr>((db << 2) + 4u);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(e[i]));  // one wait for the batch
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    uint32_t g_step = x[3 * px + 1] >= e[3 * px + 1] ? 0x10000u : 0u;
+    asm("" : "+v"(g_step));  // keeps the two steps of the word apart: one select, one add-with-carry
+    w[2 * px] = w[2 * px] + g_step + (x[3 * px] >= e[3 * px] ? 1u : 0u);
+    w[2 * px + 1] += x[3 * px + 2] >= e[3 * px + 2] ? 1u : 0u;
+  }
 }
 
 }  // namespace
@@ -134,15 +176,25 @@ __device__ __forceinline__ void half_codes(const HalfLookup &t, const float *x, 
 #ifndef BT709_RGBA16F_TILE_LANES
 #define BT709_RGBA16F_TILE_LANES 512
 #endif
-#ifndef BT709_RGBA16F_BATCH
-#define BT709_RGBA16F_BATCH 12  // values settled per LDS batch: 12 = a whole 2x2 block, 6 = two pixels
-#endif
-constexpr int kF16Batch = BT709_RGBA16F_BATCH;
 struct F16Shape {
   int nb, rp, lanes;
 };
 constexpr F16Shape kF16Large = {BT709_RGBA16F_NB, BT709_RGBA16F_RP, BT709_RGBA16F_TILE_LANES};
-constexpr F16Shape kF16Small = {2, 3, 960};  // launches of fewer than 4 workgroups per CU in the large shape
+// The XCD-aware work map pays from 8 frames per launch on here (the 1:1 kernel: from 64, bt709_kernels.h): same process, same
+// ring, 4K 32 / 16 / 8 frames per launch 0.722 / 0.689 / 0.660 against 0.685 / 0.670 / 0.650 with the plain map, 1080p 32
+// frames 0.643 against 0.612 (profiles/r05_ab_rgba16f_packed.txt).
+#ifndef BT709_RGBA16F_BAND_MIN_FRAMES
+#define BT709_RGBA16F_BAND_MIN_FRAMES 8
+#endif
+constexpr int kF16BandMinFrames = BT709_RGBA16F_BAND_MIN_FRAMES;
+// Rows of at most 1 024 blocks (1080p: 240 busy lanes of a 256-lane workgroup): a third row pair per staged table -- for LONG
+// launches only (1080p, 512 frames per launch: 0.759 against 0.726; 128 frames: 0.696 against 0.721; 32: 0.635 against 0.689).
+#ifndef BT709_RGBA16F_NARROW_RP
+#define BT709_RGBA16F_NARROW_RP 3
+#endif
+constexpr F16Shape kF16Narrow = {4, BT709_RGBA16F_NARROW_RP, 512};
+constexpr uint64_t kF16NarrowMinGroupsPerSlot = 48;  // ... of the 4 x CUs workgroup slots: 1080p from 273 frames per launch on
+constexpr F16Shape kF16Small = {2, 3, 960};   // launches of fewer than 4 workgroups per CU in the large shape
 
 // CURVE: 0 = no curve (LINEAR: the conversion alone), 1 = a power curve above a split point (Apple, sRGB, ITU: the tables decide which)
 template <int CURVE, bool HAS_ALPHA, bool PAIRS, int NB, int RP>
@@ -195,7 +247,9 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
     }
   }
   if (HAS_TABLE) {
-    stage_table(lds_raw, hp.table, hp.table_bytes);  // after the tile's loads are in flight; the device copy starts with the guard entry T[h_min - 1]
+    // after the tile's loads are in flight; the device copy starts with the guard entry T[h_min - 1], the candidate entries
+    // follow the thresholds in memory and go to their fixed place in LDS (bt709_kernels.h kHalfCandLds)
+    stage_half_tables(lds_raw, hp.table, hp.cand_offset, hp.table_bytes);
     __syncthreads();
   }
   // pin every loaded word here: one wait for all of the tile's loads, before the first store (bt709_kernels.hip)
@@ -207,12 +261,8 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
       if (HAS_ALPHA) asm volatile("" : "+v"(aa[r][j]), "+v"(ab[r][j]));
     }
   HalfLookup t;
-  t.split = hp.split;
-  t.low_scale = hp.low_scale;
-  t.h_below = hp.h_min - 1u;
-  t.table_off = lds_address(lds_raw) + 4u - (hp.h_min << 2);
-  t.cand_off = lds_address(lds_raw) + hp.cand_offset - ((kHalfCandFirst & 0x3ffu) << 3);
-  const uint32_t opaque = 0x3c00u << 16;  // A = 1.0
+  t.index_scale = hp.index_scale;
+  t.below2 = (hp.h_min - 1u) * 0x10001u;
 
 #pragma unroll
   for (int r = 0; r < RP; ++r) {
@@ -220,7 +270,7 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const uint32_t bx = bx0 + j * blockDim.x;
-      float yv[4], av[4] = {0.f, 0.f, 0.f, 0.f};
+      float yv[4], av[4] = {0.f, 0.f, 0.f, 0.f}, alpha[4] = {1.0f, 1.0f, 1.0f, 1.0f};
       yv[0] = byte_of(ya[r][j], 0), yv[1] = byte_of(ya[r][j], 1), yv[2] = byte_of(yb[r][j], 0), yv[3] = byte_of(yb[r][j], 1);
       const float cb = byte_of(cw[r][j], 0), cr = byte_of(cw[r][j], 1);
       if (HAS_ALPHA) av[0] = byte_of(aa[r][j], 0), av[1] = byte_of(aa[r][j], 1), av[2] = byte_of(ab[r][j], 0), av[3] = byte_of(ab[r][j], 1);
@@ -228,20 +278,12 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
       float x[12];  // R, G, B of the block's four pixels
 #pragma unroll
       for (int px = 0; px < 4; ++px) pixel_rgb(yv[px], c, x[3 * px], x[3 * px + 1], x[3 * px + 2]);
-      uint32_t hc[12];
-      if constexpr (kF16Batch >= 12) {
-        half_codes<HAS_TABLE, 12>(t, x, hc);
-      } else {
-        half_codes<HAS_TABLE, kF16Batch>(t, x, hc);
-        half_codes<HAS_TABLE, 12 - kF16Batch>(t, x + kF16Batch, hc + kF16Batch);
+      if (HAS_ALPHA) {
+#pragma unroll
+        for (int px = 0; px < 4; ++px) alpha[px] = alpha_value(av[px]);  // linear alpha, unquantised
       }
       uint32_t w[8];  // per pixel {R | G << 16, B | A << 16}
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        const uint32_t ha = HAS_ALPHA ? (half_bits(alpha_value(av[px])) << 16) : opaque;  // linear alpha, unquantised
-        w[2 * px] = hc[3 * px] | (hc[3 * px + 1] << 16);
-        w[2 * px + 1] = hc[3 * px + 2] | ha;
-      }
+      half_texels<HAS_TABLE>(t, x, alpha, w);
       if (bx < blocks && rp < row_pairs) {
         uint8_t *o0 = f.out + static_cast<size_t>(2 * rp) * p.out_stride + 16 * bx;
         uint8_t *o1 = o0 + p.out_stride;
@@ -262,7 +304,8 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
 const char *launch_decode_rgba16f(const DecodeParams &p_in, const HalfParams &hp_in, int frames, bool has_alpha,
                                   uint32_t in_align, uint32_t out_align, uint32_t compute_units, bool xcd_bands, hipStream_t stream) {
   if (xcd_bands && p_in.uniform && frames > kXcdBandMinFrames && frames % 8 != 0) {
-    // any count of 64 frames or more: the XCD-aware map over the multiple of 8, the plain map over the rest (launch_decode)
+    // any count of 64 frames or more: the XCD-aware map over the multiple of 8, the plain map over the rest (launch_decode); shorter
+    // launches take the map only when their count IS a multiple of 8 (a second launch would cost more than the map returns)
     const int head = frames - frames % 8;
     launch_decode_rgba16f(p_in, hp_in, head, has_alpha, in_align, out_align, compute_units, xcd_bands, stream);
     DecodeParams tail = p_in;
@@ -279,30 +322,41 @@ const char *launch_decode_rgba16f(const DecodeParams &p_in, const HalfParams &hp
   // equal tiles of at most lanes * NB blocks, lanes rounded up to whole waves: 3840 -> 1 tile x 512 lanes x 4 blocks (480 busy),
   // 1920 -> 1 x 256, 7680 -> 2 x 512
   auto tiles_of = [&](const F16Shape &sh) { return (blocks + static_cast<uint32_t>(sh.lanes * sh.nb) - 1) / static_cast<uint32_t>(sh.lanes * sh.nb); };
-  const uint64_t large_groups = static_cast<uint64_t>(tiles_of(kF16Large)) * ((row_pairs + kF16Large.rp - 1) / kF16Large.rp) * static_cast<uint32_t>(frames);
-  const bool small = large_groups < 4ull * (compute_units ? compute_units : 256u);
-  const F16Shape sh = small ? kF16Small : kF16Large;
+  auto groups_of = [&](const F16Shape &sh) { return static_cast<uint64_t>(tiles_of(sh)) * ((row_pairs + sh.rp - 1) / sh.rp) * static_cast<uint32_t>(frames); };
+  const uint64_t fill = 4ull * (compute_units ? compute_units : 256u);
+  // 0 = large, 1 = narrow, 2 = small
+  const int which = groups_of(kF16Large) < fill ? 2 : (blocks <= 256u * static_cast<uint32_t>(kF16Narrow.nb) && groups_of(kF16Narrow) >= kF16NarrowMinGroupsPerSlot * fill ? 1 : 0);
+  const F16Shape sh = which == 2 ? kF16Small : (which == 1 ? kF16Narrow : kF16Large);
   const uint32_t tiles = tiles_of(sh);
   uint32_t threads = ((blocks + tiles - 1) / tiles + static_cast<uint32_t>(sh.nb) - 1) / static_cast<uint32_t>(sh.nb);
   threads = (threads + 63) / 64 * 64;
   hp.row_pairs_per_block = static_cast<uint32_t>(sh.rp);
   hp.wide_store = out_align >= 16 ? 1 : 0;
   dim3 grid(tiles, (row_pairs + static_cast<uint32_t>(sh.rp) - 1) / static_cast<uint32_t>(sh.rp), static_cast<uint32_t>(frames));
-  if (xcd_bands && frames >= kXcdBandMinFrames && frames % 8 == 0) {
+  if (xcd_bands && frames >= kF16BandMinFrames && frames % 8 == 0) {
     p.xcd_bands = 1;
     p.frames_per_band = static_cast<uint32_t>(frames) / 8u;
     grid = dim3(tiles * 8u, grid.y, p.frames_per_band);
   }
   const dim3 block(threads);
+  LaunchShape &shape = last_launch_shape();
+  if (shape.launches++ == 0) {
+    shape.grid[0] = grid.x, shape.grid[1] = grid.y, shape.grid[2] = grid.z;
+    shape.block[0] = block.x, shape.block[1] = block.y, shape.block[2] = block.z;
+    shape.xcd_bands = static_cast<int32_t>(p.xcd_bands);
+  }
   const bool pairs = in_align >= 2;
   const int curve = hp.table_bytes == 0 ? 0 : 1;
-  // the candidate index is 10 bits of x's float pattern (half_code): the allocation covers every value of it, the part behind the
-  // 641 real entries is never staged and never used (an x that reads it is below every split point)
-  const size_t lds = curve ? std::max<size_t>(hp.table_bytes, hp.cand_offset + 8u * (0x400u - (kHalfCandFirst & 0x3ffu))) : 16;
+  // thresholds from byte 0, candidate entries from kHalfCandLds (bt709_kernels.h); the host refuses a table that does not fit
+#ifndef BT709_RGBA16F_LDS_FLOOR
+#define BT709_RGBA16F_LDS_FLOOR 0  // lab: a larger allocation = fewer workgroups per CU (41 KiB: three instead of four)
+#endif
+  const size_t lds = curve ? std::max<size_t>(kHalfCandLds + (hp.table_bytes - hp.cand_offset), BT709_RGBA16F_LDS_FLOOR) : 16;
 #define BT709_LAUNCH_RGBA16F(C, A, P)                                                                                               \
   do {                                                                                                                              \
-    if (small) hipLaunchKernelGGL((decode_nv12_rgba16f<C, A, P, kF16Small.nb, kF16Small.rp>), grid, block, lds, stream, p, hp);      \
-    else hipLaunchKernelGGL((decode_nv12_rgba16f<C, A, P, kF16Large.nb, kF16Large.rp>), grid, block, lds, stream, p, hp);           \
+    if (which == 2) hipLaunchKernelGGL((decode_nv12_rgba16f<C, A, P, kF16Small.nb, kF16Small.rp>), grid, block, lds, stream, p, hp);        \
+    else if (which == 1) hipLaunchKernelGGL((decode_nv12_rgba16f<C, A, P, kF16Narrow.nb, kF16Narrow.rp>), grid, block, lds, stream, p, hp); \
+    else hipLaunchKernelGGL((decode_nv12_rgba16f<C, A, P, kF16Large.nb, kF16Large.rp>), grid, block, lds, stream, p, hp);                  \
   } while (0)
 #define BT709_LAUNCH_RGBA16F_AP(C)                                                            \
   do {                                                                                        \
@@ -323,7 +377,7 @@ hipError_t prepare_rgba16f_kernels() {
   reinterpret_cast<const void *>(&decode_nv12_rgba16f<0, false, true, NB, RP>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<0, false, false, NB, RP>), \
   reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, true, true, NB, RP>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, true, false, NB, RP>),   \
   reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, false, true, NB, RP>), reinterpret_cast<const void *>(&decode_nv12_rgba16f<1, false, false, NB, RP>)
-  const void *fns[] = {BT709_F16_FNS(kF16Large.nb, kF16Large.rp), BT709_F16_FNS(kF16Small.nb, kF16Small.rp)};
+  const void *fns[] = {BT709_F16_FNS(kF16Large.nb, kF16Large.rp), BT709_F16_FNS(kF16Narrow.nb, kF16Narrow.rp), BT709_F16_FNS(kF16Small.nb, kF16Small.rp)};
 #undef BT709_F16_FNS
   for (const void *fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

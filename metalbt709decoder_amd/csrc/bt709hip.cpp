@@ -232,9 +232,7 @@ int ensure_half_table(bt709hip_decoder *dec, void *stream) {
   HalfParams hp = {};
   hp.split = t.split;
   hp.low_scale = t.low_scale;
-  hp.pre_add = t.pre_add;
-  hp.pre_scale = t.pre_scale;
-  hp.exponent = t.exponent;
+  hp.index_scale = t.index_scale;
   hp.h_min = t.h_min;
   if (t.split <= 1.0f) {  // a curve: the table covers [h_min, H(1.0)]; its last real entry is followed by +inf
     size_t real = t.thresholds.size();
@@ -248,10 +246,12 @@ int ensure_half_table(bt709hip_decoder *dec, void *stream) {
     image.push_back(std::numeric_limits<float>::infinity());
     image.push_back(std::numeric_limits<float>::infinity());
     while (image.size() % 4 != 0) image.push_back(std::numeric_limits<float>::infinity());
-    hp.cand_offset = static_cast<uint32_t>(image.size() * sizeof(float));  // the candidate tangents ride behind the thresholds
+    hp.cand_offset = static_cast<uint32_t>(image.size() * sizeof(float));  // the candidate entries ride behind the thresholds
     image.insert(image.end(), t.cand.begin(), t.cand.end());
     while (image.size() % 4 != 0) image.push_back(0.0f);
     hp.table_bytes = static_cast<uint32_t>(image.size() * sizeof(float));
+    // the kernel's LDS plan (bt709_kernels.h kHalfCandLds): thresholds below the fixed start of the candidates, all under 40 KiB
+    if (hp.cand_offset > kHalfCandLds || kHalfCandLds + (hp.table_bytes - hp.cand_offset) > 40u * 1024u) return BT709HIP_ERR_UNSUPPORTED;
     void *d = nullptr;
     if (int rc = upload_table(image.data(), hp.table_bytes, &d)) return rc;
     hp.table = d;
@@ -995,6 +995,7 @@ int decode_batch_now(bt709hip_decoder *dec, int count, const bt709hip_frame *fra
   hipStream_t s = pick(dec->ctx, stream);
   if (info.format == BT709HIP_FORMAT_RGBA16F) {  // the reference's pre-10.14 intermediate: linear-light halves
     if (int rc = ensure_half_table(dec, stream)) return rc;
+    last_launch_shape() = LaunchShape{};
     tl_kernel_name = launch_decode_rgba16f(p, dec->half, count, dec->has_alpha != 0, info.in_align, info.out_align,
                                            static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), dec->xcd_bands != 0, s);
     return finish_launch(s, wait_until_completed);

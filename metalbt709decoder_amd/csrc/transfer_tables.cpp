@@ -248,28 +248,70 @@ bool build_half_table(int gamma, HalfTable *out) {
   }
   out->thresholds.push_back(inf);  // T[h_max + 1]
   while (out->thresholds.size() % 4 != 0) out->thresholds.push_back(inf);
-  // candidate tangents (transfer_tables.h), slope / intercept form: p(x) = slope * x + intercept is the tangent of the curve at
-  // x_q scaled by `keep` = 1 - 2^-19.  Computed in double from the curve's constants; both floats are then moved one step
-  // toward a SMALLER p (the slope is positive and x > 0: down; the intercept: down), so that neither their rounding, nor the
-  // fma's own, nor the reference's float steps can lift p above the true value (tests/native/half_candidate_sweep.cpp checks
-  // every float from the split to 1.0).
+  // The index scale (transfer_tables.h): a float s with RN(split * s) >= 2^-4 > RN(pred(split) * s), searched among the
+  // neighbours of 2^-4 / split -- the interval of real s that works is about one float wide, and the product's own rounding
+  // decides; the build fails if none of them does (it does for all three curves).
+  {
+    const float edge = 0.0625f, below = std::nextafter(out->split, 0.0f);
+    const uint32_t s0 = to_bits(edge / out->split);
+    bool found = false;
+    for (int d = 0; d <= 16 && !found; ++d) {
+      for (int sign = -1; sign <= 1 && !found; sign += 2) {
+        const float s = from_bits(s0 + static_cast<uint32_t>(sign * d));
+        volatile float at = out->split * s, under = below * s;
+        if (at >= edge && under < edge) {
+          out->index_scale = s;
+          found = true;
+        }
+      }
+    }
+    if (!found) return false;
+  }
+  // Candidate entries, slope / intercept form.  Bucket 0 (below the split): the exact product.  Bucket i >= 1: p(x) = slope *
+  // x + intercept is the tangent of the curve at x_q = the bucket's first float (bisected on the index function itself; x_q of
+  // bucket 1 is the split point) scaled by `keep` = 1 - 2^-19.  Computed in double from the curve's constants; both floats are
+  // then moved one step toward a SMALLER p (the slope is positive and x > 0: down; the intercept: down), so that neither their
+  // rounding, nor the fma's own, nor the reference's float steps can lift p above the true value
+  // (tests/native/half_candidate_sweep.cpp checks every float from 0 to 1.0).
   out->cand.clear();
+  out->cand.push_back(0.0f);
+  out->cand.push_back(out->low_scale);
   const double a = out->pre_add, s = out->pre_scale, g = out->exponent, keep = 1.0 - 1.0 / 524288.0;
   const float ninf = -std::numeric_limits<float>::infinity();
-  for (uint32_t k = kHalfCandFirst; k < kHalfCandFirst + kHalfCandCount; ++k) {
-    const double xq = from_bits(k << 16);
+  const uint32_t last = half_cand_index(*out, 1.0f);
+  uint32_t start = lo_bits;
+  for (uint32_t i = 1; i <= last; ++i) {
+    uint32_t lo = start, hi = hi_bits;  // the index is monotone in x: bisect on the bit pattern
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (half_cand_index(*out, from_bits(mid)) >= i) hi = mid;
+      else lo = mid + 1;
+    }
+    start = lo;
+    const double xq = from_bits(lo);
     const double base = (xq + a) * s;
     const double value = std::pow(base, g) * keep, slope = g * s * std::pow(base, g - 1.0) * keep;
     out->cand.push_back(std::nextafter(static_cast<float>(value - slope * xq), ninf));
     out->cand.push_back(std::nextafter(static_cast<float>(slope), ninf));
   }
+  if (half_cand_index(*out, out->split) != 1 || half_cand_index(*out, std::nextafter(out->split, 0.0f)) != 0) return false;
   return true;
 }
 
+uint32_t half_cand_index(const HalfTable &t, float x) {
+  volatile float u = x * t.index_scale;  // v_pk_mul_f32: one binary32 rounding
+  const uint32_t ub = to_bits(u);
+  // v_cvt_pkrtz_f16_f32 of a u in [2^-14, 65504): rebias the exponent, drop 13 mantissa bits.  Smaller u (binary16
+  // subnormals, zero) convert to something below the floor and are held there by the max, whatever the hardware makes of them.
+  uint32_t hb = ub >= (113u << 23) ? (ub - (112u << 23)) >> 13 : 0u;
+  if (hb < kHalfCandFloor) hb = kHalfCandFloor;
+  return (hb >> 3) - (kHalfCandFloor >> 3);
+}
+
 float half_candidate(const HalfTable &t, float x) {
-  const uint32_t xb = to_bits(x), k = xb >> 16;
-  if (t.cand.empty() || k < kHalfCandFirst || k >= kHalfCandFirst + kHalfCandCount) return 0.0f;
-  volatile float p = std::fmaf(x, t.cand[2 * (k - kHalfCandFirst) + 1], t.cand[2 * (k - kHalfCandFirst)]);  // the kernel's one v_fma_f32
+  if (t.cand.empty() || !(x >= 0.0f && x <= 1.0f)) return 0.0f;
+  const uint32_t i = half_cand_index(t, x);
+  volatile float p = std::fmaf(x, t.cand[2 * i + 1], t.cand[2 * i]);  // the kernel's one v_fma_f32
   return p;
 }
 

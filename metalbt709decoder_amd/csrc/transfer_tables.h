@@ -146,30 +146,39 @@ bool build_uniform_table(int kind, uint32_t n_min, UniformTable *out);
 // kernel takes a CANDIDATE h0 that is H or H - 1 and settles it against the threshold above it:
 //     H = h0 + (x >= T[h0 + 1]),   T[h] = smallest float x with H(x) >= h
 // T is indexed by the OUTPUT code, so it holds exactly one entry per step (8-9 k entries, ~34 KiB).
-// The candidate (round 4; rounds 2-3 took it from v_log_f32 / v_exp_f32, two quarter-rate instructions per channel):
-// the TANGENT of the curve at the start of x's bucket, buckets = the floats that share x's exponent and top 7 mantissa
-// bits (index = bits(x) >> 16, kHalfCandFirst .. bits(1.0f) >> 16: 641 entries {intercept, slope} from 2^-5 to 1.0):
-//     p = slope * x + intercept = value(x_q) + (x - x_q) * slope,   x_q = x with the low 16 bits cleared; ONE fma (round 5;
-//     round 4 subtracted x_q first)
+// The candidate: the TANGENT of the curve at the start of x's bucket (rounds 2-3 took it from v_log_f32 / v_exp_f32, two
+// quarter-rate instructions per channel; round 4 introduced the tangents), {intercept, slope}:
+//     p = slope * x + intercept,   ONE fma
 // The curves are convex powers, so the tangent lies BELOW the curve, by at most g(g-1)/2 * 2^-14 = 1.0e-4 of the value
 // (g <= 2.4) at the far end of a bucket -- a fifth of a half's spacing (2^-11 of the value) -- and intercept and slope carry a
 // further factor 1 - 2^-19 and are rounded toward a smaller p, so that neither their rounding, the fma's, nor the reference's
 // own float steps can lift p above the true value: half(p) is H or H - 1, never H + 1.
+// Buckets (round 5, second form): the index comes from ONE v_cvt_pkrtz_f16_f32 over a PAIR of channels --
+//     u = x * index_scale (binary32, round to nearest);  hb = max(half_rtz(u), kHalfCandFloor);  bucket = hb >> 3
+// -- i.e. the values u sharing a binary16 exponent and 7 mantissa bits.  index_scale is chosen per curve so that the curve's
+// SPLIT POINT maps exactly onto the bucket boundary u = 2^-4 (kHalfCandEdge): x >= split  <=>  bucket >= 1.  Bucket 0 --
+// everything below the split, held there by the max -- has the entry {0, low_scale}: p = fma(x, low_scale, +0) IS the
+// reference's exact product x * low_scale of the piece below the split.  So the kernel needs neither the comparison with the
+// split, nor the select between product and tangent, nor the product itself (rounds 2-5a: three more instructions per
+// channel), and two channels share the conversion, the max and -- after the fma -- the v_cvt_pk_f16_f32 and the saturating
+// subtraction that indexes T.  Rounds 4-5a indexed by bits(x) >> 16 from 2^-5 (641 entries).
 struct HalfTable {
   int gamma = 0;
   float split = 0.0f;      // x < split: H(x) = half(x * low_scale) (exact product); kGammaLinear: split = 2 (always)
   float low_scale = 1.0f;  // 1/16, 1/12.92f, 1, 1/4.5f (float constants of the reference)
-  // candidate: base = (x + pre_add) * pre_scale; h0 = half(exp2(exponent * log2(base)))
-  float pre_add = 0.0f, pre_scale = 1.0f, exponent = 1.0f;
+  float pre_add = 0.0f, pre_scale = 1.0f, exponent = 1.0f;  // the curve above the split: ((x + pre_add) * pre_scale) ^ exponent
+  float index_scale = 1.0f;  // s above: RN(split * s) >= 2^-4 > RN(pred(split) * s)
   uint32_t h_min = 0;      // H(split): first code the table covers
   // T[i] = smallest x with H(x) >= h_min + i (T[0] may lie below the split); one +inf entry past H(1.0); padded to 16 bytes
   std::vector<float> thresholds;
-  // candidate tangents: {intercept, slope} of bucket k = kHalfCandFirst + i (x_q = the float with bits k << 16); empty without a curve
+  // candidate entries {intercept, slope} of bucket i = 0 .. half_cand_index(1.0); [0] = {0, low_scale}; empty without a curve
   std::vector<float> cand;
 };
-constexpr uint32_t kHalfCandFirst = 0x3d00u;                     // bits(2^-5) >> 16: below every curve's split point
-constexpr uint32_t kHalfCandCount = 0x3f80u - kHalfCandFirst + 1;  // ... up to bits(1.0f) >> 16
-// the candidate exactly as the kernel forms it (one float subtraction, one fma), for host-side replay
+constexpr uint32_t kHalfCandEdge = 0x2c00u;                // binary16 bits of 2^-4: where the split point lands
+constexpr uint32_t kHalfCandFloor = kHalfCandEdge - 8u;    // the bucket below it: every x under the split is held here
+// bucket of x, computed exactly as the kernel does (product, round-toward-zero conversion, max, shift)
+uint32_t half_cand_index(const HalfTable &t, float x);
+// the candidate exactly as the kernel forms it (the bucket's entry, one fma), for host-side replay
 float half_candidate(const HalfTable &t, float x);
 uint16_t float_to_half(float v);               // IEEE binary32 -> binary16, round to nearest even
 float curve_to_linear(int gamma, float v);     // the per-gamma video curve alone (what pass 1 writes to a float target)

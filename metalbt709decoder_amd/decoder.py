@@ -552,12 +552,16 @@ class MetalRenderContext:
         return out.view(np.uint32).reshape(tex.height, tex.width)
 
     # -- internals
-    def _upload(self, dptr, dpitch, arr, commandBuffer):
+    def _upload(self, dptr, dpitch, arr, commandBuffer, wait=True):
+        """bt709hip_upload is asynchronous and `arr` is pageable numpy memory, often a temporary of the caller: the copy is
+        waited for here (wait=False: the caller keeps `arr` alive and unchanged until it synchronises the stream itself)."""
         if arr.size == 0:
             return
         stream = commandBuffer.stream if commandBuffer else None
         _capi.check(self.lib.bt709hip_upload(self.handle, dptr, dpitch, arr.ctypes.data, arr.shape[1],
                                              arr.shape[1], arr.shape[0], stream), "upload")
+        if wait:
+            self._sync(commandBuffer)
 
     def _sync(self, commandBuffer):
         stream = commandBuffer.stream if commandBuffer else None

@@ -309,17 +309,25 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
     n = fused = 0
     for kernel in ("17decode_nv12_quads", "22decode_nv12_quads_rows", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
                    "18decode_nv12_scaled", "19decode_nv12_rgba16fILi0E", "19decode_nv12_rgba16fILi1E", "13render_scaled"):
-        # RGBA16F curve variant: the half CANDIDATE (bt709_rgba16f.hip half_code; not reference arithmetic -- the threshold
-        # table settles it, and tests/test_rgba16f.py sweeps it over every float) is the tangent slope * x + intercept:
-        # one fma with three REGISTER operands per channel, 4 pixels x 3 channels per 2x2 block, NB x RP blocks per lane
-        # (round 5: the two shipped shapes, template arguments 4 and 5), nothing else.  Round 4 took the quarter-rate
-        # v_log_f32 / v_exp_f32 out of the kernel.
+        # RGBA16F curve variant: the half CANDIDATE (bt709_rgba16f.hip half_texels; not reference arithmetic -- the threshold
+        # table settles it, and tests/test_rgba16f.py sweeps it over every float) is slope * x + intercept: one fma with three
+        # REGISTER operands per channel, 4 pixels x 3 channels per 2x2 block, NB x RP blocks per lane (the three shipped
+        # shapes, template arguments 4 and 5), nothing else; and its bucket index comes from the ONE packed float instruction
+        # of these kernels, v_pk_mul_f32 by the index scale, a pair of channels per instruction (6 per block): an index
+        # function, not reference arithmetic.  No v_log_f32 / v_exp_f32 (round 4 took them out), no comparison with the
+        # split point, no select (round 5, packed-pair form).
         for body in _kernel_bodies(asm, kernel):
-            candidate_fmas = 0
+            candidate_fmas = index_muls = 0
             if kernel == "19decode_nv12_rgba16fILi1E":
                 nb, rp = map(int, re.search(r"19decode_nv12_rgba16fILi1ELb[01]ELb[01]ELi(\d+)ELi(\d+)EE", body).groups())
-                assert (nb, rp) in ((4, 2), (2, 3))
-                candidate_fmas = 12 * nb * rp
+                assert (nb, rp) in ((4, 2), (4, 3), (2, 3))
+                candidate_fmas, index_muls = 12 * nb * rp, 6 * nb * rp
+                assert len(re.findall(r"\bv_cvt_pkrtz_f16_f32", body)) == index_muls and len(re.findall(r"\bv_pk_max_u16", body)) == index_muls
+                assert len(re.findall(r"\bv_cvt_pk_f16_f32", body)) == 8 * nb * rp       # (R, G) and (B, A) of every pixel
+                assert len(re.findall(r"\bds_read_b64", body)) == 12 * nb * rp and len(re.findall(r"\bds_read_b32", body)) == 12 * nb * rp
+                assert not re.search(r"\bv_cmp_(lt|gt)_f32", body)                      # nothing is compared with the split point
+            if kernel == "19decode_nv12_rgba16fILi0E":
+                assert "ds_read" not in body and not re.search(r"\bv_cvt_f16_f32", body)  # LINEAR: the packed conversion alone
             candidate = 0
             for line in re.findall(r"^\s*(v_(?:pk_)?(?:fma|fmac|fmamk|fmaak|mad|mac|madmk|madak)_(?:f32|f16|legacy|mix)\w*\s[^\n]*)", body, flags=re.M):
                 if candidate_fmas and re.match(r"v_fmac_f32_e32 v\d+, v\d+, v\d+$|v_fma_f32 v\d+, v\d+, v\d+, v\d+$", line.strip()):
@@ -329,11 +337,19 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
                     continue  # the uniform encode table's index, bits(fma(sum, k, 2^23)): an index function, not reference arithmetic
                 assert re.match(r"v_fmamk_f32 v\d+, v\d+, 0x3b808081, v\d+|v_fmac_f32_e32 v\d+, 0x3b808081, v\d+", line), (kernel, line)
                 fused += 1
-            assert not re.search(r"\bv_pk_(fma|mul|add)_f32", body), kernel  # half-rate packed f32 ops stay out (-fno-slp-vectorize)
+            assert not re.search(r"\bv_pk_(fma|add)_f32", body), kernel  # half-rate packed f32 ops stay out (-fno-slp-vectorize)
+            assert len(re.findall(r"\bv_pk_mul_f32", body)) == index_muls, kernel
             assert candidate == candidate_fmas, (kernel, candidate)
             assert not re.search(r"\bv_(log|exp)_f32", body), kernel  # no transcendental left in any decode kernel
             n += 1
-    assert n == 47  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in two shapes, the 1:1 kernel's big-table form)
+    assert n == 55  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in three shapes, the 1:1 kernel's big-table form)
+    # the RGBA16F kernels address LDS absolutely (table at byte 0): the dynamic allocation must be their only LDS
+    seen = 0
+    for m in re.finditer(r"\.group_segment_fixed_size:\s+(\d+)\s.*?\.name:\s+(\S+)", asm, flags=re.S):
+        if "decode_nv12_rgba16f" in m.group(2):
+            assert int(m.group(1)) == 0, m.group(2)
+            seen += 1
+    assert seen == 24
     assert fused > 300
 
 

@@ -96,11 +96,13 @@ def test_half_lookup_correction_step(pass2):
 
 
 def test_half_candidate_is_H_or_H_minus_1_for_every_float(tmp_path, oracle):
-    """Round 4: the RGBA16Float kernel takes its candidate from a table of tangents (one exact subtraction + one fma) instead
-    of v_log_f32 / v_exp_f32.  The host replay of exactly those two operations over the product's own table, for EVERY float
-    from each curve's split point to 1.0 (36-38 million per gamma), against the oracle's curve with the reference's double
-    pow: the candidate never exceeds the true value and its half is H or H - 1 -- what the single-threshold settlement needs
-    (tests/native/half_candidate_sweep.cpp).  The GPU sweeps over all 2^24 triples check the kernel's end result."""
+    """The RGBA16Float kernel takes its candidate from a table of tangents indexed by a round-toward-zero binary16 bucket of
+    the scaled channel (ONE fma; bucket 0 = everything below the curve's split point = the reference's exact product).  The
+    host replay of exactly those operations over the product's own table, for EVERY float from 0 to 1.0 (1.07 billion per
+    gamma), against the oracle's curve with the reference's double pow: the candidate never exceeds the true value, its half
+    is H or H - 1 -- what the single-threshold settlement needs -- and below the split point it is H itself, the bucket
+    boundary sitting exactly on the split (tests/native/half_candidate_sweep.cpp).  The GPU sweeps over all 2^24 triples
+    check the kernel's end result."""
     import ctypes as C
     import subprocess
     out = str(tmp_path / "libhalf_candidate_sweep.so")
@@ -115,12 +117,12 @@ def test_half_candidate_is_H_or_H_minus_1_for_every_float(tmp_path, oracle):
     lib = C.CDLL(out)
     threads = max(1, min(16, len(os.sched_getaffinity(0))))
     for gamma in (0, 1, 3):  # Apple, sRGB, ITU-709: the curves (LINEAR has no curve and no candidate)
-        res = (C.c_uint64 * 5)()
+        res = (C.c_uint64 * 6)()
         assert lib.sweep_half_candidate(gamma, threads, res) == 0
-        swept, above, outside, below, first = list(res)
-        assert swept > 30_000_000 and above == 0 and outside == 0, (gamma, swept, above, outside, hex(first))
-        assert 0 < below < swept // 4  # the tangent is low by up to a fifth of a half's spacing: H - 1 happens, not often
-    assert lib.sweep_half_candidate(2, threads, (C.c_uint64 * 5)()) == -1
+        swept, above, outside, below, first, curve = list(res)
+        assert swept == 0x3f800001 and curve > 30_000_000 and above == 0 and outside == 0, (gamma, swept, above, outside, hex(first))
+        assert 0 < below < curve // 4  # the tangent is low by up to a fifth of a half's spacing: H - 1 happens, not often
+    assert lib.sweep_half_candidate(2, threads, (C.c_uint64 * 6)()) == -1
 
 
 # ------------------------------------------------------------------ GPU
@@ -238,6 +240,49 @@ def test_gpu_rgba16f_xcd_band_work_map(gh, oracle, n, size):
         assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True), dec.lastStatus
         for (y, c), t in zip(frames, texs):
             assert np.array_equal(ctx.getBGRATexturePixels(t).view(np.uint16), oracle.decode_nv12_rgba16f(0, y, c).view(np.uint16)), bands
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (frames, (width, height), band option) -> (grid, block, bands used): the shape bt709_rgba16f.hip's launcher must pick
+    (16, (1920, 1080), 1, ((8, 270, 2), 256, 1)),   # large shape (4 blocks x 2 row pairs), 240 of 256 lanes busy, XCD map from 8 frames on
+    (16, (1920, 1080), 0, ((1, 270, 16), 256, 0)),  # the same launch under the plain map
+    (6, (1920, 1080), 1, ((1, 270, 6), 256, 0)),    # not a multiple of 8 and short: plain map, one launch
+    (288, (64, 1026), 1, ((8, 171, 36), 64, 1)),    # narrow shape (4 x 3): >= 48 workgroups per slot on rows of <= 1 024 blocks
+    (3, (3840, 2160), 1, ((1, 540, 3), 512, 0)),     # 1 620 workgroups in the large shape, past one per slot: large; 480 of 512 lanes busy
+    (1, (3840, 2160), 1, ((1, 360, 1), 960, 0)),    # a single 4K frame: the small shape (2 x 3, 960 lanes)
+])
+def test_gpu_rgba16f_work_shapes(gh, oracle, case):
+    """The three work shapes of the RGBA16Float kernel and both work maps, each asserted through bt709hip_last_launch_info
+    and checked against the oracle: rows of whole frames at the start, in the middle and at the end of the launch (every
+    frame for the small ones)."""
+    import ctypes as C
+    from metalbt709decoder_amd.decoder import DeviceBuffer
+    n, (w, h), bands, (grid, block, used) = case
+    ctx = gh.context()
+    if ctx.info().compute_units != 256:
+        pytest.skip("shape thresholds asserted for 256 CUs")
+    in_pitch, out_pitch = w * h * 3 // 2, w * h * 8
+    slab_in, slab_out = DeviceBuffer(ctx, n * in_pitch), DeviceBuffer(ctx, n * out_pitch)
+    distinct = [_frame(w, h, 900 + i) for i in range(min(n, 5))]
+    bufs, texs = [], []
+    for i in range(n):
+        y, c = distinct[i % len(distinct)]
+        base = slab_in.ptr + i * in_pitch
+        b = mb.CVPixelBuffer(ctx, w, h, w, w, planes=(base, base + w * h))
+        mb.BGRAToBT709Converter.setBT709Attributes(b)
+        b.upload_planes(y, c)
+        bufs.append(b)
+        texs.append(mb.BGRATexture(ctx, w, h, w * 8, ptr=slab_out.ptr + i * out_pitch, pixelFormat=mb.MTLPixelFormatRGBA16Float))
+    dec = gh.make_decoder(mb.MetalBT709GammaApple, options={_capi.OPT_XCD_BANDS: bands})
+    _capi.check(ctx.lib.bt709hip_memset(ctx.handle, slab_out.ptr, 0, n * out_pitch, None))
+    assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True), dec.lastStatus
+    info = _capi.LaunchInfo()
+    _capi.check(ctx.lib.bt709hip_last_launch_info(C.byref(info)))
+    assert (tuple(info.grid), info.block[0], info.xcd_bands, info.launches) == (grid, block, used, 1)
+    want = [oracle.decode_nv12_rgba16f(0, y, c).view(np.uint16) for y, c in distinct]
+    for i in sorted(set(range(n)) if n <= 16 else {0, 1, n // 8 - 1, n // 8, n // 2, n - n // 8 - 1, n - 2, n - 1}):
+        assert np.array_equal(ctx.getBGRATexturePixels(texs[i]).view(np.uint16), want[i % len(distinct)]), i
 
 
 @pytest.mark.gpu

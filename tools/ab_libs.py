@@ -92,6 +92,7 @@ def main():
     for i in range(RING):
         buf = rng.integers(0, 256, (1, yb + cb), dtype=np.uint8)
         ok(lib0, lib0.bt709hip_upload(h0, d_in.value + i * in_stride, buf.shape[1], buf.ctypes.data, buf.shape[1], buf.shape[1], 1, None))
+        lib0.bt709hip_stream_synchronize(h0, None)  # the upload is asynchronous and `buf` is replaced in the next round
     ok(lib0, lib0.bt709hip_stream_synchronize(h0, None))
     frames, surfs = (Frame * RING)(), (Surface * RING)()
     for i in range(RING):

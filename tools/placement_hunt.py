@@ -35,6 +35,7 @@ for t in range(TRIES):
     _capi.check(lib.bt709hip_malloc(h, ob * RING, C.byref(d_out)))
     for i in range(RING):
         _capi.check(lib.bt709hip_upload(h, d_in.value + i * in_stride, buf.shape[1], buf.ctypes.data, buf.shape[1], buf.shape[1], 1, None))
+        lib.bt709hip_stream_synchronize(h, None)  # the upload is asynchronous and `buf` is replaced in the next round
     _capi.check(lib.bt709hip_stream_synchronize(h, None))
     frames, surfs = (Frame * RING)(), (Surface * RING)()
     for i in range(RING):
