@@ -205,12 +205,15 @@ int bt709hip_graph_launch(bt709hip_context *ctx, void *graph, void *stream);
 int bt709hip_graph_destroy(bt709hip_context *ctx, void *graph);
 
 /* Device memory ~ make*Texture / fill* / get*TexturePixels
- * (MetalRenderContext.h:62-105).  upload/download are asynchronous on `stream`
- * (hipMemcpy2DAsync); host memory should be pinned for true overlap
- * (bt709hip_host_alloc).  The host buffer must stay allocated and unchanged until the
- * stream has passed the copy (bt709hip_stream_synchronize, an event, or a later call
- * with wait_until_completed on the same stream): freeing pageable memory under a copy
- * in flight is a GPU memory access fault, not an error code.  Pitches are bytes;
+ * (MetalRenderContext.h:62-105).  upload/download are enqueued on `stream`
+ * (hipMemcpy2DAsync).  With PINNED host memory (bt709hip_host_alloc) they are asynchronous:
+ * the buffer must stay allocated and unchanged until the stream has passed the copy
+ * (bt709hip_stream_synchronize, an event, or a later call with wait_until_completed on the
+ * same stream).  With PAGEABLE host memory (malloc, a std::vector, numpy) the call waits for
+ * the copy before it returns, like the reference's fill... / get...Pixels methods
+ * (MetalRenderContext.m:122-160) -- the runtime would otherwise keep reading a buffer its
+ * owner is free to release, which is a GPU memory access fault, not an error code.  (While
+ * `stream` is being captured into a graph nothing is waited for.)  Pitches are bytes;
  * `row_bytes` x `rows` is copied. */
 int bt709hip_malloc(bt709hip_context *ctx, size_t bytes, void **dptr);
 int bt709hip_free(bt709hip_context *ctx, void *dptr);

@@ -715,6 +715,22 @@ int bt709hip_memset(bt709hip_context *ctx, void *dptr, int value, size_t bytes, 
   return BT709HIP_OK;
 }
 
+extern "C++" {
+namespace {
+// Host memory that HIP has not pinned or registered (malloc, numpy, a std::vector): an asynchronous copy from or to it keeps
+// reading or writing it after the call has returned -- the runtime pins the pages on the fly -- and a caller that frees the
+// buffer meanwhile takes a GPU memory access fault (round 5: tools/ab_libs.py did, profiles/r05_ab_rgba16f_packed.txt 6).
+bool pageable(const void *host) {
+  hipPointerAttribute_t attr = {};
+  if (hipPointerGetAttributes(&attr, host) != hipSuccess) {
+    (void)hipGetLastError();  // older runtimes report an unregistered pointer as an error
+    return true;
+  }
+  return attr.type == hipMemoryTypeUnregistered;
+}
+}  // namespace
+}  // extern "C++"
+
 int bt709hip_upload(bt709hip_context *ctx, void *dst_dev, size_t dst_pitch, const void *src_host,
                     size_t src_pitch, size_t row_bytes, size_t rows, void *stream) {
   if (int rc = bind(ctx)) return rc;
@@ -722,8 +738,11 @@ int bt709hip_upload(bt709hip_context *ctx, void *dst_dev, size_t dst_pitch, cons
   if (dst_dev == nullptr || src_host == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (dst_pitch < row_bytes || src_pitch < row_bytes) return BT709HIP_ERR_STRIDE;
   FLUSH_STREAM(ctx, stream);
-  HIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_host, src_pitch, row_bytes, rows, hipMemcpyHostToDevice,
-                           pick(ctx, stream)));
+  hipStream_t s = pick(ctx, stream);
+  HIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_host, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, s));
+  // pageable source: the copy is complete when the call returns (the reference's fill* methods are synchronous,
+  // MetalRenderContext.m:122-160); pinned memory (bt709hip_host_alloc) stays asynchronous
+  if (!capturing(s) && pageable(src_host)) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;
 }
 
@@ -734,8 +753,9 @@ int bt709hip_download(bt709hip_context *ctx, void *dst_host, size_t dst_pitch, c
   if (dst_host == nullptr || src_dev == nullptr) return BT709HIP_ERR_INVALID_ARG;
   if (dst_pitch < row_bytes || src_pitch < row_bytes) return BT709HIP_ERR_STRIDE;
   FLUSH_STREAM(ctx, stream);
-  HIP_TRY(hipMemcpy2DAsync(dst_host, dst_pitch, src_dev, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost,
-                           pick(ctx, stream)));
+  hipStream_t s = pick(ctx, stream);
+  HIP_TRY(hipMemcpy2DAsync(dst_host, dst_pitch, src_dev, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost, s));
+  if (!capturing(s) && pageable(dst_host)) HIP_TRY(hipStreamSynchronize(s));  // as above: a pageable target is filled on return
   return BT709HIP_OK;
 }
 

@@ -46,6 +46,7 @@ struct Runtime {
   std::atomic<uint64_t> host_allocs{0}, streams{0}, events{0};
   std::vector<double> order_rates;
   size_t order_next = 0;
+  std::map<const char *, size_t> pinned;  // hipHostMalloc'ed ranges (under m): hipPointerGetAttributes tells them from pageable memory
 };
 Runtime &rt() {
   static Runtime *r = new Runtime();  // never destroyed: worker threads may outlive main's statics
@@ -325,10 +326,29 @@ hipError_t hipHostMalloc(void **ptr, size_t bytes, unsigned) {
   *ptr = std::malloc(bytes ? bytes : 1);
   if (*ptr == nullptr) return fail(hipErrorOutOfMemory);
   rt().host_allocs.fetch_add(1);
+  {
+    std::lock_guard<std::mutex> lk(rt().m);
+    rt().pinned[static_cast<const char *>(*ptr)] = bytes ? bytes : 1;
+  }
+  return hipSuccess;
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *attributes, const void *ptr) {
+  if (attributes == nullptr) return fail(hipErrorInvalidValue);
+  attributes->type = hipMemoryTypeUnregistered;
+  std::lock_guard<std::mutex> lk(rt().m);
+  auto it = rt().pinned.upper_bound(static_cast<const char *>(ptr));
+  if (it != rt().pinned.begin()) {
+    --it;
+    if (static_cast<const char *>(ptr) < it->first + it->second) attributes->type = hipMemoryTypeHost;
+  }
   return hipSuccess;
 }
 hipError_t hipHostFree(void *ptr) {
   if (ptr == nullptr) return hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(rt().m);
+    rt().pinned.erase(static_cast<const char *>(ptr));
+  }
   std::free(ptr);
   rt().host_allocs.fetch_sub(1);
   return hipSuccess;

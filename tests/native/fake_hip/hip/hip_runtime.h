@@ -67,6 +67,11 @@ hipError_t hipMalloc(void **ptr, size_t bytes);
 hipError_t hipFree(void *ptr);
 hipError_t hipHostMalloc(void **ptr, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void *ptr);
+typedef enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 } hipMemoryType;
+typedef struct hipPointerAttribute_t {
+  hipMemoryType type;
+} hipPointerAttribute_t;
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *attributes, const void *ptr);
 hipError_t hipMemGetInfo(size_t *free_bytes, size_t *total_bytes);
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream);

@@ -404,6 +404,42 @@ static void test_graphs_and_misc() {
   OK(bt709hip_context_destroy(ctx));
 }
 
+// Host-buffer lifetime of bt709hip_upload / _download: from PAGEABLE memory the copy is complete on return -- the buffer is
+// overwritten (upload) or read (download) straight away here, which under TSan is a reported race with the stream's worker
+// if the call had not waited, and a wrong byte otherwise; from PINNED memory (bt709hip_host_alloc) the call does not wait.
+static void test_host_buffer_lifetime() {
+  fake_hip_reset();
+  bt709hip_context *ctx = nullptr;
+  OK(bt709hip_context_create(0, &ctx));
+  void *s = nullptr, *dev = nullptr, *pinned = nullptr;
+  OK(bt709hip_stream_create_with_priority(ctx, 0, &s));
+  const size_t n = 1u << 20;
+  OK(bt709hip_malloc(ctx, n, &dev));
+  OK(bt709hip_host_alloc(ctx, n, &pinned));
+  for (void *stream : {static_cast<void *>(nullptr), s}) {
+    for (int round = 0; round < 20; ++round) {
+      std::vector<uint8_t> src(n, static_cast<uint8_t>(round + 1));
+      OK(bt709hip_upload(ctx, dev, 1024, src.data(), 1024, 1024, n / 1024, stream));
+      std::memset(src.data(), 0xee, n);  // the caller's buffer is the caller's again
+      std::vector<uint8_t> back(n, 0);
+      OK(bt709hip_download(ctx, back.data(), 1024, dev, 1024, 1024, n / 1024, stream));
+      CHECK(back[0] == round + 1 && back[n - 1] == round + 1 && back[n / 2] == round + 1);  // filled on return, with the bytes uploaded
+    }
+    // pinned memory: asynchronous as before -- the bytes are there after the stream has been waited for
+    std::memset(pinned, 0x5a, n);
+    OK(bt709hip_upload(ctx, dev, 1024, pinned, 1024, 1024, n / 1024, stream));
+    OK(bt709hip_stream_synchronize(ctx, stream));
+    std::memset(pinned, 0, n);
+    OK(bt709hip_download(ctx, pinned, 1024, dev, 1024, 1024, n / 1024, stream));
+    OK(bt709hip_stream_synchronize(ctx, stream));
+    CHECK(static_cast<uint8_t *>(pinned)[n - 1] == 0x5a);
+  }
+  OK(bt709hip_host_free(ctx, pinned));
+  OK(bt709hip_free(ctx, dev));
+  OK(bt709hip_stream_destroy(ctx, s));
+  OK(bt709hip_context_destroy(ctx));
+}
+
 // Argument fuzz: every decode / rescale / encode / plane entry point with random geometry, pitches, alignments, tags, formats,
 // NULLs and counts.  On the fake runtime a launch touches nothing, so whatever the shim lets through is harmless here -- the point
 // is the shim's OWN reads (descriptor arrays, alpha arrays, per-frame loops) under ASan / UBSan, and that every call returns a
@@ -494,7 +530,7 @@ int main(int argc, char **argv) {
     void (*fn)();
   } tests[] = {{"coalescing", test_coalescing_threads}, {"two_decoders", test_two_decoders_one_stream_and_age}, {"pool_sharder", test_pool_and_sharder},
                {"ring", test_ring_hunts},               {"ring_set", test_ring_set},                             {"graphs", test_graphs_and_misc},
-               {"fuzz", test_argument_fuzz}};
+               {"host_buffers", test_host_buffer_lifetime},     {"fuzz", test_argument_fuzz}};
   for (auto &t : tests) {
     if (!only.empty() && only != t.name) continue;
     const int before = failures;
