@@ -56,7 +56,7 @@ static_assert((kHalfCandFloor & 7u) == 0 && (kHalfCandLds & 15u) == 0 && kHalfCa
 // workgroup (256 lanes), 5 of a 512-lane one.
 __device__ __forceinline__ void stage_half_tables(unsigned char *lds, const void *src, uint32_t cand_offset, uint32_t bytes) {
   const u32x4 *s = reinterpret_cast<const u32x4 *>(src);
-  const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+  const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
   const uint32_t n = bytes / 16, n_thresholds = cand_offset / 16, gap = (kHalfCandLds - cand_offset) / 16;
   u32x4 *d = reinterpret_cast<u32x4 *>(lds);
   constexpr int kBatch = 5;
@@ -207,7 +207,11 @@ decode_nv12_rgba16f(const DecodeParams p, const HalfParams hp) {
   const uint32_t tile = p.xcd_bands ? blockIdx.x >> 3 : blockIdx.x;
   const FramePlanes f = frame_planes(p, p.xcd_bands ? (blockIdx.x & 7u) * p.frames_per_band + blockIdx.z : blockIdx.z);
   const uint32_t blocks = p.width >> 1, row_pairs = p.height >> 1;
-  const uint32_t rp_base = blockIdx.y * RP;
+  // blockDim.y SLICES of a workgroup share its table, each with row pairs of its own (narrow frames: a 1080p row pair keeps 240
+  // lanes busy -- two slices make the 512-lane workgroup a 4K row pair gets).  blockDim.x is a multiple of 64: a wave lies in one
+  // slice, its row pointers stay scalar.
+  const uint32_t slice = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const uint32_t rp_base = (blockIdx.y * blockDim.y + slice) * RP;
   const uint32_t bx0 = tile * (blockDim.x * NB) + threadIdx.x;
 
   // Every load of the tile first: the bytes of a 2x2 block as loaded -- Y top | Y bottom, CbCr, alpha top | alpha bottom (two
@@ -333,12 +337,28 @@ const char *launch_decode_rgba16f(const DecodeParams &p_in, const HalfParams &hp
   hp.row_pairs_per_block = static_cast<uint32_t>(sh.rp);
   hp.wide_store = out_align >= 16 ? 1 : 0;
   dim3 grid(tiles, (row_pairs + static_cast<uint32_t>(sh.rp) - 1) / static_cast<uint32_t>(sh.rp), static_cast<uint32_t>(frames));
+  // slices (see the kernel), for rows that fill fewer than 256 lanes: as many as make a 512-lane workgroup, fewer while the launch
+  // would otherwise have too few workgroups.  Same process, same ring (profiles/r05_ab_rgba16f_packed.txt 7): 720p 1 024 / 64
+  // frames per launch 0.646 / 0.601 against 0.562 / 0.545 without, 640 x 360 0.58-0.59 against 0.38-0.41; NOT for 1080p's 256
+  // lanes (two slices: 0.70-0.71 against 0.72, 32 frames per launch 0.646 against 0.676).
+#ifndef BT709_RGBA16F_MAX_SLICES
+#define BT709_RGBA16F_MAX_SLICES 8
+#endif
+#ifndef BT709_RGBA16F_SLICE_MIN_FILL
+#define BT709_RGBA16F_SLICE_MIN_FILL 2
+#endif
+  uint32_t slices = 1;
+  if (which != 2) {
+    slices = threads >= 256u ? 1u : std::min<uint32_t>(512u / threads, BT709_RGBA16F_MAX_SLICES);
+    while (slices > 1 && static_cast<uint64_t>(tiles) * ((grid.y + slices - 1) / slices) * static_cast<uint32_t>(frames) < BT709_RGBA16F_SLICE_MIN_FILL * fill) --slices;
+    grid.y = (grid.y + slices - 1) / slices;
+  }
   if (xcd_bands && frames >= kF16BandMinFrames && frames % 8 == 0) {
     p.xcd_bands = 1;
     p.frames_per_band = static_cast<uint32_t>(frames) / 8u;
     grid = dim3(tiles * 8u, grid.y, p.frames_per_band);
   }
-  const dim3 block(threads);
+  const dim3 block(threads, slices);
   LaunchShape &shape = last_launch_shape();
   if (shape.launches++ == 0) {
     shape.grid[0] = grid.x, shape.grid[1] = grid.y, shape.grid[2] = grid.z;

@@ -248,12 +248,14 @@ def test_gpu_rgba16f_xcd_band_work_map(gh, oracle, n, size):
     (16, (1920, 1080), 1, ((8, 270, 2), 256, 1)),   # large shape (4 blocks x 2 row pairs), 240 of 256 lanes busy, XCD map from 8 frames on
     (16, (1920, 1080), 0, ((1, 270, 16), 256, 0)),  # the same launch under the plain map
     (6, (1920, 1080), 1, ((1, 270, 6), 256, 0)),    # not a multiple of 8 and short: plain map, one launch
-    (288, (64, 1026), 1, ((8, 171, 36), 64, 1)),    # narrow shape (4 x 3): >= 48 workgroups per slot on rows of <= 1 024 blocks
+    (288, (64, 1026), 1, ((8, 22, 36), (64, 8), 1)),  # narrow shape (4 x 3): >= 48 workgroups per slot on rows of <= 1 024 blocks; 8 slices of one wave, 171 groups on 176 slices
+    (64, (1280, 720), 1, ((8, 90, 8), (192, 2), 1)),  # rows of 160 busy lanes: two SLICES per workgroup share the staged table
+    (96, (640, 362), 0, ((1, 23, 96), (128, 4), 0)),  # four slices of 128 lanes, 91 row-pair groups: the last workgroup's last slice is past the frame
     (3, (3840, 2160), 1, ((1, 540, 3), 512, 0)),     # 1 620 workgroups in the large shape, past one per slot: large; 480 of 512 lanes busy
     (1, (3840, 2160), 1, ((1, 360, 1), 960, 0)),    # a single 4K frame: the small shape (2 x 3, 960 lanes)
 ])
 def test_gpu_rgba16f_work_shapes(gh, oracle, case):
-    """The three work shapes of the RGBA16Float kernel and both work maps, each asserted through bt709hip_last_launch_info
+    """The three work shapes of the RGBA16Float kernel, its slices and both work maps, each asserted through bt709hip_last_launch_info
     and checked against the oracle: rows of whole frames at the start, in the middle and at the end of the launch (every
     frame for the small ones)."""
     import ctypes as C
@@ -279,7 +281,8 @@ def test_gpu_rgba16f_work_shapes(gh, oracle, case):
     assert dec.decodeBT709Batch(bufs, texs, waitUntilCompleted=True), dec.lastStatus
     info = _capi.LaunchInfo()
     _capi.check(ctx.lib.bt709hip_last_launch_info(C.byref(info)))
-    assert (tuple(info.grid), info.block[0], info.xcd_bands, info.launches) == (grid, block, used, 1)
+    block = block if isinstance(block, tuple) else (block, 1)
+    assert (tuple(info.grid), (info.block[0], info.block[1]), info.xcd_bands, info.launches) == (grid, block, used, 1)
     want = [oracle.decode_nv12_rgba16f(0, y, c).view(np.uint16) for y, c in distinct]
     for i in sorted(set(range(n)) if n <= 16 else {0, 1, n // 8 - 1, n // 8, n // 2, n - n // 8 - 1, n - 2, n - 1}):
         assert np.array_equal(ctx.getBGRATexturePixels(texs[i]).view(np.uint16), want[i % len(distinct)]), i
