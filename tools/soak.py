@@ -103,7 +103,9 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
         rs.release()
     elif kind == 9:  # round 5: batched RGBA16Float launches (small frames: the small shape; many frames: the large one)
         n = int(rng.integers(1, 33))
-        hh = min(h, 24)
+        hh = h if rng.integers(0, 3) == 0 else min(h, 24)  # tall ones: the large shape, with slices when the rows are narrow
+        if hh == h and rng.integers(0, 2) == 0:
+            w = 4 * int(rng.integers(1, 120))
         dec = gh.make_decoder(g)
         frs = [gh.random_nv12(w, hh, seed=int(rng.integers(0, 1 << 30))) for _ in range(n)]
         bufs = [gh.make_buffer(fy, fc, dec.gamma) for fy, fc in frs]
