@@ -23,7 +23,10 @@ constexpr int kMaxBatch = 32;          // == BT709HIP_MAX_BATCH: frames in the k
 // XCD-aware work map (bt709_kernels.hip decode_nv12_quads): used for launches of a multiple of 8 frames from this many on.
 // Measured (round 3, same call, plain vs banded): decode 32 frames 0.756 / 0.741-0.761, 64 0.741 / 0.745-0.760, 128 0.72 / 0.77,
 // 256 0.70 / 0.76-0.81; encoder 32 pictures 0.70 / 0.67, 256 0.69 / 0.73: a band needs ~8 frames to pay.
-constexpr int kXcdBandMinFrames = 64;
+#ifndef BT709_XCD_BAND_MIN_FRAMES
+#define BT709_XCD_BAND_MIN_FRAMES 64
+#endif
+constexpr int kXcdBandMinFrames = BT709_XCD_BAND_MIN_FRAMES;
 constexpr int kMaxUniformBatch = 65535;  // evenly spaced frames per launch (grid.z limit)
 
 enum KernelVariant : int {
