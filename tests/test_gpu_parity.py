@@ -1478,3 +1478,41 @@ def test_bench_line_on_the_gpu():
     pl = d["config"]["placement"]
     assert pl["tries"] == 2 and pl["rings_resident"] == ["first", "hunted"] and pl["pairings_probed"] >= 2
     assert abs(d["value"] - 48 * 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_upload_and_download_own_nothing_of_a_pageable_buffer(gh):
+    """bt709hip_upload / _download with ordinary (pageable) host memory are complete on return, like the reference's
+    -fillBGRATexture: / -getBGRATexturePixels: (Renderer/MetalRenderContext.m:122-160): the source is overwritten and
+    RELEASED right after the call -- 3.1 MB numpy arrays, i.e. mmap'ed blocks that go back to the kernel when freed: the
+    pattern that gave a lab tool a GPU memory access fault in round 5 while the copy was still asynchronous -- and the bytes
+    downloaded into a fresh buffer are checked without a synchronise in between.  Pinned memory stays asynchronous."""
+    import ctypes as C
+    ctx = gh.context()
+    lib, h = ctx.lib, ctx.handle
+    n, rounds = 3110400, 24
+    dev = C.c_void_p()
+    _capi.check(lib.bt709hip_malloc(h, n * rounds, C.byref(dev)))
+    rng = np.random.default_rng(31)
+    sums = []
+    for i in range(rounds):
+        buf = rng.integers(0, 256, n, dtype=np.uint8)
+        sums.append(int(buf.astype(np.uint32).sum()))
+        _capi.check(lib.bt709hip_upload(h, dev.value + i * n, n, buf.ctypes.data, n, n, 1, None))
+        buf[:] = 0
+        del buf  # the block is unmapped here
+    for i in range(rounds):
+        back = np.empty(n, np.uint8)
+        _capi.check(lib.bt709hip_download(h, back.ctypes.data, n, dev.value + i * n, n, n, 1, None))
+        assert int(back.astype(np.uint32).sum()) == sums[i], i  # filled on return
+        del back
+    pinned = C.c_void_p()
+    _capi.check(lib.bt709hip_host_alloc(h, n, C.byref(pinned)))
+    host = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_uint8)), shape=(n,))
+    host[:] = 0
+    _capi.check(lib.bt709hip_download(h, pinned, n, dev.value, n, n, 1, None))
+    _capi.check(lib.bt709hip_stream_synchronize(h, None))
+    assert int(host.astype(np.uint32).sum()) == sums[0]
+    del host
+    _capi.check(lib.bt709hip_host_free(h, pinned))
+    _capi.check(lib.bt709hip_free(h, dev))
