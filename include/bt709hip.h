@@ -589,6 +589,10 @@ int bt709hip_gamma_thresholds(int gamma, float thresholds[255]);
  * host-built bucket table (same index function, same compare): the byte the GPU would produce, and
  * optionally the bucket count N and the bucket index.  Returns the byte, or <0 on a bad argument. */
 int bt709hip_gamma_lookup(int gamma, float x, int *bucket_count, int *bucket_index);
+/* The same for the table the 1:1 kernels (decode, +unconvert:) stage: where the uniform table is large because the thresholds
+ * crowd near zero (the LINEAR mode: 4 096 buckets) they use a LOG-bucket form of it, bucket = (bits(x + a) >> 16) - first, a = 2^-5
+ * (645 buckets); for the other modes this is bt709hip_gamma_lookup.  *log_form (optional) = 1 / 0. */
+int bt709hip_gamma_lookup_decode(int gamma, float x, int *bucket_count, int *bucket_index, int *log_form);
 int bt709hip_matrix_constants(float constants[8]);
 /* RGBA16F targets: the threshold table of the half-float composite H(x) = half(curve_to_linear(x))
  * (host memory out).  thresholds: up to `capacity` floats, T[i] = smallest x with H(x) >= first_code + i;

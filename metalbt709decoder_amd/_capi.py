@@ -191,6 +191,7 @@ SYMBOLS = {
     "bt709hip_last_hip_error_string": (C.c_char_p, []),
     "bt709hip_gamma_thresholds": (_I, [_I, C.POINTER(C.c_float)]),
     "bt709hip_gamma_lookup": (_I, [_I, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bt709hip_gamma_lookup_decode": (_I, [_I, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bt709hip_matrix_constants": (_I, [C.POINTER(C.c_float)]),
     "bt709hip_half_thresholds": (_I, [_I, C.POINTER(C.c_float), _I]),
     "bt709hip_half_lookup": (_I, [_I, C.c_float, _I, C.POINTER(C.c_int)]),

@@ -135,16 +135,20 @@ __device__ __forceinline__ void magic_index4(const float *x, uint32_t *t, float 
   for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(__fadd_rn(x[i], magic));
 }
 
-// Lookup constants of the byte-valued bucket table (TransferBucket, 8 bytes) held at `lds_table`.
+// Lookup constants of the byte-valued bucket table (TransferBucket, 8 bytes) held at `lds_table`: bucket q of x is
+// (bits(x + magic) >> shift) - first (DecodeParams::unit1_*: uniform form shift 0, log-bucket form shift 16).
 struct UnitLookup {
-  float magic;      // M = 2^23 / N
-  uint32_t offset;  // LDS address of the table - (bits(M) << 3)
+  float magic;      // M = 2^23 / N, or the log form's addend
+  uint32_t offset;  // LDS address of the table - (first << 3)
+  uint32_t shift;   // 0 / 16; the fast kernels take it as a template argument instead
 };
 
-__device__ __forceinline__ UnitLookup unit_lookup(float magic, const void *lds_table) {
+template <typename Params>  // DecodeParams or the +unconvert: kernel's own
+__device__ __forceinline__ UnitLookup unit_lookup(const Params &p, const void *lds_table) {
   UnitLookup u;
-  u.magic = magic;
-  u.offset = lds_address(lds_table) - (__float_as_uint(magic) << 3);
+  u.magic = p.unit1_magic;
+  u.offset = lds_address(lds_table) - (p.unit1_first << 3);
+  u.shift = p.unit1_shift;
   return u;
 }
 

@@ -60,7 +60,11 @@ struct DecodeParams {
   uint32_t table_encode_bytes;
   float encode_scale;  // n_fine of table_encode
   uint32_t encode_offset, encode_shift;
-  float unit_magic;    // 2^23 / N: floats in [M, 2M) have ulp 1/N (bt709_device.h magic_index12)
+  float unit_magic;    // 2^23 / N: floats in [M, 2M) have ulp 1/N (bt709_device.h magic_index12): table_linear's index
+  // table_unit's index (the 1:1 kernels): q = (bits(x + unit1_magic) >> unit1_shift) - unit1_first.  Uniform form: the same M,
+  // shift 0, first = bits(M); log-bucket form (transfer_tables.h TransferTable::buckets_log): log_add, 16, log_first.
+  float unit1_magic;
+  uint32_t unit1_first, unit1_shift;
   uint32_t width;      // luma (source) dimensions
   uint32_t height;
   uint32_t y_stride;

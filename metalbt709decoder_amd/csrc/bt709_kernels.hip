@@ -35,7 +35,7 @@ namespace {
 // QUANT: the decoder's mode is sRGB, whose composite is the plain quantiser ("no curve at all", BT709.h:977-983):
 // every channel is quantise_byte of its saturated value -- no table, no LDS.  Always set for alpha decoders
 // (hasAlphaChannel forces the sRGB mode, MetalBT709Decoder.m:165-169).
-template <bool HAS_ALPHA, bool QUANT>
+template <bool HAS_ALPHA, bool QUANT, bool LOGIDX>
 __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, uint32_t yb, uint32_t cw, uint32_t aa,
                                             uint32_t ab, uint32_t alpha_word, u32x4 &top, u32x4 &bot) {
   const Chroma c0 = chroma_terms(byte_of(cw, 0), byte_of(cw, 1));
@@ -53,6 +53,10 @@ __device__ __forceinline__ void decode_quad(const UnitLookup &u, uint32_t ya, ui
     uint32_t t[24];
     magic_index12(x, t, u.magic);
     magic_index12(x + 12, t + 12, u.magic);
+    if (LOGIDX) {  // log-bucket table (the LINEAR mode): the sum's exponent and top 7 mantissa bits
+#pragma unroll
+      for (int i = 0; i < 24; ++i) t[i] >>= 16;
+    }
 #pragma unroll
     for (int i = 0; i < 24; ++i) byte[i] = bucket_byte(u, x[i], t[i]);
   }
@@ -87,6 +91,8 @@ __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[
   uint32_t t[12];
   magic_index12(x, t, u.magic);
 #pragma unroll
+  for (int i = 0; i < 12; ++i) t[i] >>= u.shift;  // general path: the table's form is a run-time value
+#pragma unroll
   for (int px = 0; px < 4; ++px)
     out[px] = pack_bgra(bucket_byte(u, x[3 * px], t[3 * px]), bucket_byte(u, x[3 * px + 1], t[3 * px + 1]),
                         bucket_byte(u, x[3 * px + 2], t[3 * px + 2]), alpha_word);
@@ -99,10 +105,10 @@ __device__ __forceinline__ void decode_block(const UnitLookup &u, const float y[
 // alpha pointers and strides 4-byte aligned; output pointer and stride 16-byte
 // aligned.  grid = (tiles, H/2, frames); a tile is blockDim * kQuadsPerLane quads.
 // ---------------------------------------------------------------------------
-// RP: consecutive row pairs a workgroup covers, all of them loaded before the table is staged (RP = 1: the shipped shape of every
-// mode whose table is small; RP = 2: the LINEAR mode, whose 33 KiB table is then paid for by twice the pixels -- round 5,
-// decode_nv12_quads_rows below).
-template <bool HAS_ALPHA, bool NT, bool QUANT, int RP>
+// RP: consecutive row pairs a workgroup covers, all of them loaded before the table is staged (1 in every shipped kernel; 2 and 4
+// served the LINEAR mode's 33 KiB uniform table in the first half of round 5, until its log-bucket table made it 5 KiB:
+// decode_nv12_quads_log below).  LOGIDX: the table is in log-bucket form (one shift more per channel).
+template <bool HAS_ALPHA, bool NT, bool QUANT, int RP, bool LOGIDX = false>
 __device__ __forceinline__ void quads_body(const DecodeParams &p, unsigned char *lds_raw) {
   constexpr int UNROLL = kQuadsPerLane;
 
@@ -169,7 +175,7 @@ __device__ __forceinline__ void quads_body(const DecodeParams &p, unsigned char 
       if (HAS_ALPHA) asm volatile("" : "+v"(aa[r][u]), "+v"(ab[r][u]));
     }
 
-  const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
+  const UnitLookup ul = unit_lookup(p, lds_raw);
 #pragma unroll
   for (int r = 0; r < RP; ++r) {
     const uint32_t rp_raw = rp_first + r;
@@ -179,7 +185,7 @@ __device__ __forceinline__ void quads_body(const DecodeParams &p, unsigned char 
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t q = (q0 + u * blockDim.x);
       u32x4 top, bot;
-      decode_quad<HAS_ALPHA, QUANT>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
+      decode_quad<HAS_ALPHA, QUANT, LOGIDX>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
                              bot);
       if (q < quads && rp_raw < row_pairs) {
         store16<NT>(o0 + 16 * q, top);
@@ -196,23 +202,17 @@ decode_nv12_quads(const DecodeParams p) {
   quads_body<HAS_ALPHA, NT, QUANT, 1>(p, lds_raw);
 }
 
-// The same kernel over RP row pairs per workgroup, for decoders whose table is large (LINEAR: 4 096 buckets = 33 KiB staged per
-// workgroup): grid.y = ceil(row pairs / (blockDim.y * RP)).  Round 5, one process, one ring, LINEAR mode, 4K (profiles/r05_ab_linear_rows.txt):
-// 256 frames per launch RP = 1 / 2 / 3 / 4: 0.706 / 0.759 / 0.765 / 0.777; 32 per launch: 0.714 / 0.713 / 0.667 / 0.652.  So: 4 under
-// the XCD-aware map (64 frames and more), 2 for launches of 8 frames and more, the plain kernel below that.  (Round 4 had tried two
-// row pairs as a 1 024-lane workgroup, blockDim.y = 2, and lost 1 %: more lanes, not more pixels per lane.)
-#ifndef BT709_QUADS_BIG_TABLE_BYTES
-#define BT709_QUADS_BIG_TABLE_BYTES (16u << 10)
-#endif
-#ifndef BT709_QUADS_BIG_TABLE_RP_BANDED
-#define BT709_QUADS_BIG_TABLE_RP_BANDED 4
-#endif
-constexpr uint32_t kBigTableBytes = BT709_QUADS_BIG_TABLE_BYTES;  // tables above this use decode_nv12_quads_rows
-template <bool NT, int RP>
+// The plain kernel over a LOG-bucket table (DecodeParams::unit1_shift == 16; transfer_tables.h TransferTable::buckets_log):
+// the LINEAR mode's 4 096 uniform buckets become 645 -- 5 KiB staged per workgroup instead of 33 -- for one shift per channel.
+// One process, one ring, 4K, LINEAR mode (profiles/r05_ab_linear_log.txt), against the first half of round 5's answer to the
+// 33 KiB table (the same body over 2 / 4 row pairs per workgroup, `decode_nv12_quads_rows`, itself 0.706 -> 0.777 over the plain
+// kernel): 256 / 64 / 32 / 8 / 1 frames per launch 0.788 / 0.763 / 0.767 / 0.721 / 0.472 against 0.778 / 0.706 / 0.708 /
+// 0.648 / 0.451.  The rows kernel is gone.
+template <bool NT>
 __global__ void __launch_bounds__(kMaxBlockThreads)
-decode_nv12_quads_rows(const DecodeParams p) {
+decode_nv12_quads_log(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  quads_body<false, NT, false, RP>(p, lds_raw);
+  quads_body<false, NT, false, 1, true>(p, lds_raw);
 }
 
 // ---------------------------------------------------------------------------
@@ -229,7 +229,7 @@ decode_nv12_blocks(const DecodeParams p) {
     __syncthreads();
   }
 
-  const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
+  const UnitLookup ul = unit_lookup(p, lds_raw);
   const FramePlanes f = frame_planes(p, blockIdx.y);
   const uint32_t bw = p.width >> 1;
   const uint32_t row_pairs = p.height >> 1;
@@ -280,7 +280,8 @@ struct UnconvertParams {
   uint32_t in_stride, out_stride, width, height;
   const void *table_unit;
   uint32_t table_unit_bytes;
-  float unit_magic;
+  float unit1_magic;  // DecodeParams::unit1_*
+  uint32_t unit1_first, unit1_shift;
   uint32_t alpha_word;
 };
 
@@ -314,7 +315,7 @@ unconvert_packed444(const UnconvertParams p) {
     stage_table(lds_raw, p.table_unit, p.table_unit_bytes);  // after the loads are in flight
     __syncthreads();
   }
-  const UnitLookup ul = unit_lookup(p.unit_magic, lds_raw);
+  const UnitLookup ul = unit_lookup(p, lds_raw);
   if (!live) return;
 #pragma unroll
   for (uint32_t r = 0; r < ROWS; ++r) {
@@ -330,7 +331,7 @@ unconvert_packed444(const UnconvertParams p) {
       uint32_t b[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch)
-        b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)));
+        b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)) >> ul.shift);
       o[k] = pack_bgra(b[0], b[1], b[2], p.alpha_word);
     }
     uint8_t *out = frame_out + static_cast<size_t>(row0 + r) * p.out_stride;
@@ -361,7 +362,9 @@ const char *launch_unconvert(const DecodeParams &t, const UnconvertBatch &b, siz
   p.height = height;
   p.table_unit = t.table_unit;
   p.table_unit_bytes = t.table_unit_bytes;
-  p.unit_magic = t.unit_magic;
+  p.unit1_magic = t.unit1_magic;
+  p.unit1_first = t.unit1_first;
+  p.unit1_shift = t.unit1_shift;
   p.alpha_word = t.alpha_word;
   const uint32_t groups = vec ? width / 4 : width;
   const dim3 grid((groups + kBlockThreads - 1) / kBlockThreads, vec ? height / 2 : height, static_cast<uint32_t>(b.count));  // vec: two rows per workgroup row
@@ -428,20 +431,10 @@ const char *launch_decode(const DecodeParams &p_in, int frames, int variant, boo
       else hipLaunchKernelGGL((decode_nv12_quads<false, false, true>), grid, block, lds, stream, p);
       return nontemporal ? "decode_nv12_quads<nt,quantiser>" : "decode_nv12_quads<quantiser>";
     }
-    const uint32_t big_rp = p_in.table_unit_bytes <= kBigTableBytes ? 1u : (banded.xcd_bands ? static_cast<uint32_t>(BT709_QUADS_BIG_TABLE_RP_BANDED) : (frames >= 8 ? 2u : 1u));
-    if (big_rp > 1) {  // the LINEAR mode: several row pairs per workgroup share the 33 KiB table
-      dim3 g2 = grid;
-      g2.y = (grid.y + big_rp - 1) / big_rp;
-      if (big_rp == 4) {
-        if (nontemporal) hipLaunchKernelGGL((decode_nv12_quads_rows<true, 4>), g2, block, lds, stream, p);
-        else hipLaunchKernelGGL((decode_nv12_quads_rows<false, 4>), g2, block, lds, stream, p);
-      } else {
-        if (nontemporal) hipLaunchKernelGGL((decode_nv12_quads_rows<true, 2>), g2, block, lds, stream, p);
-        else hipLaunchKernelGGL((decode_nv12_quads_rows<false, 2>), g2, block, lds, stream, p);
-      }
-      LaunchShape &sh = last_launch_shape();
-      if (sh.launches == 1) sh.grid[1] = g2.y;
-      return nontemporal ? "decode_nv12_quads_rows<nt>" : "decode_nv12_quads_rows";
+    if (p_in.unit1_shift != 0) {  // log-bucket table (the LINEAR mode)
+      if (nontemporal) hipLaunchKernelGGL((decode_nv12_quads_log<true>), grid, block, lds, stream, p);
+      else hipLaunchKernelGGL((decode_nv12_quads_log<false>), grid, block, lds, stream, p);
+      return nontemporal ? "decode_nv12_quads_log<nt>" : "decode_nv12_quads_log";
     }
     if (nontemporal) {
       hipLaunchKernelGGL((decode_nv12_quads<false, true, false>), grid, block, lds, stream, p);
@@ -480,10 +473,8 @@ hipError_t prepare_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false, true>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, true, false>),
       reinterpret_cast<const void *>(&decode_nv12_quads<false, false, false>),
-      reinterpret_cast<const void *>(&decode_nv12_quads_rows<true, 2>),
-      reinterpret_cast<const void *>(&decode_nv12_quads_rows<false, 2>),
-      reinterpret_cast<const void *>(&decode_nv12_quads_rows<true, 4>),
-      reinterpret_cast<const void *>(&decode_nv12_quads_rows<false, 4>),
+      reinterpret_cast<const void *>(&decode_nv12_quads_log<true>),
+      reinterpret_cast<const void *>(&decode_nv12_quads_log<false>),
       reinterpret_cast<const void *>(&unconvert_packed444<true, false>),
       reinterpret_cast<const void *>(&unconvert_packed444<false, false>),
       reinterpret_cast<const void *>(&decode_nv12_blocks<true, true>),

@@ -85,6 +85,8 @@ struct bt709hip_decoder {
   std::atomic<bool> ready{false};  // release-stored after the tables below are published, acquire-loaded by every decode
   // device copies (transfer_tables.h)
   uint32_t table_n = 0;            // bucket count N of the decoder's gamma
+  float unit1_magic = 0.0f;        // index function of d_table_unit (DecodeParams::unit1_*): uniform or log-bucket form
+  uint32_t unit1_first = 0, unit1_shift = 0;
   void *d_table_unit = nullptr;    // TransferBucket[N + 1] (decode kernels)
   uint32_t table_unit_bytes = 0;
   void *d_table_linear = nullptr;  // TransferBucketLinear[N + 1] (rescale kernels, decode side)
@@ -276,6 +278,9 @@ void set_tables(DecodeParams *p, const bt709hip_decoder *dec) {
   p->encode_offset = dec->encode_offset;
   p->encode_shift = dec->encode_shift;
   p->unit_magic = 8388608.0f / static_cast<float>(dec->table_n);  // 2^23 / N, exact: N is a power of two
+  p->unit1_magic = dec->unit1_magic;
+  p->unit1_first = dec->unit1_first;
+  p->unit1_shift = dec->unit1_shift;
 }
 
 int64_t byte_step(const void *a, const void *b) {
@@ -875,7 +880,17 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
       !build_uniform_table(kGammaLinear, 256, &enc_u))
     return BT709HIP_ERR_UNSUPPORTED;
   dec->table_n = t.n;
-  dec->table_unit_bytes = static_cast<uint32_t>(t.buckets_unit.size() * sizeof(TransferBucket));
+  // the 1:1 kernels' table: the log-bucket form where the builder found one at most half the size (the LINEAR mode: 5 KiB
+  // instead of 33), else the uniform buckets the rescale kernels' table_linear shares its layout with
+  const bool log_form = !t.buckets_log.empty();
+  const std::vector<TransferBucket> &unit = log_form ? t.buckets_log : t.buckets_unit;
+  const float uniform_magic = 8388608.0f / static_cast<float>(t.n);
+  uint32_t uniform_first;
+  std::memcpy(&uniform_first, &uniform_magic, sizeof uniform_first);
+  dec->unit1_magic = log_form ? t.log_add : uniform_magic;
+  dec->unit1_first = log_form ? t.log_first : uniform_first;
+  dec->unit1_shift = log_form ? 16u : 0u;
+  dec->table_unit_bytes = static_cast<uint32_t>(unit.size() * sizeof(TransferBucket));
   dec->table_linear_bytes = static_cast<uint32_t>(t.buckets_linear.size() * sizeof(TransferBucketLinear));
   dec->encode_n = enc.n_fine;
   dec->encode_offset = enc.coarse_offset;
@@ -884,7 +899,7 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
   void *d_unit = nullptr, *d_linear = nullptr, *d_enc = nullptr, *d_enc_u = nullptr;
   const uint32_t enc_u_bytes = static_cast<uint32_t>(enc_u.buckets.size() * sizeof(TransferBucket));
-  int rc = upload_table(t.buckets_unit.data(), dec->table_unit_bytes, &d_unit);
+  int rc = upload_table(unit.data(), dec->table_unit_bytes, &d_unit);
   if (rc == BT709HIP_OK) rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &d_linear);
   if (rc == BT709HIP_OK) rc = upload_table(enc.buckets.data(), dec->encode_bytes, &d_enc);
   if (rc == BT709HIP_OK) rc = upload_table(enc_u.buckets.data(), enc_u_bytes, &d_enc_u);
@@ -1925,22 +1940,46 @@ int bt709hip_gamma_thresholds(int gamma, float thresholds[255]) {
   return BT709HIP_OK;
 }
 
-int bt709hip_gamma_lookup(int gamma, float x, int *bucket_count, int *bucket_index_out) {
-  // one table per gamma, built on first use (host only: no device involved)
+extern "C++" {
+namespace {
+// one table per gamma, built on first use (host only: no device involved); nullptr: unknown gamma
+const TransferTable *host_transfer_table(int gamma) {
   static std::mutex mutex;
   static TransferTable tables[kGammaCount];
   static bool built[kGammaCount] = {false, false, false, false};
-  if (gamma < 0 || gamma >= kGammaCount || !(x >= 0.0f && x <= 1.0f)) return BT709HIP_ERR_INVALID_ARG;
+  if (gamma < 0 || gamma >= kGammaCount) return nullptr;
   std::lock_guard<std::mutex> lock(mutex);
   if (!built[gamma]) {
-    if (!build_transfer_table(gamma, &tables[gamma])) return BT709HIP_ERR_UNSUPPORTED;
+    if (!build_transfer_table(gamma, &tables[gamma])) return nullptr;
     built[gamma] = true;
   }
-  const TransferTable &t = tables[gamma];
+  return &tables[gamma];
+}
+}  // namespace
+}  // extern "C++"
+
+int bt709hip_gamma_lookup(int gamma, float x, int *bucket_count, int *bucket_index_out) {
+  if (gamma < 0 || gamma >= kGammaCount || !(x >= 0.0f && x <= 1.0f)) return BT709HIP_ERR_INVALID_ARG;
+  const TransferTable *tp = host_transfer_table(gamma);
+  if (tp == nullptr) return BT709HIP_ERR_UNSUPPORTED;
+  const TransferTable &t = *tp;
   const uint32_t q = bucket_index(x, 8388608.0f / static_cast<float>(t.n));
   if (bucket_count) *bucket_count = static_cast<int>(t.n);
   if (bucket_index_out) *bucket_index_out = static_cast<int>(q);
   const TransferBucket &b = t.buckets_unit[q];
+  return static_cast<int>(b.base + (x >= b.edge ? 1u : 0u));
+}
+
+int bt709hip_gamma_lookup_decode(int gamma, float x, int *bucket_count, int *bucket_index_out, int *log_form) {
+  if (gamma < 0 || gamma >= kGammaCount || !(x >= 0.0f && x <= 1.0f)) return BT709HIP_ERR_INVALID_ARG;
+  const TransferTable *tp = host_transfer_table(gamma);
+  if (tp == nullptr) return BT709HIP_ERR_UNSUPPORTED;
+  if (log_form) *log_form = tp->buckets_log.empty() ? 0 : 1;
+  if (tp->buckets_log.empty()) return bt709hip_gamma_lookup(gamma, x, bucket_count, bucket_index_out);
+  const uint32_t q = bucket_index_log(x, tp->log_add) - tp->log_first;  // as decoder_setup hands it to the kernels (unit1_*)
+  if (bucket_count) *bucket_count = static_cast<int>(bucket_index_log(1.0f, tp->log_add) - tp->log_first + 1);
+  if (bucket_index_out) *bucket_index_out = static_cast<int>(q);
+  const TransferBucket &b = tp->buckets_log[q];
   return static_cast<int>(b.base + (x >= b.edge ? 1u : 0u));
 }
 

@@ -151,9 +151,44 @@ bool build_transfer_table(int gamma, TransferTable *out) {
       e.lin_below = std::ldexp(lin_of_byte[b[q].base], kLinearScaleLog2);      // exact: power of two
       e.lin_above = std::ldexp(lin_of_byte[b[q].base + 1], kLinearScaleLog2);
     }
+    // the log-bucket form (transfer_tables.h): the smallest of log_add = 2^-3 .. 2^-10 that keeps one threshold per bucket,
+    // taken if it is at most half the uniform table
+    out->log_add = 0.0f;
+    out->log_first = 0;
+    out->buckets_log.clear();
+    for (int e = 3; e <= 10; ++e) {
+      const float add = std::ldexp(1.0f, -e);
+      const uint32_t first = bucket_index_log(0.0f, add), count = bucket_index_log(1.0f, add) - first + 1;
+      if (2 * count > n + 1) break;  // smaller adds only add buckets
+      std::vector<TransferBucket> lb(count, TransferBucket{inf, 0u});
+      std::vector<uint32_t> lheld(count, 0u);
+      bool fits = true;
+      for (int k = 0; k < 255 && fits; ++k) {
+        if (out->thresholds[k] == inf) continue;
+        const uint32_t q = bucket_index_log(out->thresholds[k], add) - first;
+        if (q >= count || lheld[q] != 0) fits = false;
+        else lheld[q] = 1, lb[q].edge = out->thresholds[k];
+      }
+      if (!fits) continue;
+      uint32_t seen = 0;
+      for (uint32_t q = 0; q < count; ++q) {
+        lb[q].base = seen;
+        seen += lheld[q];
+      }
+      out->log_add = add;
+      out->log_first = first;
+      out->buckets_log = lb;
+      while ((out->buckets_log.size() * sizeof(TransferBucket)) % 16 != 0) out->buckets_log.push_back(TransferBucket{inf, 255u});
+      break;
+    }
     return true;
   }
   return false;
+}
+
+uint32_t bucket_index_log(float x, float log_add) {
+  volatile float t = x + log_add;  // one binary32 add, round to nearest even (v_add_f32)
+  return to_bits(t) >> 16;
 }
 
 uint16_t float_to_half(float v) {

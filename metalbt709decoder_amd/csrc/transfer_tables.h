@@ -70,7 +70,17 @@ struct TransferTable {
   // buckets 0..N (bucket N: x == 1.0), padded to a 16-byte multiple
   std::vector<TransferBucket> buckets_unit;
   std::vector<TransferBucketLinear> buckets_linear;  // the same N + 1 buckets, linearised outputs
+  // LOG-bucket form of buckets_unit, for the 1:1 kernels, where it is at most half the size (round 5: the LINEAR mode, whose
+  // thresholds crowd near zero -- sRGB's slope 12.92 -- and force N = 4096 uniform buckets, 33 KiB per workgroup):
+  //     q = (bits(x + log_add) >> 16) - log_first        log_first = bits(log_add) >> 16
+  // i.e. the floats x + log_add that share an exponent and 7 mantissa bits: buckets (x + log_add) / 128 wide, growing with x as
+  // the thresholds' spacing does.  One more VALU instruction per channel than the uniform form (the shift); 645 buckets = 5 KiB
+  // for the LINEAR mode.  log_add == 0: not built (the uniform form is small already).
+  float log_add = 0.0f;
+  uint32_t log_first = 0;
+  std::vector<TransferBucket> buckets_log;  // padded to a 16-byte multiple
 };
+uint32_t bucket_index_log(float x, float log_add);  // bits(x + log_add) >> 16, the add as the kernels do it
 
 // q of the comment above, computed exactly as the kernels do (csrc/bt709_device.h magic_index).
 uint32_t bucket_index(float x, float magic);

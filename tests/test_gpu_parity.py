@@ -350,8 +350,8 @@ def test_frame_sharder_four_lanes_on_one_device(gh, oracle):
 @pytest.mark.parametrize("case", [((3840, 8), 64, False), ((7680, 4), 72, False), ((1920, 12), 80, False), ((328, 10), 64, False),
                                   ((640, 6), 64, True), ((640, 6), 64, False, "sRGB"), ((644, 6), 72, False, "Linear"),
                                   ((1280, 4), 64, False, "ITU709"), ((640, 6), 70, False), ((328, 6), 77, True),
-                                  # the LINEAR mode's big-table kernel (decode_nv12_quads_rows): 4 row pairs per workgroup under the map,
-                                  # 2 for launches of 8-63 frames; ragged last groups (5 and 6 row pairs), stacked row pairs (1920 wide)
+                                  # the LINEAR mode's log-bucket kernel (decode_nv12_quads_log) under the map and below it, odd row-pair
+                                  # counts, stacked row pairs (1920 wide)
                                   ((644, 10), 72, False, "Linear"), ((1920, 12), 80, False, "Linear"), ((644, 10), 12, False, "Linear"),
                                   ((1920, 12), 9, False, "Linear"), ((3840, 6), 3, False, "Linear")])
 def test_xcd_band_work_map(gh, oracle, case):

@@ -84,6 +84,47 @@ def test_host_built_thresholds_equal_reference(lib, refdata, oracle, gamma):
 
 
 @pytest.mark.parametrize("gamma", [0, 1, 2, 3])
+def test_host_decode_table_lookup_is_exact_at_every_breakpoint(lib, oracle, gamma):
+    """The table the 1:1 kernels stage (bt709hip_gamma_lookup_decode): for the LINEAR mode the LOG-bucket form -- bucket =
+    (bits(x + 2^-5) >> 16) - first, 645 buckets instead of 4 096 -- replayed on the host with the kernels' own index function.
+    Breakpoints are the thresholds and the bucket boundaries (the floats x where x + 2^-5 crosses a multiple of 2^16 in its
+    bit pattern): every float within 2 ulps of each against the oracle's composite, plus a strided sweep; the index is
+    monotone and ends at the last bucket."""
+    n, q, log_form = C.c_int(), C.c_int(), C.c_int()
+    assert lib.bt709hip_gamma_lookup_decode(gamma, 0.0, C.byref(n), C.byref(q), C.byref(log_form)) == oracle.transfer_to_byte(gamma, 0.0)
+    assert q.value == 0 and log_form.value == (1 if gamma == 2 else 0)
+    N = n.value
+    if not log_form.value:
+        m = C.c_int()
+        lib.bt709hip_gamma_lookup(gamma, 0.0, C.byref(m), None)
+        assert N == m.value  # the uniform table: covered by the test below
+        return
+    assert N == 645
+    pts = set()
+    thr = oracle.thresholds(gamma)
+    for t in thr[np.isfinite(thr)].view(np.uint32):
+        pts.update(range(max(int(t) - 2, 0), int(t) + 3))
+    add = np.float32(2.0 ** -5)
+    for k in range(int(np.array([add], np.float32).view(np.uint32)[0]) >> 16, (0x3F800000 >> 16) + 8):
+        edge = np.array([k << 16], np.uint32).view(np.float32)[0] - add  # exact: both are multiples of 2^-28 here or coarser
+        if 0.0 <= edge <= 1.0:
+            b = int(np.array([edge], np.float32).view(np.uint32)[0])
+            pts.update(range(max(b - 3, 0), b + 4))
+    pts.update(range(0, 0x3F800000, 104729))
+    one = 0x3F800000
+    xs = np.array(sorted(p for p in pts if p <= one), dtype=np.uint32).view(np.float32)
+    last_q, seen = -1, set()
+    for x in xs:
+        got = lib.bt709hip_gamma_lookup_decode(gamma, float(x), None, C.byref(q), None)
+        assert got == oracle.transfer_to_byte(gamma, float(x)), (gamma, float(x).hex())
+        assert last_q <= q.value < N
+        last_q = q.value
+        seen.add(q.value)
+    assert last_q == N - 1 and len(seen) == N  # every bucket visited, x == 1.0 in the last one
+    assert lib.bt709hip_gamma_lookup_decode(gamma, 1.5, None, None, None) == _capi.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("gamma", [0, 1, 2, 3])
 def test_host_bucket_lookup_is_exact_at_every_breakpoint(lib, oracle, gamma):
     """The kernels' lookup (bucket index by one float add, then one compare) replayed on the host:
     a piecewise-constant function can only be wrong next to a breakpoint, and its breakpoints are
@@ -307,7 +348,7 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
     instruction has 1/255f (0x3b808081) as its multiplier, and a multiply fused with the float -> half
     conversion (v_fma_mix*: one rounding instead of two) appears nowhere."""
     n = fused = 0
-    for kernel in ("17decode_nv12_quads", "22decode_nv12_quads_rows", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
+    for kernel in ("17decode_nv12_quads", "21decode_nv12_quads_log", "18decode_nv12_blocks", "16decode_nv12_half", "20decode_nv12_half_rep",
                    "18decode_nv12_scaled", "19decode_nv12_rgba16fILi0E", "19decode_nv12_rgba16fILi1E", "13render_scaled"):
         # RGBA16F curve variant: the half CANDIDATE (bt709_rgba16f.hip half_texels; not reference arithmetic -- the threshold
         # table settles it, and tests/test_rgba16f.py sweeps it over every float) is slope * x + intercept: one fma with three
@@ -342,7 +383,7 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
             assert candidate == candidate_fmas, (kernel, candidate)
             assert not re.search(r"\bv_(log|exp)_f32", body), kernel  # no transcendental left in any decode kernel
             n += 1
-    assert n == 55  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in three shapes, the 1:1 kernel's big-table form)
+    assert n == 53  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in three shapes, the 1:1 kernel's big-table form)
     # the RGBA16F kernels address LDS absolutely (table at byte 0): the dynamic allocation must be their only LDS
     seen = 0
     for m in re.finditer(r"\.group_segment_fixed_size:\s+(\d+)\s.*?\.name:\s+(\S+)", asm, flags=re.S):

@@ -69,7 +69,7 @@ GATES = [
 #endif
 """),
     ("bt709_kernels.hip",
-     """      decode_quad<HAS_ALPHA, QUANT>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
+     """      decode_quad<HAS_ALPHA, QUANT, LOGIDX>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
                              bot);
       if (q < quads && rp_raw < row_pairs) {
 """,
@@ -77,7 +77,7 @@ GATES = [
       top = u32x4{ya[r][u], yb[r][u], cw[r][u], ya[r][u] ^ cw[r][u]};
       bot = u32x4{yb[r][u], cw[r][u], ya[r][u], yb[r][u] ^ cw[r][u]};
 #else
-      decode_quad<HAS_ALPHA, QUANT>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
+      decode_quad<HAS_ALPHA, QUANT, LOGIDX>(ul, ya[r][u], yb[r][u], cw[r][u], HAS_ALPHA ? aa[r][u] : 0u, HAS_ALPHA ? ab[r][u] : 0u, p.alpha_word, top,
                              bot);
 #endif
 #if defined(BT709_LAB_NO_STORES)  // with BT709_LAB_NO_ARITH: the loads alone (a store about once in 2^32 quads keeps them alive)
@@ -405,7 +405,7 @@ constexpr bool kRepUniformEncode = true;
      """      uint32_t b[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch)
-        b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)));
+        b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)) >> ul.shift);
       o[k] = pack_bgra(b[0], b[1], b[2], p.alpha_word);
 """,
      """#if defined(BT709_LAB_UNC_NO_ARITH)  // WRONG OUTPUT: +unconvert:'s loads and stores with no lookups
@@ -414,7 +414,7 @@ constexpr bool kRepUniformEncode = true;
       uint32_t b[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch)
-        b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)));
+        b[ch] = QUANT ? quantise_byte(x[3 * k + ch]) : bucket_byte(ul, x[3 * k + ch], __float_as_uint(__fadd_rn(x[3 * k + ch], ul.magic)) >> ul.shift);
       o[k] = pack_bgra(b[0], b[1], b[2], p.alpha_word);
 #endif
 """),

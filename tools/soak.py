@@ -3,7 +3,7 @@
 decode (opaque / alpha, 8-bit and RGBA16Float targets), exact 2:1 (both kernels, with alpha), any-ratio
 (with alpha), the reference's two passes through both intermediate formats, the encoder, the frame ring and the
 coalescing submit (round 4); round 5: ring sets on every visible device, batched RGBA16Float launches of both kernel
-shapes, +unconvert: batches, the LINEAR mode's big-table kernel at batch sizes on both sides of its row-pair switch.
+shapes, +unconvert: batches, the LINEAR mode's log-bucket kernel at many batch sizes.
 Fresh seeds every time it is used; the committed tests hold the fixed-seed fuzz."""
 import os
 import sys
@@ -122,7 +122,7 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
         assert mb.BGRAToBT709Converter.unconvertBatch(dec, frs, texs, ww, hh), dec.lastStatus
         got = np.concatenate([ctx.getBGRATexturePixels(t).reshape(-1) for t in texs])
         want = np.concatenate([oracle.unconvert_packed(g, f, ww, hh) | np.uint32(dec.alphaFill << 24) for f in frs])
-    elif kind == 11:  # round 5: the LINEAR mode through decode_nv12_quads_rows (2 row pairs per workgroup from 8 frames on), ragged heights
+    elif kind == 11:  # round 5: the LINEAR mode (its log-bucket table, decode_nv12_quads_log) at batch sizes on both sides of the work map's thresholds, ragged heights
         n = int(rng.integers(1, 24))
         hh = 2 * int(rng.integers(1, 12))
         dec = gh.make_decoder(mb.MetalBT709GammaLinear)
