@@ -599,7 +599,7 @@ int bt709hip_matrix_constants(float constants[8]);
  * returns the number of entries the table has (0: the gamma has no curve), or <0. */
 int bt709hip_half_thresholds(int gamma, float *thresholds, int capacity);
 /* The kernels' settlement of one saturated x replayed on the host: the candidate is the exact code
- * H(x) moved by candidate_offset (0 or -1: the kernel biases its fast exp2/log2 downward, so it lands on
+ * H(x) moved by candidate_offset (0 or -1: the kernel's candidate, one fma over a tangent of the curve, lies below the true value and lands on
  * H or H - 1), then corrected against the one threshold above it.  Returns the half code;
  * *table_entries (optional) as above. */
 int bt709hip_half_lookup(int gamma, float x, int candidate_offset, int *table_entries);
