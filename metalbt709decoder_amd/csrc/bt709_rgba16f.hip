@@ -164,9 +164,10 @@ __device__ __forceinline__ void half_texels(const HalfLookup &t, const float *x,
 //   (4, 2, 512)  0.745 / 0.691 / 0.434      (4, 3, 512)  0.750 / 0.629 / 0.496      (8, 2, 256)  0.749 / 0.659 / 0.457
 //   (2, 3, 960)  0.716 / 0.682 / 0.536      (2, 2, 960)  0.654 / 0.630 / 0.457      (4, 1, 512)  0.628 / 0.583 / 0.487
 // Shipped: (4, 2, 512) -- a 4K row pair is one tile of 480 busy lanes, 8 waves per workgroup, four workgroups per CU -- and
-// (2, 3, 960) for launches too small to fill the chip with it (a single 4K frame is 540 such workgroups).  The same shapes
-// with the arithmetic deleted stream at 0.84: what is left between 0.75 and that is the lookups' own cost (225 VALU
-// instructions and 24 LDS gathers per 2x2 block), not the traffic pattern.
+// (2, 3, 960) for launches too small to fill the chip with it (a single 4K frame is 540 such workgroups).  With the lookups in
+// their packed-pair form (half_texels above; those numbers were taken with 12 instructions per channel) the shipped shape runs
+// at 0.76-0.78 and within 1.4 % of the same launch with its arithmetic deleted: what is left to the table-less pattern's 0.84
+// is the 39 KiB staged per workgroup (profiles/r05_ab_rgba16f_packed.txt; the shapes re-measured there: (4, 2, 512) still).
 #ifndef BT709_RGBA16F_NB
 #define BT709_RGBA16F_NB 4
 #endif
