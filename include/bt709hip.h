@@ -39,9 +39,10 @@
 extern "C" {
 #endif
 
-/* ABI version: bumped whenever a struct layout or a signature in this file changes.  Bindings compare
+/* ABI version: bumped whenever a struct layout or a signature in this file changes or an export is added (501:
+ * bt709hip_gamma_lookup_decode; upload / download wait for pageable host memory).  Bindings compare
  * it with bt709hip_abi_version() so that a library older than the header is refused, not mis-called. */
-#define BT709HIP_VERSION 500
+#define BT709HIP_VERSION 501
 
 typedef struct bt709hip_context bt709hip_context; /* ~ MetalRenderContext */
 typedef struct bt709hip_decoder bt709hip_decoder; /* ~ MetalBT709Decoder  */

@@ -24,7 +24,7 @@ class Surface(C.Structure):  # bt709hip_surface
                 ("format", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 500  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
+ABI_VERSION = 501  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
 
 # bt709hip_format
 FORMAT_BGRA8_SRGB = 0
