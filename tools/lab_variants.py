@@ -250,6 +250,29 @@ constexpr bool kRepUniformEncode = true;
     const f32x2 u = f32x2{x[2 * i], x[2 * i + 1]} * t.index_scale;  // binary32 products (v_pk_mul_f32; -ffp-contract=off)
 #endif
 """),
+    # CORRECT output: the table staged by LDS DMA (global_load_lds_dwordx4: L2 -> LDS without the trip through VGPRs and ds_write)
+    ("bt709_rgba16f.hip",
+     """  u32x4 *d = reinterpret_cast<u32x4 *>(lds);
+  constexpr int kBatch = 5;
+  for (uint32_t base = tid; base < n; base += nthreads * kBatch) {
+""",
+     """#if defined(BT709_LAB_F16_DMA_STAGING)
+  {
+    const uint32_t cand16 = n_thresholds + gap, total16 = cand16 + (n - n_thresholds);  // the LDS image in 16-byte words
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, waves = nthreads >> 6;
+    for (uint32_t c = wave; c * 64u < total16; c += waves) {  // a wave fills 1 KiB of LDS per instruction
+      const uint32_t L = c * 64u + lane;
+      if (L < n_thresholds || (L >= cand16 && L < total16))
+        __builtin_amdgcn_global_load_lds(s + (L < n_thresholds ? L : L - gap), (__attribute__((address_space(3))) void *)(lds + c * 1024u), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+#endif
+  u32x4 *d = reinterpret_cast<u32x4 *>(lds);
+  constexpr int kBatch = 5;
+  for (uint32_t base = tid; base < n; base += nthreads * kBatch) {
+"""),
     # the two gathers of the packed-pair form, one at a time (WRONG OUTPUT; the VALU work around them stays)
     ("bt709_rgba16f.hip",
      """    c[2 * i] = *reinterpret_cast<LdsPairPtr>((pk & 0xfff8u) + kCandBias);  // {intercept, slope}
@@ -423,7 +446,7 @@ constexpr bool kRepUniformEncode = true;
 MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT709_LAB_NO_TABLE", "BT709_NO_FMA_CENTRE",
           "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
           "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE", "BT709_LAB_F16_NO_ARITH", "BT709_LAB_F16_NO_TABLE",
-          "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32"]
+          "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_F16_DMA_STAGING", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32"]
 
 
 def make_lab_sources(dst=LAB_SRC):
