@@ -52,8 +52,8 @@ static_assert((kHalfCandFloor & 7u) == 0 && (kHalfCandLds & 15u) == 0 && kHalfCa
 
 // The table image of a launch (thresholds, then candidate entries) -> LDS: the thresholds to byte 0, the entries to
 // kHalfCandLds.  Every load of a lane is issued before its first write (bt709_device.h stage_table: a round of the loop is an
-// L2 round trip inside the workgroup's lifetime): at most 40 KiB = 2 560 sixteen-byte words, 10 per lane of the smallest
-// workgroup (256 lanes), 5 of a 512-lane one.
+// L2 round trip inside the workgroup's lifetime), five at a time: at most 40 KiB = 2 560 sixteen-byte words, one round for a
+// 512-lane workgroup, two for 256 lanes, more for the 64-lane workgroups of very narrow frames.
 __device__ __forceinline__ void stage_half_tables(unsigned char *lds, const void *src, uint32_t cand_offset, uint32_t bytes) {
   const u32x4 *s = reinterpret_cast<const u32x4 *>(src);
   const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
