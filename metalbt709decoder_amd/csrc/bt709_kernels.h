@@ -46,8 +46,8 @@ struct DecodeParams {
   FramePlanes frames[kMaxBatch];
   // decode kernels: TransferBucket[N + 1], edges in x units (transfer_tables.h buckets_unit)
   const void *table_unit;
-  // rescale kernels: TransferBucketLinear[N + 1] (edges in x units) and the two-resolution
-  // sRGB-encode table (transfer_tables.h SplitTable): q = min(qf, (qf >> encode_shift) + encode_offset)
+  // rescale kernels: TransferBucketLinear[N + 1] (edges in x units) and the sRGB-encode table in LOG-bucket form
+  // (transfer_tables.h TransferTable::buckets_log of the LINEAR composite): bucket of a mean v = (bits(v + encode_log_add) >> 16) - encode_log_first
   const void *table_linear;
   const void *table_encode;
   // persistent 2:1 kernel, encode side: the same composite as a uniform table with a non-power-of-two
@@ -58,8 +58,8 @@ struct DecodeParams {
   uint32_t table_unit_bytes;
   uint32_t table_linear_bytes;
   uint32_t table_encode_bytes;
-  float encode_scale;  // n_fine of table_encode
-  uint32_t encode_offset, encode_shift;
+  float encode_log_add;
+  uint32_t encode_log_first;
   float unit_magic;    // 2^23 / N: floats in [M, 2M) have ulp 1/N (bt709_device.h magic_index12): table_linear's index
   // table_unit's index (the 1:1 kernels): q = (bits(x + unit1_magic) >> unit1_shift) - unit1_first.  Uniform form: the same M,
   // shift 0, first = bits(M); log-bucket form (transfer_tables.h TransferTable::buckets_log): log_add, 16, log_first.
@@ -121,12 +121,12 @@ struct RenderParams {
   uint32_t width, height, out_width, out_height;
   float scale_x, scale_y;
   uint32_t rows;       // output rows a workgroup walks (filled by the launcher)
-  // tables (device): two-resolution sRGB-encode buckets and lin[256] = sRGB_nonLinearNormToLinear(byteNorm(b))
+  // tables (device): log-bucket sRGB-encode buckets and lin[256] = sRGB_nonLinearNormToLinear(byteNorm(b))
   // (the alpha channel is filtered and quantised in arithmetic)
   const void *table_encode, *table_lin;
   uint32_t table_encode_bytes;
-  float encode_scale;  // n_fine of table_encode
-  uint32_t encode_offset, encode_shift;
+  float encode_log_add;        // table_encode is the log-bucket form (as DecodeParams)
+  uint32_t encode_log_first;
   int64_t in_step, out_step;  // batched launches: surface i of the launch = surface 0 + i * step (evenly spaced, as in a ring)
 };
 // grid = (column tiles, strips of `rows` output rows, frames)

@@ -9,8 +9,9 @@
 // decoded to its 8-bit sRGB value and linearised as the sRGB8 sampler would -- the decode-side
 // table returns that linear float directly, {edge, lin(base), lin(base + 1)} in one 16-byte
 // bucket (transfer_tables.h TransferBucketLinear) -- the taps are combined in linear light, and the result is sRGB-encoded and quantised
-// through the LINEAR-mode composite, held as a two-resolution bucket table (transfer_tables.h
-// SplitTable).
+// through the LINEAR-mode composite, held as a log-bucket table (transfer_tables.h TransferTable::buckets_log: 645
+// buckets, index by one fma and one shift; rounds 1-5a: a two-resolution table, three instructions more per lookup).
+// The persistent 2:1 kernel keeps a uniform table with a non-power-of-two bucket count (index by ONE fma).
 //
 // The kernels are bound by VALU issue slots and by the LDS pipe together (12 decode-side + 3 encode-side lookups
 // per output pixel; DESIGN.md 6.0 has the counters): per decode-side lookup a saturating add, the magic add, the
@@ -39,9 +40,10 @@ struct RescaleLookup {
   uint32_t dec_off;    // LDS address + lane's copy offset - (bits(magic) << dec_shift)
   uint32_t enc_shift;  // log2(8 R2)
   uint32_t enc_off;    // LDS address of the encode table + lane's copy offset
-  uint32_t split_offset, split_shift;  // SplitTable: q = min(qf, (qf >> shift) + offset)
-  float quarter_scale;  // 0.25 * scale
-  float scale;          // n_fine of the encode table * 2^40 (the linear values come scaled by 2^-40)
+  // log-bucket encode table (every kernel but the persistent 2:1 one): bucket of a value a in the kernel's own domain =
+  // (bits(fma(a, quarter_unscale, enc_add)) >> 16) - first; a * quarter_unscale is the mean in [0, 1], exact (a power of two)
+  float enc_add;
+  uint32_t enc_log_off;  // enc_off - (first << enc_shift)
   // uniform encode table (persistent kernel): v = sum * quarter_unscale is the mean itself, xs = v * enc_n
   float quarter_unscale;  // 0.25 * 2^40
   float enc_n;
@@ -65,16 +67,15 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   u32x2 *d2 = reinterpret_cast<u32x2 *>(lds_raw + dec_bytes);
   const u32x2 *src2 = reinterpret_cast<const u32x2 *>(UNIFORM_ENCODE ? p.table_encode_u : p.table_encode);
   const uint32_t n2 = ((UNIFORM_ENCODE ? p.table_encode_u_bytes : p.table_encode_bytes) / 8) << r2;
-  if (UNIFORM_ENCODE) {
-    // edges move into the domain of the taps' sum: edge * 4 * 2^-40 (a power of two: exact; +inf stays +inf)
+  {
+    // edges move into the domain of the value the kernel compares -- the taps' sum, or their weighted sum: edge * 2^sum_log2 *
+    // 2^-40 (a power of two: exact; +inf stays +inf)
     const float to_sum = __uint_as_float(static_cast<uint32_t>(127 + sum_log2 + kLinearScaleLog2) << 23);
     stage_batched(d2, n2, tid, nthreads, [&](uint32_t i) {
       u32x2 e = src2[i >> r2];
       e.x = __float_as_uint(__fmul_rn(__uint_as_float(e.x), to_sum));
       return e;
     });
-  } else {
-    stage_batched(d2, n2, tid, nthreads, [&](uint32_t i) { return src2[i >> r2]; });
   }
 
   const uint32_t base = lds_address(lds_raw);
@@ -84,11 +85,10 @@ __device__ __forceinline__ RescaleLookup stage_rescale_tables(unsigned char *lds
   r.dec_off = base + (tid & ((1u << r1) - 1u)) * 16u - (__float_as_uint(r.magic) << r.dec_shift);
   r.enc_shift = 3u + r2;
   r.enc_off = base + dec_bytes + (tid & ((1u << r2) - 1u)) * 8u;
-  r.split_offset = p.encode_offset;
-  r.split_shift = p.encode_shift;
+  r.enc_add = p.encode_log_add;
+  r.enc_log_off = r.enc_off - (p.encode_log_first << r.enc_shift);
+  asm volatile("" : "+v"(r.enc_log_off));  // ONE addend of the v_lshl_add
   const float unscale = __uint_as_float(static_cast<uint32_t>(127 - kLinearScaleLog2) << 23);  // 2^40
-  r.scale = __fmul_rn(p.encode_scale, unscale);
-  r.quarter_scale = __fmul_rn(0.25f, r.scale);
   r.quarter_unscale = __fmul_rn(__uint_as_float((127u - sum_log2) << 23), unscale);  // 2^-sum_log2 * 2^40
   r.enc_n = p.encode_u_n;
   r.enc_u_off = r.enc_off - (0x4b000000u << r.enc_shift);
@@ -109,14 +109,15 @@ __device__ __forceinline__ uint32_t encode_byte_uniform(const RescaleLookup &r, 
   return e.y + (s >= __uint_as_float(e.x) ? 1u : 0u);
 }
 
-// sRGB byte of a linear value scaled into the encode table's domain (xs = v * n_fine)
-__device__ __forceinline__ uint32_t encode_byte(const RescaleLookup &r, float xs) {
-  // fine index below the split, coarse above: the two index functions cross exactly at the split
-  // and the fine one grows faster, so the smaller one is always the right one
-  const uint32_t qf = static_cast<uint32_t>(xs);
-  const uint32_t q = min(qf, (qf >> r.split_shift) + r.split_offset);
-  const u32x2 e = *reinterpret_cast<LdsPairPtr>((q << r.enc_shift) + r.enc_off);
-  return e.y + (xs >= __uint_as_float(e.x) ? 1u : 0u);
+// sRGB byte of a linear-light value a in the kernel's own domain (a sum of taps times 2^-40, a weighted sum, a unit-range mean:
+// RescaleLookup::quarter_unscale takes it to the mean v in [0, 1]) through the LOG-bucket table: bucket = (bits(v + add) >> 16) -
+// first -- ONE fma (the product inside is exact: a power of two), one shift -- and the bucket's edge compared in a's own domain
+// (edges pre-divided at staging).  Rounds 2-5a used a two-resolution table here: multiply, convert, shift, add, min (three
+// instructions more per lookup).
+__device__ __forceinline__ uint32_t encode_byte(const RescaleLookup &r, float a) {
+  const uint32_t t = __float_as_uint(__builtin_fmaf(a, r.quarter_unscale, r.enc_add)) >> 16;
+  const u32x2 e = *reinterpret_cast<LdsPairPtr>((t << r.enc_shift) + r.enc_log_off);
+  return e.y + (a >= __uint_as_float(e.x) ? 1u : 0u);
 }
 
 // linear-light values (times 2^-40) of 12 saturated channel values: kLinBatch buckets in flight per wait
@@ -203,8 +204,7 @@ __device__ __forceinline__ uint32_t half_px(const RescaleLookup &r, float y00, f
   const float sg = __fadd_rn(__fadd_rn(__fadd_rn(lg[0], lg[1]), lg[2]), lg[3]);
   const float sb = __fadd_rn(__fadd_rn(__fadd_rn(lb[0], lb[1]), lb[2]), lb[3]);
   if (UNIFORM_ENCODE) return pack_bgra(encode_byte_uniform(r, sr), encode_byte_uniform(r, sg), encode_byte_uniform(r, sb), alpha_word);
-  return pack_bgra(encode_byte(r, __fmul_rn(sr, r.quarter_scale)), encode_byte(r, __fmul_rn(sg, r.quarter_scale)),
-                   encode_byte(r, __fmul_rn(sb, r.quarter_scale)), alpha_word);
+  return pack_bgra(encode_byte(r, sr), encode_byte(r, sg), encode_byte(r, sb), alpha_word);
 }
 
 // The two output pixels of a quad through the uniform encode table, SOFTWARE-PIPELINED over the LDS (round 4).  half_px
@@ -773,9 +773,9 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
       acc[k] = __fadd_rn(acc[k], __fmul_rn(w[2], bot.v[k]));
       acc[k] = __fadd_rn(acc[k], __fmul_rn(w[3], bot.v[3 + k]));
     }
-    const uint32_t R = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[0]) : encode_byte(r, __fmul_rn(acc[0], r.scale));
-    const uint32_t G = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[1]) : encode_byte(r, __fmul_rn(acc[1], r.scale));
-    const uint32_t B = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[2]) : encode_byte(r, __fmul_rn(acc[2], r.scale));
+    const uint32_t R = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[0]) : encode_byte(r, acc[0]);
+    const uint32_t G = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[1]) : encode_byte(r, acc[1]);
+    const uint32_t B = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[2]) : encode_byte(r, acc[2]);
     uint32_t aw = p.alpha_word;
     if (HAS_ALPHA) {
       float av = __fmul_rn(w[0], top.a[0]);
@@ -820,7 +820,7 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
 
 // A workgroup = 256 output columns x kScaledStrips strips of `scaled_rows` output rows of one frame; its
 // waves share nothing but the single-copy tables.  Measured on 4K -> 1440p, 8 frames per launch, same call
-// (profiles/r02_ab_scaled.txt): one strip + the 6 KiB two-resolution encode table (14 KiB staged per
+// (profiles/r02_ab_scaled.txt): one strip + the (then) 6 KiB two-resolution encode table (14 KiB staged per
 // workgroup) 240 Gpixel/s; two strips per workgroup 224; the 24 KiB uniform encode table (9 fewer VALU
 // instructions per pixel, but 32 KiB staged per 4 096 output pixels and 5 workgroups per CU) 194.
 #ifndef BT709_SCALED_STRIPS
@@ -903,8 +903,9 @@ render_scaled(const RenderParams p) {
   RescaleLookup r = {};
   r.enc_shift = 3;
   r.enc_off = 1024u;  // behind lin[256]
-  r.split_offset = p.encode_offset;
-  r.split_shift = p.encode_shift;
+  r.enc_add = p.encode_log_add;
+  r.enc_log_off = r.enc_off - (p.encode_log_first << r.enc_shift);
+  r.quarter_unscale = 1.0f;  // the filter's sums are unit-range values here: the table's own domain, edges staged as they are
   typedef __attribute__((address_space(3))) const float *LdsFloatPtr;
   uint32_t two = 2u;  // SDWA operands cannot be inline constants
   asm("" : "+v"(two));
@@ -1013,9 +1014,9 @@ render_scaled(const RenderParams p) {
       acc[k] = __fadd_rn(acc[k], __fmul_rn(w[2], bot.s[k]));
       acc[k] = __fadd_rn(acc[k], __fmul_rn(w[3], bot.s[4 + k]));
     }
-    const uint32_t R = encode_byte(r, __fmul_rn(add_sat(acc[0], 0.0f), p.encode_scale));
-    const uint32_t G = encode_byte(r, __fmul_rn(add_sat(acc[1], 0.0f), p.encode_scale));
-    const uint32_t B = encode_byte(r, __fmul_rn(add_sat(acc[2], 0.0f), p.encode_scale));
+    const uint32_t R = encode_byte(r, add_sat(acc[0], 0.0f));
+    const uint32_t G = encode_byte(r, add_sat(acc[1], 0.0f));
+    const uint32_t B = encode_byte(r, add_sat(acc[2], 0.0f));
     const uint32_t A = alpha_word_of(acc[3]);
     __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, A), rout, ox * 4u, oy * p.out_stride, 0);
   };

@@ -48,7 +48,8 @@ struct bt709hip_context {
   EncoderTables encoders[3][3];  // [input gamma][output gamma], built on first use
   // bt709hip_render_scaled (pass 2 alone): built on first use under encoder_mutex
   void *d_render_encode = nullptr, *d_render_lin = nullptr;
-  uint32_t render_encode_bytes = 0, render_encode_n = 0, render_encode_offset = 0, render_encode_shift = 0;
+  uint32_t render_encode_bytes = 0, render_encode_log_first = 0;
+  float render_encode_log_add = 0.0f;
   // decoders of this context with BT709HIP_OPT_COALESCE on: every entry point that takes a stream issues their queued
   // frames for that stream first (flush_stream), so the stream keeps its order
   std::atomic<int> n_coalescing{0};
@@ -91,10 +92,10 @@ struct bt709hip_decoder {
   uint32_t table_unit_bytes = 0;
   void *d_table_linear = nullptr;  // TransferBucketLinear[N + 1] (rescale kernels, decode side)
   uint32_t table_linear_bytes = 0;
-  void *d_encode = nullptr;        // LINEAR-mode two-resolution TransferBucket[] (rescale kernels, encode side)
+  void *d_encode = nullptr;        // the sRGB-encode composite's log-bucket TransferBucket[] (rescale kernels, encode side)
   uint32_t encode_bytes = 0;
-  uint32_t encode_n = 0;
-  uint32_t encode_offset = 0, encode_shift = 0;
+  float encode_log_add = 0.0f;
+  uint32_t encode_log_first = 0;
   void *d_encode_u = nullptr;      // the same composite as a UniformTable (persistent 2:1 kernel)
   uint32_t encode_u_bytes = 0, encode_u_n = 0;
   // RGBA16F targets: threshold table of the half-float composite (transfer_tables.h HalfTable), built on
@@ -274,9 +275,8 @@ void set_tables(DecodeParams *p, const bt709hip_decoder *dec) {
   p->encode_u_n = static_cast<float>(dec->encode_u_n);
   p->table_encode = dec->d_encode;
   p->table_encode_bytes = dec->encode_bytes;
-  p->encode_scale = static_cast<float>(dec->encode_n);
-  p->encode_offset = dec->encode_offset;
-  p->encode_shift = dec->encode_shift;
+  p->encode_log_add = dec->encode_log_add;
+  p->encode_log_first = dec->encode_log_first;
   p->unit_magic = 8388608.0f / static_cast<float>(dec->table_n);  // 2^23 / N, exact: N is a power of two
   p->unit1_magic = dec->unit1_magic;
   p->unit1_first = dec->unit1_first;
@@ -874,9 +874,9 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   if (int rc = bind(dec->ctx)) return rc;
 
   TransferTable t;
-  SplitTable enc;  // sRGB encoder of the rescale kernel: two-resolution form (6 KiB instead of 33)
+  TransferTable enc;  // sRGB encoder of the rescale kernels: the LINEAR composite's log-bucket form (5 KiB instead of 33)
   UniformTable enc_u;
-  if (!build_transfer_table(dec->gamma, &t) || !build_split_table(kGammaLinear, &enc) ||
+  if (!build_transfer_table(dec->gamma, &t) || !build_transfer_table(kGammaLinear, &enc) || enc.buckets_log.empty() ||
       !build_uniform_table(kGammaLinear, 256, &enc_u))
     return BT709HIP_ERR_UNSUPPORTED;
   dec->table_n = t.n;
@@ -892,16 +892,14 @@ int bt709hip_decoder_setup(bt709hip_decoder *dec) {
   dec->unit1_shift = log_form ? 16u : 0u;
   dec->table_unit_bytes = static_cast<uint32_t>(unit.size() * sizeof(TransferBucket));
   dec->table_linear_bytes = static_cast<uint32_t>(t.buckets_linear.size() * sizeof(TransferBucketLinear));
-  dec->encode_n = enc.n_fine;
-  dec->encode_offset = enc.coarse_offset;
-  dec->encode_shift = 0;
-  for (float r = enc.coarse_scale; r < 1.0f; r *= 2.0f) ++dec->encode_shift;  // log2(fine buckets per coarse bucket)
-  dec->encode_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
+  dec->encode_log_add = enc.log_add;
+  dec->encode_log_first = enc.log_first;
+  dec->encode_bytes = static_cast<uint32_t>(enc.buckets_log.size() * sizeof(TransferBucket));
   void *d_unit = nullptr, *d_linear = nullptr, *d_enc = nullptr, *d_enc_u = nullptr;
   const uint32_t enc_u_bytes = static_cast<uint32_t>(enc_u.buckets.size() * sizeof(TransferBucket));
   int rc = upload_table(unit.data(), dec->table_unit_bytes, &d_unit);
   if (rc == BT709HIP_OK) rc = upload_table(t.buckets_linear.data(), dec->table_linear_bytes, &d_linear);
-  if (rc == BT709HIP_OK) rc = upload_table(enc.buckets.data(), dec->encode_bytes, &d_enc);
+  if (rc == BT709HIP_OK) rc = upload_table(enc.buckets_log.data(), dec->encode_bytes, &d_enc);
   if (rc == BT709HIP_OK) rc = upload_table(enc_u.buckets.data(), enc_u_bytes, &d_enc_u);
   if (rc != BT709HIP_OK) {  // a retry starts from scratch: nothing is published, nothing leaks
     if (d_unit) (void)hipFree(d_unit);
@@ -1264,23 +1262,21 @@ int render_tables(bt709hip_context *ctx, hipStream_t s) {
   std::lock_guard<std::mutex> lock(ctx->encoder_mutex);
   if (ctx->d_render_lin != nullptr) return BT709HIP_OK;
   if (capturing(s)) return BT709HIP_ERR_NOT_SETUP;
-  SplitTable enc;
-  if (!build_split_table(kGammaLinear, &enc)) return BT709HIP_ERR_UNSUPPORTED;
+  TransferTable enc;
+  if (!build_transfer_table(kGammaLinear, &enc) || enc.buckets_log.empty()) return BT709HIP_ERR_UNSUPPORTED;
   float lin[256];
   for (int b = 0; b < 256; ++b) lin[b] = srgb_to_linear(b * (1.0f / 255.0f));
   void *d_enc = nullptr, *d_lin = nullptr;
-  const uint32_t enc_bytes = static_cast<uint32_t>(enc.buckets.size() * sizeof(TransferBucket));
-  int rc = upload_table(enc.buckets.data(), enc_bytes, &d_enc);
+  const uint32_t enc_bytes = static_cast<uint32_t>(enc.buckets_log.size() * sizeof(TransferBucket));
+  int rc = upload_table(enc.buckets_log.data(), enc_bytes, &d_enc);
   if (rc == BT709HIP_OK) rc = upload_table(lin, sizeof lin, &d_lin);
   if (rc != BT709HIP_OK) {
     if (d_enc) (void)hipFree(d_enc);
     return rc;
   }
   ctx->render_encode_bytes = enc_bytes;
-  ctx->render_encode_n = enc.n_fine;
-  ctx->render_encode_offset = enc.coarse_offset;
-  ctx->render_encode_shift = 0;
-  for (float r = enc.coarse_scale; r < 1.0f; r *= 2.0f) ++ctx->render_encode_shift;
+  ctx->render_encode_log_add = enc.log_add;
+  ctx->render_encode_log_first = enc.log_first;
   ctx->d_render_encode = d_enc;
   ctx->d_render_lin = d_lin;  // the "built" marker: last
   return BT709HIP_OK;
@@ -1358,9 +1354,8 @@ static int render_scaled_launch(bt709hip_context *ctx, int count, const bt709hip
   p.table_encode = ctx->d_render_encode;
   p.table_lin = ctx->d_render_lin;
   p.table_encode_bytes = ctx->render_encode_bytes;
-  p.encode_scale = static_cast<float>(ctx->render_encode_n);
-  p.encode_offset = ctx->render_encode_offset;
-  p.encode_shift = ctx->render_encode_shift;
+  p.encode_log_add = ctx->render_encode_log_add;
+  p.encode_log_first = ctx->render_encode_log_first;
   p.in_step = in_step;
   p.out_step = out_step;
   const char *name = launch_render_scaled(p, count, in->format == BT709HIP_FORMAT_RGBA16F,

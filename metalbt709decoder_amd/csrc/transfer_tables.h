@@ -111,7 +111,8 @@ bool build_encode_tables(int in_gamma, int out_gamma, EncodeTables *out);
 
 // Two-resolution bucket table over x in [0,1] for composites whose thresholds crowd near zero
 // (the encoder's BT709_from_linear tables need N = 4096 uniformly, 33 KiB, only because of
-// their first 1/16 of the range).  With xs = n_fine * x:
+// their first 1/16 of the range).  Used by the ENCODER (bt709_encode.hip); the rescale kernels' encode side moved to the
+// log-bucket form above in round 5 (fewer instructions per lookup).  With xs = n_fine * x:
 //     q = xs < split ? (uint)xs : (uint)(xs * coarse_scale) + coarse_offset
 //       = min((uint)xs, ((uint)xs >> log2(ratio)) + coarse_offset)   // the two index functions cross at
 //                                                                    // the split, the fine one grows faster

@@ -376,6 +376,8 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
                     continue
                 if re.match(r"v_fmaak_f32 v\d+, [sv]\d+, v\d+, 0x4b000000$", line.strip()):
                     continue  # the uniform encode table's index, bits(fma(sum, k, 2^23)): an index function, not reference arithmetic
+                if re.match(r"v_fmamk_f32 v\d+, v\d+, 0x5[23]800000, v\d+$|v_fmac_f32_e32 v\d+, 0x5[23]800000, v\d+$", line.strip()):
+                    continue  # the log-bucket encode table's index, bits(fma(sum, 2^38 | 2^40, 2^-5)) >> 16: the product is exact (a power of two)
                 assert re.match(r"v_fmamk_f32 v\d+, v\d+, 0x3b808081, v\d+|v_fmac_f32_e32 v\d+, 0x3b808081, v\d+", line), (kernel, line)
                 fused += 1
             assert not re.search(r"\bv_pk_(fma|add)_f32", body), kernel  # half-rate packed f32 ops stay out (-fno-slp-vectorize)
