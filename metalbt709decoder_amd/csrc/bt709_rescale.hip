@@ -835,6 +835,10 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
 #define BT709_SCALED_DEC_COPIES_LOG2 0
 #endif
 constexpr uint32_t kScaledDecCopiesLog2 = BT709_SCALED_DEC_COPIES_LOG2;
+#ifndef BT709_SCALED_ENC_COPIES_LOG2
+#define BT709_SCALED_ENC_COPIES_LOG2 0
+#endif
+constexpr uint32_t kScaledEncCopiesLog2 = BT709_SCALED_ENC_COPIES_LOG2;  // interleaved copies of the 5 KiB encode-side table
 constexpr uint32_t kScaledStrips = BT709_SCALED_STRIPS;
 constexpr bool kScaledUniform = BT709_SCALED_UNIFORM != 0;
 // PERSISTENT: the launch has as many workgroups as the chip holds at once and workgroup g takes the work items g,
@@ -846,7 +850,7 @@ template <int TAPS, bool HAS_ALPHA, bool PERSISTENT>
 __global__ void __launch_bounds__(kBlockThreads *kScaledStrips)
 decode_nv12_scaled(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const RescaleLookup r = stage_rescale_tables<kScaledUniform>(lds_raw, p, kScaledDecCopiesLog2, 0, 0);
+  const RescaleLookup r = stage_rescale_tables<kScaledUniform>(lds_raw, p, kScaledDecCopiesLog2, kScaledEncCopiesLog2, 0);
   __syncthreads();
   if (PERSISTENT) {
     const uint32_t strips = (p.out_height + p.scaled_rows - 1) / p.scaled_rows;
@@ -1159,7 +1163,7 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
   p.scaled_rows = rows;
   const uint32_t strips = (p.out_height + rows - 1) / rows;
   const uint32_t strip_groups = (strips + kScaledStrips - 1) / kScaledStrips;
-  const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << kScaledDecCopiesLog2) + (kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes);
+  const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << kScaledDecCopiesLog2) + ((kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes) << kScaledEncCopiesLog2);
   const dim3 block(kBlockThreads, kScaledStrips);
   const bool persistent = taps != TAPS_SHARED;
   dim3 grid(cols, strip_groups, static_cast<uint32_t>(frames));
