@@ -40,9 +40,9 @@ extern "C" {
 #endif
 
 /* ABI version: bumped whenever a struct layout or a signature in this file changes or an export is added (501:
- * bt709hip_gamma_lookup_decode; upload / download wait for pageable host memory).  Bindings compare
+ * bt709hip_gamma_lookup_decode; upload / download wait for pageable host memory; 502: bt709hip_ring_options.format).  Bindings compare
  * it with bt709hip_abi_version() so that a library older than the header is refused, not mis-called. */
-#define BT709HIP_VERSION 501
+#define BT709HIP_VERSION 502
 
 typedef struct bt709hip_context bt709hip_context; /* ~ MetalRenderContext */
 typedef struct bt709hip_decoder bt709hip_decoder; /* ~ MetalBT709Decoder  */
@@ -408,8 +408,8 @@ int bt709hip_pool_wait(bt709hip_pool *pool, int slot, const void **bgra, size_t 
 int bt709hip_pool_release(bt709hip_pool *pool, int slot);
 
 /* --------------------------------------------------------------- frame ring */
-/* Frames that live in DEVICE memory: a ring of `frames` same-sized NV12 inputs carved from one slab and their BGRA8 outputs
- * from another (frame i at slab + i * spacing: any count goes out as one launch, bt709hip_decode_batch's "evenly spaced"
+/* Frames that live in DEVICE memory: a ring of `frames` same-sized NV12 inputs carved from one slab and their outputs (BGRA8, or RGBA16F through
+ * bt709hip_ring_options.format) from another (frame i at slab + i * spacing: any count goes out as one launch, bt709hip_decode_batch's "evenly spaced"
  * form) -- what a streaming application keeps resident, and what bench.py times.  The reference's twin is the set of
  * CVPixelBuffers + the render texture it keeps per in-flight frame (AAPLRenderer.m:34, 530-862); unified memory has no
  * placement to choose, a discrete HBM device does: where the two slabs land decides how fast the launch streams (the same
@@ -454,6 +454,11 @@ typedef struct {
   uint32_t max_ms;      /* wall-clock budget of the hunt in milliseconds (checked before every probe); 0 = none */
   int32_t frugal;       /* != 0: max_bytes = the ring + ONE candidate pair, whatever is free: the incumbent pair and the pair being
                            probed are all that ever lives */
+  int32_t format;       /* render target of the ring's outputs: BT709HIP_FORMAT_BGRA8_SRGB (0, the default) or BT709HIP_FORMAT_RGBA16F
+                           (8 bytes per pixel, linear-light halves: the reference's fallback intermediate, AAPLRenderer.m:143-170; not
+                           with half_scale).  The hunt then probes with THAT launch: the RGBA16F kernel's 84 %-written stream lands
+                           in the slow or the fast regime by the same lottery (0.70 against 0.77) (ABI 502) */
+  int32_t reserved;
 } bt709hip_ring_options;
 int bt709hip_ring_create(bt709hip_decoder *dec, int width, int height, int frames, int half_scale, int tries, bt709hip_ring **out);
 /* the same with an explicit budget (bt709hip_ring_create = options NULL) */

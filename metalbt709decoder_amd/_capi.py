@@ -24,7 +24,7 @@ class Surface(C.Structure):  # bt709hip_surface
                 ("format", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 501  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
+ABI_VERSION = 502  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
 
 # bt709hip_format
 FORMAT_BGRA8_SRGB = 0
@@ -55,7 +55,7 @@ class RingPlacement(C.Structure):  # bt709hip_ring_placement
 
 
 class RingOptions(C.Structure):  # bt709hip_ring_options
-    _fields_ = [("max_bytes", C.c_uint64), ("max_ms", C.c_uint32), ("frugal", C.c_int32)]
+    _fields_ = [("max_bytes", C.c_uint64), ("max_ms", C.c_uint32), ("frugal", C.c_int32), ("format", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LaunchInfo(C.Structure):  # bt709hip_launch_info

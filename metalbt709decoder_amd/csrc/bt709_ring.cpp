@@ -20,7 +20,7 @@
 struct bt709hip_ring {
   bt709hip_decoder *dec = nullptr;
   bt709hip_context *ctx = nullptr;
-  int width = 0, height = 0, frames = 0, half = 0, has_alpha = 0;
+  int width = 0, height = 0, frames = 0, half = 0, has_alpha = 0, format = BT709HIP_FORMAT_BGRA8_SRGB;
   size_t y_bytes = 0, c_bytes = 0, in_stride = 0, out_stride = 0;
   void *d_in = nullptr, *d_out = nullptr;
   std::vector<bt709hip_frame> f, a;
@@ -72,9 +72,10 @@ void bind_slabs(bt709hip_ring *r, void *in, void *out) {
     bt709hip_surface &o = r->o[static_cast<size_t>(i)];
     std::memset(&o, 0, sizeof o);
     o.bgra = static_cast<uint8_t *>(out) + static_cast<size_t>(i) * r->out_stride;
-    o.stride = static_cast<size_t>(ow) * 4;
+    o.stride = static_cast<size_t>(ow) * (r->format == BT709HIP_FORMAT_RGBA16F ? 8 : 4);
     o.width = ow;
     o.height = oh;
+    o.format = r->format;
   }
 }
 
@@ -175,7 +176,11 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   if (dec == nullptr || width <= 0 || height <= 0 || frames <= 0 || frames > 65535 || tries < 0) return BT709HIP_ERR_INVALID_ARG;
   if ((width & 1) || (height & 1)) return BT709HIP_ERR_ODD_DIMENSIONS;
   if (half_scale && ((width & 3) || (height & 3))) return BT709HIP_ERR_ODD_DIMENSIONS;
+  const int format = options != nullptr ? options->format : BT709HIP_FORMAT_BGRA8_SRGB;
+  if (format != BT709HIP_FORMAT_BGRA8_SRGB && format != BT709HIP_FORMAT_RGBA16F) return BT709HIP_ERR_INVALID_ARG;
+  if (format == BT709HIP_FORMAT_RGBA16F && half_scale) return BT709HIP_ERR_UNSUPPORTED;  // the fused 2:1 kernel writes BGRA8
   if (int rc = bt709hip_decoder_setup(dec)) return rc;
+  if (int rc = bt709hip_decoder_prepare_format(dec, format)) return rc;  // the RGBA16F threshold table, before any probe
   bt709hip_context *ctx = bt709hip_decoder_context(dec);
   if (ctx == nullptr) return BT709HIP_ERR_NOT_SETUP;
   bt709hip_ring *r = new (std::nothrow) bt709hip_ring();
@@ -183,14 +188,15 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   const double t_start = now_s();
   r->dec = dec;
   r->ctx = ctx;
-  r->width = width, r->height = height, r->frames = frames, r->half = half_scale ? 1 : 0;
+  r->width = width, r->height = height, r->frames = frames, r->half = half_scale ? 1 : 0, r->format = format;
+  const size_t out_px_bytes = format == BT709HIP_FORMAT_RGBA16F ? 8 : 4;
   r->has_alpha = bt709hip_decoder_has_alpha(dec) > 0;
   r->y_bytes = static_cast<size_t>(width) * height;
   r->c_bytes = static_cast<size_t>(width) * (height / 2);
   const int ow = r->half ? width / 2 : width, oh = r->half ? height / 2 : height;
   // frames 256-byte aligned: the fast kernels want 16, a frame boundary on a cache-line boundary costs nothing
   r->in_stride = round_up(r->y_bytes + r->c_bytes + (r->has_alpha ? r->y_bytes : 0), 256);
-  r->out_stride = round_up(static_cast<size_t>(ow) * oh * 4, 256);
+  r->out_stride = round_up(static_cast<size_t>(ow) * oh * out_px_bytes, 256);
   r->f.resize(static_cast<size_t>(frames));
   r->o.resize(static_cast<size_t>(frames));
   if (r->has_alpha) r->a.resize(static_cast<size_t>(frames));
@@ -265,7 +271,7 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   if (tries > 1 && bt709hip_event_create(ctx, &pr.e0) == BT709HIP_OK && bt709hip_event_create(ctx, &pr.e1) == BT709HIP_OK) {
     if (coalesce > 1) (void)bt709hip_decoder_set_option(dec, BT709HIP_OPT_COALESCE, 0);
     const double px_per_launch = static_cast<double>(width) * height * frames;
-    pr.bytes_per_launch = (static_cast<double>(r->y_bytes + r->c_bytes + (r->has_alpha ? r->y_bytes : 0)) + static_cast<double>(ow) * oh * 4) * frames;
+    pr.bytes_per_launch = (static_cast<double>(r->y_bytes + r->c_bytes + (r->has_alpha ? r->y_bytes : 0)) + static_cast<double>(ow) * oh * static_cast<double>(out_px_bytes)) * frames;
     // a probe = ~15 ms of the ring's own launches (3 launches resolved the top candidates to only +-1.5 %)
     const int reps = std::max(3, static_cast<int>((8.0 * 256 * 3840 * 2160 + px_per_launch - 1) / px_per_launch));
     // PRESCAN: every output candidate under input 0, one after the other.  Output slabs come in two regimes (~0.74 / ~0.80+ of

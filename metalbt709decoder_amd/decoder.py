@@ -171,9 +171,12 @@ class FrameRing:
     reference's twin is its per-in-flight-frame CVPixelBuffers + render texture (AAPLRenderer.m:34, 530-862); unified
     memory has no placement to choose."""
 
-    def __init__(self, decoder, size, frames, halfScale=False, tries=0, maxBytes=0, maxMilliseconds=0, frugal=False, _handle=None):
+    def __init__(self, decoder, size, frames, halfScale=False, tries=0, maxBytes=0, maxMilliseconds=0, frugal=False, _handle=None,
+                 pixelFormat=MTLPixelFormatBGRA8Unorm_sRGB):
         """maxBytes / maxMilliseconds / frugal: the hunt's budget (bt709hip_ring_options; 0 = half of the free device memory, no
-        time limit).  _handle: wrap a ring that somebody else owns (FrameRingSet's lanes)."""
+        time limit).  pixelFormat: the ring's render targets, BGRA8 sRGB or MTLPixelFormatRGBA16Float (the hunt then probes with
+        that launch).  _handle: wrap a ring that somebody else owns (FrameRingSet's lanes)."""
+        self.pixelFormat = pixelFormat
         self.decoder, (self.width, self.height), self.frames = decoder, size, int(frames)
         self.ctx = decoder.metalRenderContext
         self.lib = self.ctx.lib
@@ -185,7 +188,7 @@ class FrameRing:
         if not decoder.setupMetal():
             raise RuntimeError("decoder setup failed: %s" % decoder.lastStatus)
         h = C.c_void_p()
-        opt = _capi.RingOptions(int(maxBytes), int(maxMilliseconds), int(bool(frugal)))
+        opt = _capi.RingOptions(int(maxBytes), int(maxMilliseconds), int(bool(frugal)), _FORMAT_OF[pixelFormat], 0)
         _capi.check(self.lib.bt709hip_ring_create_ex(decoder._handle, self.width, self.height, self.frames, int(bool(halfScale)),
                                                      int(tries), C.byref(opt), C.byref(h)), "ring create")
         self.handle = h
@@ -213,7 +216,7 @@ class FrameRing:
         """BGRATexture view of output frame i."""
         o = Surface()
         _capi.check(self.lib.bt709hip_ring_frame(self.handle, i, None, None, C.byref(o)), "ring frame")
-        return BGRATexture(self.ctx, o.width, o.height, o.stride, ptr=o.bgra)
+        return BGRATexture(self.ctx, o.width, o.height, o.stride, ptr=o.bgra, pixelFormat=self.pixelFormat)
 
     def placement(self):
         p = _capi.RingPlacement()
@@ -250,12 +253,12 @@ class FrameRingSet:
     (Renderer/AAPLRenderer.m:874-985).  Host frames: FrameSharder."""
 
     def __init__(self, devices, size, frames, gamma=MetalBT709GammaApple, hasAlphaChannel=False, halfScale=False, tries=0, maxBytes=0,
-                 maxMilliseconds=0, frugal=False):
+                 maxMilliseconds=0, frugal=False, pixelFormat=MTLPixelFormatBGRA8Unorm_sRGB):
         self.lib = _capi.load()
         self.width, self.height = size
         self.frames = int(frames)
         arr = (C.c_int * len(devices))(*devices)
-        opt = _capi.RingOptions(int(maxBytes), int(maxMilliseconds), int(bool(frugal)))
+        opt = _capi.RingOptions(int(maxBytes), int(maxMilliseconds), int(bool(frugal)), _FORMAT_OF[pixelFormat], 0)
         h = C.c_void_p()
         self.lastStatus = self.lib.bt709hip_ringset_create(arr, len(devices), int(gamma), int(bool(hasAlphaChannel)), self.width,
                                                            self.height, self.frames, int(bool(halfScale)), int(tries), C.byref(opt),
@@ -273,7 +276,8 @@ class FrameRingSet:
             dec.hasAlphaChannel = bool(hasAlphaChannel)
             dec.gamma = self.lib.bt709hip_decoder_get_gamma(dec._handle)
             dec._borrowed = ctx._borrowed = True
-            ring = FrameRing(dec, size, frames, halfScale=halfScale, _handle=self.lib.bt709hip_ringset_lane_ring(self.handle, lane))
+            ring = FrameRing(dec, size, frames, halfScale=halfScale, _handle=self.lib.bt709hip_ringset_lane_ring(self.handle, lane),
+                             pixelFormat=pixelFormat)
             self.lanes.append(ring)
 
     def decode(self, first=0, count=None, waitUntilCompleted=False):

@@ -325,6 +325,22 @@ static void test_ring_hunts() {
   OK(bt709hip_decoder_get_option(dec, BT709HIP_OPT_COALESCE, &v));
   CHECK(p.probes >= 1 && p.first_GBps > 1000.0f && v == 32);
   OK(bt709hip_ring_destroy(ring));
+  OK(bt709hip_decoder_set_option(dec, BT709HIP_OPT_COALESCE, 0));
+  // RGBA16Float render targets (options.format): 8-byte texels in the descriptors, the hunt on that launch; refused with
+  // half_scale and for an unknown format, nothing allocated by the refusals
+  bt709hip_ring_options f16 = {200ull << 30, 0, 0, BT709HIP_FORMAT_RGBA16F, 0};
+  fake_hip_set_rate_by_allocation_order(rates, static_cast<int>(sizeof rates / sizeof rates[0]));
+  OK(bt709hip_ring_create_ex(dec, w, h, n, 0, 3, &f16, &ring));
+  bt709hip_surface o;
+  OK(bt709hip_ring_frame(ring, 5, nullptr, nullptr, &o));
+  OK(bt709hip_ring_placement_info(ring, &p));
+  CHECK(o.format == BT709HIP_FORMAT_RGBA16F && o.stride == static_cast<size_t>(w) * 8 && p.chosen_out == 2 && p.probes >= 3);
+  OK(bt709hip_ring_decode(ring, 8, 16, nullptr, 1));
+  OK(bt709hip_ring_destroy(ring));
+  ring = nullptr;
+  CHECK(bt709hip_ring_create_ex(dec, w, h, n, 1, 3, &f16, &ring) == BT709HIP_ERR_UNSUPPORTED && ring == nullptr);
+  bt709hip_ring_options bad = {0, 0, 0, 7, 0};
+  CHECK(bt709hip_ring_create_ex(dec, w, h, n, 0, 3, &bad, &ring) == BT709HIP_ERR_INVALID_ARG && ring == nullptr);
   OK(bt709hip_decoder_destroy(dec));
   OK(bt709hip_context_destroy(ctx));
 }

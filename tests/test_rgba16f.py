@@ -358,3 +358,31 @@ def test_gpu_render_scaled_batch(gh, oracle, fmt):
     other = ctx.makeBGRATexture((w + 2, h), pixelFormat=fmt)
     assert not scale.renderScaledBatch(ctx, views[:2], None, [inters[0], other], True) and scale.lastStatus == _capi.ERR_SIZE_MISMATCH
     assert not scale.renderScaledBatch(ctx, views[:2], None, inters[:1], True) and scale.lastStatus == _capi.ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_gpu_rgba16f_frame_ring(gh, oracle):
+    """A frame ring with RGBA16Float render targets (bt709hip_ring_options.format): descriptors carry the format and the 8-byte
+    texels, the placement hunt runs with the RGBA16F launch as its probe (the ring is large enough to be hunted), every frame of
+    one launch equals the oracle; the half-scale combination is refused."""
+    import ctypes as C
+    ctx = gh.context()
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    w, h, n = 1920, 1080, 32  # 32 x (3.1 + 16.6) MB = 630 MB: above the hunt's 256 MB floor
+    ring = mb.FrameRing(dec, (w, h), n, tries=2, pixelFormat=mb.MTLPixelFormatRGBA16Float)
+    frames = [_frame(w, h, 1200 + i) for i in range(3)]
+    for i in range(n):
+        ring.pixelBuffer(i).upload_planes(*frames[i % 3])
+    o = _capi.Surface()
+    _capi.check(ctx.lib.bt709hip_ring_frame(ring.handle, 1, None, None, C.byref(o)))
+    assert o.format == _capi.FORMAT_RGBA16F and o.stride == w * 8 and (o.width, o.height) == (w, h)
+    pl = ring.placement()
+    assert pl.tries == 2 and pl.out_candidates >= 2 and pl.chosen_GBps > 100.0 and pl.probes >= 2
+    assert ring.decode(0, n, waitUntilCompleted=True), dec.lastStatus
+    assert b"rgba16f" in ctx.lib.bt709hip_last_kernel_name()
+    want = [oracle.decode_nv12_rgba16f(0, y, c).view(np.uint16) for y, c in frames]
+    for i in (0, 1, 2, 7, 8, 16, n - 1):
+        assert np.array_equal(ctx.getBGRATexturePixels(ring.texture(i)).view(np.uint16), want[i % 3]), i
+    ring.release()
+    with pytest.raises(RuntimeError):
+        mb.FrameRing(dec, (64, 32), 4, halfScale=True, pixelFormat=mb.MTLPixelFormatRGBA16Float)

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=1)
     ap.add_argument("--xcd-bands", type=int, default=1, help="decoder option BT709HIP_OPT_XCD_BANDS")
     ap.add_argument("--gamma", default="apple", choices=["apple", "srgb", "linear", "itu709"])
+    ap.add_argument("--placement-tries", type=int, default=0, help="--path rgba16f: candidates per slab of the frame ring's hunt (0 = the product's default)")
     ap.add_argument("--library", default=None, help="a variant build of libbt709hip.so (python -m metalbt709decoder_amd.build --variant)")
     args = ap.parse_args()
     if args.library:
@@ -62,10 +63,23 @@ def main():
     out_px = 8 if path == "rgba16f" else 4
     in_pitch = (W * H * (in_px or 0) if in_px else W * H * 3 // 2 + 255) // 256 * 256
     out_pitch = (OW * OH * out_px + 255) // 256 * 256
-    slab_in, slab_out = DeviceBuffer(ctx, ring * in_pitch), DeviceBuffer(ctx, ring * out_pitch)
     frames, surfs, inters = (_capi.Frame * ring)(), (_capi.Surface * ring)(), (_capi.Surface * ring)()
     rng = np.random.default_rng(0x709)
-    for i in range(ring):
+    frame_ring = None
+    if path == "rgba16f":
+        # the product's own placement: a frame ring with RGBA16Float targets, hunted with the RGBA16F launch as the probe
+        # (bt709hip_ring_options.format; rounds 2-5a took two single-slab allocations and this pattern's 0.70 / 0.77 lottery)
+        frame_ring = mb.FrameRing(dec, (W, H), ring, tries=args.placement_tries, pixelFormat=mb.MTLPixelFormatRGBA16Float)
+        for i in range(ring):
+            y, c = gh.random_nv12(W, H, seed=0x709 + i)
+            frame_ring.pixelBuffer(i).upload_planes(y, c)
+            f, o = _capi.Frame(), _capi.Surface()
+            _capi.check(lib.bt709hip_ring_frame(frame_ring.handle, i, C.byref(f), None, C.byref(o)), "ring frame")
+            frames[i], surfs[i] = f, o
+        slab_in = slab_out = None
+    else:
+        slab_in, slab_out = DeviceBuffer(ctx, ring * in_pitch), DeviceBuffer(ctx, ring * out_pitch)
+    for i in range(ring if frame_ring is None else 0):
         base = slab_in.ptr + i * in_pitch
         if in_px:  # an intermediate as pass 1 leaves it (random bytes / random halves in [0, 1])
             if in_px == 4:
