@@ -85,7 +85,9 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
         ndev = mb.load_library().bt709hip_device_count()
         devices = list(range(ndev)) * 2
         n, half = int(rng.integers(1, 9)), bool(rng.integers(0, 3) == 0)
-        rs = mb.FrameRingSet(devices, (w, h), n, gamma=g, hasAlphaChannel=a is not None, halfScale=half, tries=1)
+        f16 = not half and bool(rng.integers(0, 3) == 0)  # RGBA16Float render targets (bt709hip_ring_options.format)
+        rs = mb.FrameRingSet(devices, (w, h), n, gamma=g, hasAlphaChannel=a is not None, halfScale=half, tries=1,
+                             pixelFormat=mb.MTLPixelFormatRGBA16Float if f16 else mb.MTLPixelFormatBGRA8Unorm_sRGB)
         assert rs.handle, rs.lastStatus
         frs = {}
         for lane, ring in enumerate(rs.lanes):
@@ -98,7 +100,9 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 300):
         assert rs.decode(first, count) and rs.synchronize()
         got = np.concatenate([ring.ctx.getBGRATexturePixels(ring.texture(i)).view(np.uint8).reshape(-1)
                               for ring in rs.lanes for i in range(first, first + count)])
-        want = np.concatenate([(oracle.decode_nv12_half(g, *frs[lane, i], alpha=a) if half else oracle.decode_nv12(g, *frs[lane, i], alpha=a)).reshape(-1)
+        want = np.concatenate([(oracle.decode_nv12_half(g, *frs[lane, i], alpha=a) if half else
+                                oracle.decode_nv12_rgba16f(g, *frs[lane, i], alpha=a).view(np.uint8) if f16 else
+                                oracle.decode_nv12(g, *frs[lane, i], alpha=a).view(np.uint8)).reshape(-1)
                                for lane in range(len(devices)) for i in range(first, first + count)])
         rs.release()
     elif kind == 9:  # round 5: batched RGBA16Float launches (small frames: the small shape; many frames: the large one)
