@@ -122,6 +122,29 @@ def test_ring_set_alpha_half_scale(gh, oracle):
     rs.release()
 
 
+def test_ring_set_rgba16f_targets(gh, oracle):
+    """A ring set whose lanes render into RGBA16Float targets (bt709hip_ring_options.format through bt709hip_ringset_create): an
+    alpha decoder on every visible device, every texel of every lane against the oracle (linear-light halves, alpha included)."""
+    devices = lane_sets()[0]
+    w, h, n = 192, 24, 4
+    rs = mb.FrameRingSet(devices, (w, h), n, hasAlphaChannel=True, tries=1, pixelFormat=mb.MTLPixelFormatRGBA16Float)
+    assert rs.handle, rs.lastStatus
+    for lane, ring in enumerate(rs.lanes):
+        fr = [gh.random_nv12(w, h, seed=400 + 10 * lane + i) for i in range(n)]
+        al = [np.random.default_rng(450 + 10 * lane + i).integers(0, 256, (h, w), dtype=np.uint8) for i in range(n)]
+        for i in range(n):
+            ring.pixelBuffer(i).upload_planes(*fr[i])
+            ab = ring.alphaPixelBuffer(i)
+            ring.ctx._upload(ab.y_ptr, ab.y_stride, al[i], None)
+        assert rs.decode(waitUntilCompleted=True)
+        for i in range(n):
+            tex = ring.texture(i)
+            assert tex.bytesPerPixel == 8 and tex.stride == w * 8
+            got = ring.ctx.getBGRATexturePixels(tex).view(np.uint16)
+            assert np.array_equal(got, oracle.decode_nv12_rgba16f(1, fr[i][0], fr[i][1], alpha=al[i]).view(np.uint16)), (lane, i)
+    rs.release()
+
+
 @pytest.mark.parametrize("double", [False, True])
 def test_frame_sharder_on_every_visible_device(gh, oracle, double):
     """bt709hip_shard_*: a lane (context + decoder + in-flight pool) on every visible device -- bind(ctx) / hipSetDevice across
