@@ -811,3 +811,33 @@ def test_profile_summary_cuts_a_kernel_trace_to_the_sentinel_bracketed_regions(t
         csv.writer(f).writerows([rows[0], rows[1], rows[2]])
     assert pmc_summary.timed_dispatches(str(plain), "decode_nv12") is None
     assert pmc_summary.timed_dispatch_ids(list(csv.DictReader(open(plain)))) is None
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """Every struct of include/bt709hip.h that crosses the C ABI by value or by pointer has a ctypes twin in _capi.py: a C program
+    compiled against the header prints sizeof and the offset of every field, and they must equal ctypes' own layout -- a field
+    added to the header alone (or to the bindings alone) fails here, before it mis-calls the library."""
+    pairs = {"bt709hip_frame": _capi.Frame, "bt709hip_surface": _capi.Surface, "bt709hip_ring_placement": _capi.RingPlacement,
+             "bt709hip_ring_options": _capi.RingOptions, "bt709hip_launch_info": _capi.LaunchInfo, "bt709hip_device_info": _capi.DeviceInfo}
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "bt709hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, field, cname, field))
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr  # a field the header does not have is a compile error
+    got = dict(line.rsplit(" ", 1) for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got["%s size" % cname]) == C.sizeof(cls), cname
+        for field, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, field)]) == getattr(cls, field).offset, (cname, field)
+    # and the header has no struct the bindings do not know (opaque handles aside)
+    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    named = set(re.findall(r"^\} (bt709hip_\w+);", hdr, flags=re.M)) - {"bt709hip_status", "bt709hip_gamma", "bt709hip_matrix_tag",
+                                                                        "bt709hip_transfer_tag", "bt709hip_format",
+                                                                        "bt709hip_context_option", "bt709hip_decoder_option"}
+    assert named == set(pairs), named ^ set(pairs)
