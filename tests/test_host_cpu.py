@@ -841,3 +841,17 @@ def test_ctypes_structs_match_the_header(tmp_path):
                                                                         "bt709hip_transfer_tag", "bt709hip_format",
                                                                         "bt709hip_context_option", "bt709hip_decoder_option"}
     assert named == set(pairs), named ^ set(pairs)
+
+
+def test_ctypes_constants_match_the_header():
+    """Status codes, render-target formats and option ids of _capi.py against the enumerators of include/bt709hip.h, by name:
+    BT709HIP_<NAME> = value  <->  _capi.<NAME> (BT709HIP_OK -> OK); every enumerator of those enums has a twin."""
+    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    seen = 0
+    for enum in ("bt709hip_status", "bt709hip_format", "bt709hip_context_option", "bt709hip_decoder_option"):
+        body = re.search(r"typedef enum \{([^}]*)\} %s;" % enum, hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        for name, value in re.findall(r"BT709HIP_(\w+)\s*=\s*(-?\d+)", body):
+            assert getattr(_capi, name) == int(value), (enum, name)
+            seen += 1
+    assert seen >= 12 + 2 + 5 + 7
