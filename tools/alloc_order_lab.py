@@ -47,6 +47,10 @@ elif MODE == "spaced_freed":
     d_in, spacer = malloc(in_bytes), malloc(3 << 30)
     d_out = malloc(out_bytes)
     lib.bt709hip_free(h, spacer)
+elif MODE.startswith("far"):  # far32 / far96 / far160: a spacer of that many GB between the two, freed afterwards
+    d_in, spacer = malloc(in_bytes), malloc(int(MODE[3:]) << 30)
+    d_out = malloc(out_bytes)
+    lib.bt709hip_free(h, spacer)
 else:
     raise SystemExit("unknown mode")
 frames, surfs = (Frame * RING)(), (Surface * RING)()
