@@ -500,7 +500,7 @@ class InFlightFramePool {
 class FrameRing {
  public:
   // options: the hunt's budget and the ring's render-target format (bt709hip_ring_options: max_bytes, max_ms, frugal, format --
-  // BT709HIP_FORMAT_RGBA16F makes it a ring of RGBA16Float targets; nullptr = BGRA8, four times the ring, no time limit)
+  // BT709HIP_FORMAT_RGBA16F makes it a ring of RGBA16Float targets; nullptr = BGRA8, a hunt within twice the ring, no time limit)
   FrameRing(MetalBT709Decoder &decoder, int width, int height, int frames, bool halfScale = false, int tries = 0,
             const bt709hip_ring_options *options = nullptr)
       : decoder_(decoder) {

@@ -160,6 +160,19 @@ __device__ __forceinline__ void linearise6(const RescaleLookup &r, const float *
     lin[i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z), __fadd_rn(x[i], -__uint_as_float(e[i].x)));
 }
 
+// one pixel (decode_nv12_scaled's wave-decodes-once form); x[3] is padding
+__device__ __forceinline__ void linearise3(const RescaleLookup &r, const float *x, float *lin) {
+  uint32_t t[4];
+  u32x4 e[3];
+  magic_index4(x, t, r.magic);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e[i] = *reinterpret_cast<LdsQuadPtr>((t[i] << r.dec_shift) + r.dec_off);
+  asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]));  // one wait
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    lin[i] = __builtin_amdgcn_fmed3f(__uint_as_float(e[i].y), __uint_as_float(e[i].z), __fadd_rn(x[i], -__uint_as_float(e[i].x)));
+}
+
 // Alpha decoders only.  Pass 2 reads the alpha channel of the 8-bit intermediate as a plain unorm
 // (AAPLShaders.metal:411-438 writes it, the sampler of MetalScaleRenderContext.m:55-105 filters it): each tap is
 // byteNorm(decoded alpha byte), the result round(255 v).  No tables: an alpha decoder runs the sRGB mode, whose
@@ -552,7 +565,7 @@ decode_nv12_half_rep(const DecodeParams p) {
 //   TAPS_BYTES any layout: byte loads.
 // 4-byte coalesced stores.
 // ---------------------------------------------------------------------------
-enum : int { TAPS_BYTES = 0, TAPS_PAIRS = 1, TAPS_WIDE = 2, TAPS_SHARED = 3 };
+enum : int { TAPS_BYTES = 0, TAPS_PAIRS = 1, TAPS_WIDE = 2, TAPS_SHARED = 3, TAPS_ONCE = 4 };
 
 // Vertical taps of a strip of at most 64 output rows starting at oy0: lane i holds row oy0 + i (sy = (oy + 0.5f) *
 // scale_y - 0.5f, y0 = floor(sy), fy = sy - y0).  gfx950 has no scalar float unit, so one evaluation costs 8 VALU
@@ -588,13 +601,22 @@ __device__ __forceinline__ StripTaps strip_taps(uint32_t oy0, float scale_y) {
 //     ds_bpermute_b32 when (and only when) the row is decoded.  Pays when most fetched rows are not
 //     decoded, i.e. when enlarging; the launcher picks it for scale_y < 1.  All 64 lanes must call;
 //     `live` masks the store.
+//   TAPS_ONCE (CbCr plane 2-byte aligned, 63 * scale_x + 2 <= 63: enlarging): the WAVE decodes a source row ONCE.
+//     Neighbouring output columns of an enlargement sit on the same source columns (at 2x every source pixel is a tap
+//     of four lanes), and with per-lane taps every one of them runs the matrix and the three lookups again.  Here lane
+//     l fetches and decodes source column wx0 + l (wx0 = lane 0's left tap; the 64 columns cover every tap of the
+//     wave) -- one byte + one CbCr pair loaded, one pixel_rgb, three lookups instead of six -- and a lane takes the
+//     linear values of its two taps out of its neighbours' registers with six ds_bpermute_b32 (no LDS bank conflicts,
+//     no table traffic).  Same floats per source pixel whoever computes them: bit-identical output.  All 64 lanes must
+//     call; `live` masks the store.
 //   UNIFORM_ENCODE: the encode side goes through the uniform table (staged with sum_log2 = 0).
 template <int TAPS, bool HAS_ALPHA, bool UNIFORM_ENCODE>
 __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const RescaleLookup &r,
                                              const FramePlanes &f, uint32_t ox_raw, uint32_t oy0, uint32_t oy1, const StripTaps &vt) {
-  // TAPS_SHARED: every lane of the wave stays alive; one past the row's end works on the last column again and does not store
+  // TAPS_SHARED / TAPS_ONCE: every lane of the wave stays alive; one past the row's end works on the last column again and does not store
+  constexpr bool BY_WAVE = TAPS == TAPS_SHARED || TAPS == TAPS_ONCE;
   const bool live = ox_raw < p.out_width;
-  const uint32_t ox = TAPS == TAPS_SHARED ? min(ox_raw, p.out_width - 1u) : ox_raw;
+  const uint32_t ox = BY_WAVE ? min(ox_raw, p.out_width - 1u) : ox_raw;
 
   const float sx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ox), 0.5f), p.scale_x), -0.5f);
   const float x0f = __builtin_floorf(sx);
@@ -614,6 +636,11 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
   const uint32_t wybase = __builtin_amdgcn_readfirstlane(ybase), wcbase = __builtin_amdgcn_readfirstlane(cbase);
   const uint32_t yoff = min(wybase + 4u * lane, p.width - 4u), coff = min(wcbase + 4u * lane, p.width - 4u);
   const uint32_t ysrc = ybase - wybase, csrc = cbase - wcbase;
+  // TAPS_ONCE: this lane's own source column (the wave's columns start at lane 0's left tap) and the ds_bpermute
+  // addresses (4 * lane) of the lanes that hold its two taps
+  const uint32_t wx0 = __builtin_amdgcn_readfirstlane(xs[0]);
+  const uint32_t own_x = min(wx0 + lane, p.width - 1u), own_c = 2u * (own_x >> 1);
+  const uint32_t tap_lane[2] = {4u * (xs[0] - wx0), 4u * (xs[1] - wx0)};
 
   // vertical taps of a row: the same for every lane, taken from the strip's lanes (strip_taps)
   struct RowTaps {
@@ -646,7 +673,11 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
     Fetched1 v = {};
     const int yo = srow * static_cast<int>(p.y_stride), co = (srow >> 1) * static_cast<int>(p.cbcr_stride);
     const int ao = HAS_ALPHA ? srow * static_cast<int>(p.alpha_stride) : 0;
-    if (TAPS == TAPS_SHARED) {
+    if (TAPS == TAPS_ONCE) {
+      v.y[0] = __builtin_amdgcn_raw_buffer_load_b8(ry, own_x, yo, 0);
+      v.c[0] = __builtin_amdgcn_raw_buffer_load_b16(rc, own_c, co, 0);
+      if (HAS_ALPHA) v.a[0] = __builtin_amdgcn_raw_buffer_load_b8(ra, own_x, ao, 0);
+    } else if (TAPS == TAPS_SHARED) {
       v.y[0] = __builtin_amdgcn_raw_buffer_load_b32(ry, yoff, yo, 0);
       v.c[0] = __builtin_amdgcn_raw_buffer_load_b32(rc, coff, co, 0);
       if (HAS_ALPHA) v.a[0] = __builtin_amdgcn_raw_buffer_load_b32(ra, yoff, ao, 0);
@@ -720,6 +751,27 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
   int chroma_row = -1;
   Chroma ch0 = {}, ch1 = {};
   auto decode_row = [&](const Fetched1 &raw, int srow) {
+    if (TAPS == TAPS_ONCE) {  // this lane's OWN source pixel, then the two taps from the lanes that hold them
+      if ((srow >> 1) != chroma_row) {
+        ch0 = chroma_terms(byte_of(raw.c[0], 0), byte_of(raw.c[0], 1));
+        chroma_row = srow >> 1;
+      }
+      float x[4], own[4];
+      pixel_rgb(byte_of(raw.y[0], 0), ch0, x[0], x[1], x[2]);
+      x[3] = 0.0f;
+      linearise3(r, x, own);
+      if (HAS_ALPHA) own[3] = alpha_norm_arith(byte_of(raw.a[0], 0));
+      RowLin rl;
+      rl.a[0] = rl.a[1] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          rl.v[3 * t + k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(static_cast<int>(tap_lane[t]), __builtin_bit_cast(int, own[k])));
+        if (HAS_ALPHA) rl.a[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(static_cast<int>(tap_lane[t]), __builtin_bit_cast(int, own[3])));
+      }
+      return rl;
+    }
     const TapBytes fr = tap_bytes(raw);
     if ((srow >> 1) != chroma_row) {
       ch0 = chroma_terms(byte_of(fr.cc, 0), byte_of(fr.cc, 1));
@@ -745,11 +797,11 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
   // flight at a skipped decode would leave its destination registers pending, and hipcc then drains vmcnt
   // (stores included) wherever it reuses one of them.  No instruction is emitted, only the s_waitcnt.
   auto landed = [&](const Fetched1 &v) {
-    if (TAPS == TAPS_SHARED) asm volatile("" ::"v"(v.y[0]), "v"(v.c[0]));
+    if (BY_WAVE) asm volatile("" ::"v"(v.y[0]), "v"(v.c[0]));
     else if (TAPS == TAPS_BYTES) asm volatile("" ::"v"(v.y[0]), "v"(v.y[1]), "v"(v.c[0]), "v"(v.c[1]), "v"(v.c[2]), "v"(v.c[3]));
     else asm volatile("" ::"v"(v.y[0]), "v"(v.y[1]), "v"(v.c[0]), "v"(v.c[1]));
     if (HAS_ALPHA) {
-      if (TAPS == TAPS_SHARED) asm volatile("" ::"v"(v.a[0]));
+      if (BY_WAVE) asm volatile("" ::"v"(v.a[0]));
       else asm volatile("" ::"v"(v.a[0]), "v"(v.a[1]));
     }
   };
@@ -784,7 +836,7 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
       av = __fadd_rn(av, __fmul_rn(w[3], bot.a[1]));
       aw = alpha_word_of(av);
     }
-    if (TAPS != TAPS_SHARED || live)
+    if (!BY_WAVE || live)
       __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, oy * p.out_stride, 0);
   };
 
@@ -863,7 +915,7 @@ decode_nv12_scaled(const DecodeParams p) {
       const uint32_t oy0 = (sg * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y)) * p.scaled_rows;
       if (oy0 >= p.out_height) continue;  // the whole wave
       const StripTaps vt = strip_taps(oy0, p.scale_y);  // before any lane is masked off
-      if (TAPS == TAPS_SHARED || ox < p.out_width)
+      if (TAPS == TAPS_SHARED || TAPS == TAPS_ONCE || ox < p.out_width)
         scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height), vt);
     }
     return;
@@ -873,7 +925,7 @@ decode_nv12_scaled(const DecodeParams p) {
   const uint32_t oy0 = (blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y)) * p.scaled_rows;
   if (oy0 >= p.out_height) return;  // the whole wave
   const StripTaps vt = strip_taps(oy0, p.scale_y);  // before any lane leaves
-  if (TAPS != TAPS_SHARED && ox >= p.out_width) return;  // TAPS_SHARED: the wave fetches together
+  if (TAPS != TAPS_SHARED && TAPS != TAPS_ONCE && ox >= p.out_width) return;  // TAPS_SHARED / TAPS_ONCE: the wave works together
   scaled_strip<TAPS, HAS_ALPHA, kScaledUniform>(p, r, f, ox, oy0, min(oy0 + p.scaled_rows, p.out_height), vt);
 }
 
@@ -1147,6 +1199,15 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
 #define BT709_SCALED_SHARED_BELOW 1.0f
 #endif
   if (taps == TAPS_WIDE && p.scale_y < BT709_SCALED_SHARED_BELOW && p.scale_x * 64.0f + 12.0f <= 252.0f) taps = TAPS_SHARED;
+  // Enlarging horizontally: the wave decodes each source pixel once (TAPS_ONCE).  A wave's taps must lie within 64
+  // source columns of lane 0's left tap: x0(lane 63) - x0(lane 0) <= floor(63 scale_x) + 1, plus one for the right tap.
+#ifndef BT709_SCALED_ONCE_BELOW
+#define BT709_SCALED_ONCE_BELOW 0.95f  // 63 * 0.95 + 2 = 61.85: within the 64 lanes with margin for the rounding of sx
+#endif
+#ifndef BT709_SCALED_ONCE_PERSISTENT
+#define BT709_SCALED_ONCE_PERSISTENT 0
+#endif
+  if (align >= 2 && p.scale_x <= BT709_SCALED_ONCE_BELOW && p.scale_y < BT709_SCALED_SHARED_BELOW) taps = TAPS_ONCE;
 
   // rows per strip: as many as still leave ~8 workgroups per CU (table staging is per workgroup)
 #ifndef BT709_SCALED_WG_PER_CU
@@ -1165,12 +1226,13 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
   const uint32_t strip_groups = (strips + kScaledStrips - 1) / kScaledStrips;
   const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << kScaledDecCopiesLog2) + ((kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes) << kScaledEncCopiesLog2);
   const dim3 block(kBlockThreads, kScaledStrips);
-  const bool persistent = taps != TAPS_SHARED;
+  const bool persistent = taps == TAPS_ONCE ? BT709_SCALED_ONCE_PERSISTENT != 0 : taps != TAPS_SHARED;
   dim3 grid(cols, strip_groups, static_cast<uint32_t>(frames));
   const void *fn = nullptr;
 #define BT709_PICK_SCALED(T, P)                                                                                        \
   fn = has_alpha ? reinterpret_cast<const void *>(&decode_nv12_scaled<T, true, P>) : reinterpret_cast<const void *>(&decode_nv12_scaled<T, false, P>)
-  if (taps == TAPS_SHARED) BT709_PICK_SCALED(TAPS_SHARED, false);
+  if (taps == TAPS_ONCE) BT709_PICK_SCALED(TAPS_ONCE, BT709_SCALED_ONCE_PERSISTENT != 0);
+  else if (taps == TAPS_SHARED) BT709_PICK_SCALED(TAPS_SHARED, false);
   else if (taps == TAPS_WIDE) BT709_PICK_SCALED(TAPS_WIDE, true);
   else if (taps == TAPS_PAIRS) BT709_PICK_SCALED(TAPS_PAIRS, true);
   else BT709_PICK_SCALED(TAPS_BYTES, true);
@@ -1233,6 +1295,8 @@ hipError_t prepare_rescale_kernels() {
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_WIDE, true, true>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_SHARED, false, false>),
       reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_SHARED, true, false>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_ONCE, false, BT709_SCALED_ONCE_PERSISTENT != 0>),
+      reinterpret_cast<const void *>(&decode_nv12_scaled<TAPS_ONCE, true, BT709_SCALED_ONCE_PERSISTENT != 0>),
       reinterpret_cast<const void *>(&render_scaled<true>),
       reinterpret_cast<const void *>(&render_scaled<false>),
   };

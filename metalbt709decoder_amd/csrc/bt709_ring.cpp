@@ -209,19 +209,16 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   tries = std::min(tries, kMaxTries);
   if (in_bytes + out_bytes < kHuntMinBytes) tries = 1;
 
-  // THE BUDGET.  Default: four rings' worth, at most half of what is free now (a second process on the device, or this one's
-  // next ring, still finds room while the hunt runs); frugal: the incumbent pair + one candidate pair.  A budget that cannot hold the ring and one more
-  // output slab leaves nothing to compare.
+  // THE BUDGET.  Default (round 6): FRUGAL -- the incumbent pair + one candidate pair = twice the ring -- because that is all the
+  // hunt needs: free + allocate hands out other physical pages, so holding every candidate buys nothing (round 5,
+  // profiles/r05_hunt_budget.txt: the 11.7 GB 4K ring hunted within 23 / 32 / 64 / 148 GB lands at 0.806-0.814 / 0.802-0.811 /
+  // 0.811-0.812 / 0.811 of the roofline, in 0.9 / 1.2 / 1.9 / 3.7 s; round 6's five fresh processes on the default:
+  // profiles/r06_hunt_default.txt).  A caller who wants the wide hunt back names its budget in options->max_bytes.  A budget that
+  // cannot hold the ring and one more output slab leaves nothing to compare.
+  const bool frugal = options == nullptr || options->frugal || options->max_bytes == 0;
   Ledger led{ctx};
   {
-    size_t free_b = 0;
-    if (bt709hip_mem_info(ctx, &free_b, nullptr) != BT709HIP_OK) free_b = 0;
-    // default: four times the ring, never more than half of what is free (round 5, profiles/r05_hunt_budget.txt: the 11.7 GB 4K
-    // ring hunted within 23 / 32 / 64 GB lands at 0.806-0.814 / 0.802-0.811 / 0.811-0.812 of the roofline, within 148 GB -- round
-    // 4's behaviour -- at 0.811: free + allocate hands out other physical pages, holding every candidate buys nothing)
-    size_t budget = options != nullptr && options->max_bytes != 0 ? static_cast<size_t>(options->max_bytes)
-                                                                   : std::min(free_b / 2, 4 * (in_bytes + out_bytes));
-    if (options != nullptr && options->frugal) budget = 2 * (in_bytes + out_bytes);
+    size_t budget = frugal ? 2 * (in_bytes + out_bytes) : static_cast<size_t>(options->max_bytes);
     if (tries > 1 && budget < in_bytes + 2 * out_bytes) {
       tries = 1;
       pl.stopped_by = 1;
@@ -237,7 +234,6 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   // rate by ~1 % -- but never more than a quarter of the budget, and always leaving room for two outputs.
   std::vector<Slab> ins, outs;
   {
-    const bool frugal = options != nullptr && options->frugal;
     int n_in = frugal ? std::min(tries, 2) : tries;
     while (n_in > 1 && ((!frugal && static_cast<size_t>(n_in) * in_bytes > led.budget / 4) || static_cast<size_t>(n_in) * in_bytes + 2 * out_bytes > led.budget)) --n_in;
     for (int i = 0; i < n_in; ++i) {
@@ -377,16 +373,19 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   pl.chosen_in = bi;
   pl.chosen_out = bo;
   pl.evicted = led.evicted;
-  void *keep_in = ins[static_cast<size_t>(bi)].p, *keep_out = outs[static_cast<size_t>(bo)].p;
+  // After a failed probe bi / bo may still name slab 0 of each kind, and output 0 may have been evicted (freed) by the budget:
+  // only a slab that is still alive is kept (and, on the error path below, freed) -- never a pointer the ledger gave back.
+  void *keep_in = ins[static_cast<size_t>(bi)].alive ? ins[static_cast<size_t>(bi)].p : nullptr;
+  void *keep_out = outs[static_cast<size_t>(bo)].alive ? outs[static_cast<size_t>(bo)].p : nullptr;
   ins[static_cast<size_t>(bi)].alive = false;  // not the hunt's any more
   outs[static_cast<size_t>(bo)].alive = false;
   pl.peak_bytes = led.peak;
   free_everything();
   if (pl.tries > 1) pl.hunt_ms = static_cast<float>((now_s() - t_start) * 1e3);
-  if (pr.rc != BT709HIP_OK) {
-    (void)bt709hip_free(ctx, keep_in);
-    (void)bt709hip_free(ctx, keep_out);
-    const int rc = pr.rc;
+  if (pr.rc != BT709HIP_OK || keep_in == nullptr || keep_out == nullptr) {
+    if (keep_in) (void)bt709hip_free(ctx, keep_in);  // live slabs only: a successful free leaves the probe's HIP error in place
+    if (keep_out) (void)bt709hip_free(ctx, keep_out);
+    const int rc = pr.rc != BT709HIP_OK ? pr.rc : BT709HIP_ERR_HIP;
     delete r;
     return rc;
   }

@@ -173,8 +173,8 @@ class FrameRing:
 
     def __init__(self, decoder, size, frames, halfScale=False, tries=0, maxBytes=0, maxMilliseconds=0, frugal=False, _handle=None,
                  pixelFormat=MTLPixelFormatBGRA8Unorm_sRGB):
-        """maxBytes / maxMilliseconds / frugal: the hunt's budget (bt709hip_ring_options; 0 = half of the free device memory, no
-        time limit).  pixelFormat: the ring's render targets, BGRA8 sRGB or MTLPixelFormatRGBA16Float (the hunt then probes with
+        """maxBytes / maxMilliseconds / frugal: the hunt's budget (bt709hip_ring_options; maxBytes 0 = the default: twice the ring --
+        the incumbent pair + one candidate pair, `frugal` -- which also caps the input candidates at two; no time limit).  pixelFormat: the ring's render targets, BGRA8 sRGB or MTLPixelFormatRGBA16Float (the hunt then probes with
         that launch).  _handle: wrap a ring that somebody else owns (FrameRingSet's lanes)."""
         self.pixelFormat = pixelFormat
         self.decoder, (self.width, self.height), self.frames = decoder, size, int(frames)

@@ -385,7 +385,7 @@ def test_isa_fused_multiply_adds_are_only_the_proven_one(asm):
             assert candidate == candidate_fmas, (kernel, candidate)
             assert not re.search(r"\bv_(log|exp)_f32", body), kernel  # no transcendental left in any decode kernel
             n += 1
-    assert n == 53  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in three shapes, the 1:1 kernel's big-table form)
+    assert n == 55  # every instantiation the launchers can pick (round 5: the RGBA16F kernel in three shapes, the 1:1 kernel's big-table form; round 6: the any-ratio kernel's wave-decodes-once form, with and without alpha)
     # the RGBA16F kernels address LDS absolutely (table at byte 0): the dynamic allocation must be their only LDS
     seen = 0
     for m in re.finditer(r"\.group_segment_fixed_size:\s+(\d+)\s.*?\.name:\s+(\S+)", asm, flags=re.S):
@@ -430,7 +430,7 @@ def test_isa_valu_budget_contract(asm):
         for body in _kernel_bodies(asm, kernel):
             assert "s_setreg" not in body, kernel
             n += 1
-    assert n == 25
+    assert n == 27
     for kernel in ("16encode_bgra_nv12", "23encode_bgra_nv12_blocks"):
         for body in _kernel_bodies(asm, kernel):
             to_zero = len(re.findall(r"s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 0, 2\), 3", body))

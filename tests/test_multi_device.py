@@ -211,12 +211,18 @@ def test_ring_hunt_under_a_budget(gh, oracle):
     assert 0 <= p.chosen_out < p.out_candidates and p.out_prescan_GBps[p.chosen_out] > 100.0
     check(frugal)
     frugal.release()
-    default = mb.FrameRing(dec, (w, h), n, tries=3)  # four times the ring (<= half of the free memory)
+    default = mb.FrameRing(dec, (w, h), n, tries=3)  # round 6: the default IS the frugal hunt (twice the ring)
     p = default.placement()
-    assert abs(p.budget_bytes - 4 * ring_bytes) < (1 << 20) and ring_bytes < p.peak_bytes <= p.budget_bytes
-    assert p.stopped_by in (0, 1) and p.evicted >= 0 and p.out_candidates >= 3
+    assert abs(p.budget_bytes - 2 * ring_bytes) < (1 << 20) and ring_bytes < p.peak_bytes <= p.budget_bytes
+    assert p.in_candidates <= 2 and p.stopped_by == 1 and p.evicted == p.out_candidates - 2 and p.out_candidates >= 3
     check(default)
     default.release()
+    wide = mb.FrameRing(dec, (w, h), n, tries=3, maxBytes=4 * ring_bytes)  # round 5's default, by name
+    p = wide.placement()
+    assert abs(p.budget_bytes - 4 * ring_bytes) < (1 << 20) and ring_bytes < p.peak_bytes <= p.budget_bytes
+    assert p.stopped_by in (0, 1) and p.evicted >= 0 and p.out_candidates >= 3
+    check(wide)
+    wide.release()
     roomy = mb.FrameRing(dec, (w, h), n, tries=3, maxBytes=free0.value // 2)  # round 4's behaviour: every candidate stays alive
     q = roomy.placement()
     assert q.evicted == 0 and q.stopped_by == 0 and q.peak_bytes >= ring_bytes + 2 * n * w * h * 4  # at least three outputs alive at once

@@ -271,3 +271,37 @@ def test_fuzzed_rescale_geometry(gh, oracle, rep):
         info = (case, w, hgt, ow, oh, gamma, use_alpha, exact, ys, cs, os_, oy, oc, oo, lib.bt709hip_last_kernel_name())
         assert np.array_equal(rows[:, :4 * ow], want), info
         assert (rows[:, 4 * ow:] == 0x5A).all() and (raw[:oo] == 0x5A).all() and (raw[oo + os_ * oh:] == 0x5A).all(), info
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma", [0, 2])
+@pytest.mark.parametrize("shape", [((640, 64), (1280, 128)), ((100, 40), (333, 77)), ((1900, 32), (2000, 36)), ((1920, 32), (2021, 40)),
+                                   ((322, 18), (1287, 31)), ((64, 16), (4096, 16)), ((480, 270), (960, 540))])
+def test_gpu_enlarging_wave_decodes_each_source_pixel_once(gh, oracle, gamma, shape):
+    """Round 6: when the view is wider than the frame (AAPLRenderer.m:891-977, a 1080p clip in a larger view) the 64 lanes of a
+    wave decode 64 consecutive SOURCE columns once and take their two taps from each other's registers (ds_bpermute) instead of
+    each lane decoding both of its taps.  Shapes: exact 2x, an odd ratio with a ragged last wave, scale_x = 0.95 (the widest
+    span the form accepts: 61 of its 64 columns) and just above it (per-lane taps again), a wave whose taps all sit on a
+    handful of columns (64x), the right-edge clamp."""
+    (w, h), (ow, oh) = shape
+    y, c = _frame(w, h, w + h + ow + gamma)
+    got = gpu_scaled(gh, y, c, ow, oh, gamma)
+    assert np.array_equal(got, oracle.decode_nv12_scaled(gamma, y, c, ow, oh))
+
+
+@pytest.mark.gpu
+def test_gpu_enlarging_with_alpha_and_odd_luma_stride(gh, oracle):
+    """The same form with an alpha plane (a fourth value travels between the lanes) and with a luma plane at an odd pitch and
+    address (the form only needs the CbCr plane 2-byte aligned)."""
+    ctx = gh.context()
+    (w, h), (ow, oh) = (200, 24), (517, 50)
+    y, c = _frame(w, h, 61)
+    a = np.random.default_rng(62).integers(0, 256, (h, w), dtype=np.uint8)
+    got = gpu_scaled(gh, y, c, ow, oh, mb.MetalBT709GammaSRGB, alpha=a)
+    assert np.array_equal(got, oracle.decode_nv12_scaled(mb.MetalBT709GammaSRGB, y, c, ow, oh, alpha=a))
+    dec = gh.make_decoder(mb.MetalBT709GammaApple)
+    buf = gh.make_buffer(y, c, dec.gamma, y_stride=203, cbcr_stride=202)
+    tex = ctx.makeBGRATexture((ow, oh))
+    assert dec.decodeBT709Scaled(buf, tex, ctx.commandQueue.commandBuffer(), True), dec.lastStatus
+    got = ctx.getBGRATexturePixels(tex).view(np.uint8).reshape(oh, ow * 4)
+    assert np.array_equal(got, oracle.decode_nv12_scaled(0, y, c, ow, oh))

@@ -31,6 +31,9 @@ Gates (macro -> what it does; profiles/ file it produced):
   BT709_LAB_UNC_NO_ARITH  +unconvert: kernel, WRONG OUTPUT: loads + stores only                              r05_ab_unconvert_ceiling.txt
   BT709_LAB_HALF_ENCODE_B32  persistent 2:1 kernel, WRONG OUTPUT: 4-byte encode entries, twice the copies        r05_ab_half_encode_b32.txt
   BT709_LAB_SCALED_QUARTER_FEWER_TAPS  any-ratio kernel, WRONG OUTPUT: a quarter of the tap decodes deleted   r05_ab_scaled_r15_bound.txt
+  BT709_LAB_SCALED_HALF_FEWER_TAPS     any-ratio kernel, WRONG OUTPUT: the right tap a copy of the left one (half the decodes)  r06_ab_scaled_share.txt
+  BT709_LAB_SCALED_PAIR_DPP            the same with the copy taken from the next lane by a DPP move (lane-pair exchange)      r06_ab_scaled_share.txt
+  BT709_LAB_SCALED_ONCE_LDS            wave-decodes-once form exchanging through a wave-private LDS tile (same bytes out)      r06_ab_scaled_share.txt
 """
 import os
 import shutil
@@ -368,7 +371,27 @@ constexpr bool kRepUniformEncode = true;
 """,
      """    float x[6];
     RowLin rl;
-#if defined(BT709_LAB_SCALED_QUARTER_FEWER_TAPS)  // WRONG OUTPUT
+#if defined(BT709_LAB_SCALED_HALF_FEWER_TAPS) || defined(BT709_LAB_SCALED_PAIR_DPP)  // WRONG OUTPUT: tap 0 decoded, tap 1 a copy of it / of the next lane's
+    pixel_rgb(byte_of(fr.yy, 0), ch0, x[0], x[1], x[2]);
+    {
+      uint32_t t3[4];
+      const float xp[4] = {x[0], x[1], x[2], 0.0f};
+      magic_index4(xp, t3, r.magic);
+      u32x4 e3[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e3[i] = *reinterpret_cast<LdsQuadPtr>((t3[i] << r.dec_shift) + r.dec_off);
+      asm volatile("" : "+v"(e3[0]), "+v"(e3[1]), "+v"(e3[2]));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        rl.v[i] = __builtin_amdgcn_fmed3f(__uint_as_float(e3[i].y), __uint_as_float(e3[i].z), __fadd_rn(x[i], -__uint_as_float(e3[i].x)));
+#if defined(BT709_LAB_SCALED_PAIR_DPP)  // the lane-pair exchange as a DPP move (row_shl:1): what sharing between lane l and l + 1 costs
+        rl.v[3 + i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rl.v[i]), 0x101, 0xf, 0xf, false));
+#else
+        rl.v[3 + i] = rl.v[i];
+#endif
+      }
+    }
+#elif defined(BT709_LAB_SCALED_QUARTER_FEWER_TAPS)  // WRONG OUTPUT
     pixel_rgb(byte_of(fr.yy, 0), ch0, x[0], x[1], x[2]);
     if (srow & 1) {  // wave-uniform
       uint32_t t3[4];
@@ -391,6 +414,61 @@ constexpr bool kRepUniformEncode = true;
     linearise6(r, x, rl.v);
 #endif
 """),
+    # round 6: the wave-decodes-once form's exchange through a wave-private LDS tile instead of ds_bpermute (same bytes out)
+    ("bt709_rescale.hip",
+     """      RowLin rl;
+      rl.a[0] = rl.a[1] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          rl.v[3 * t + k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(static_cast<int>(tap_lane[t]), __builtin_bit_cast(int, own[k])));
+        if (HAS_ALPHA) rl.a[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(static_cast<int>(tap_lane[t]), __builtin_bit_cast(int, own[3])));
+      }
+      return rl;
+""",
+     """      RowLin rl;
+      rl.a[0] = rl.a[1] = 0.0f;
+#if defined(BT709_LAB_SCALED_ONCE_LDS)  // the decode-once TILE: own pixel written to LDS (16 bytes per lane, behind the tables), taps read back
+      {
+        typedef __attribute__((address_space(3))) u32x4 *LdsQuadW;
+        const uint32_t tile = p.lab_tile_off + (threadIdx.y * blockDim.x + (threadIdx.x & ~63u)) * 16u;  // this wave's 1 KiB
+        if (!HAS_ALPHA) own[3] = 0.0f;
+        u32x4 w = {__float_as_uint(own[0]), __float_as_uint(own[1]), __float_as_uint(own[2]), __float_as_uint(own[3])};
+        *reinterpret_cast<LdsQuadW>(tile + lane * 16u) = w;
+        asm volatile("" ::: "memory");
+        const u32x4 t0 = *reinterpret_cast<LdsQuadPtr>(tile + tap_lane[0] * 4u), t1 = *reinterpret_cast<LdsQuadPtr>(tile + tap_lane[1] * 4u);
+        asm volatile("" ::: "memory");
+        rl.v[0] = __uint_as_float(t0.x), rl.v[1] = __uint_as_float(t0.y), rl.v[2] = __uint_as_float(t0.z);
+        rl.v[3] = __uint_as_float(t1.x), rl.v[4] = __uint_as_float(t1.y), rl.v[5] = __uint_as_float(t1.z);
+        if (HAS_ALPHA) rl.a[0] = __uint_as_float(t0.w), rl.a[1] = __uint_as_float(t1.w);
+      }
+#else
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          rl.v[3 * t + k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(static_cast<int>(tap_lane[t]), __builtin_bit_cast(int, own[k])));
+        if (HAS_ALPHA) rl.a[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(static_cast<int>(tap_lane[t]), __builtin_bit_cast(int, own[3])));
+      }
+#endif
+      return rl;
+"""),
+    ("bt709_rescale.hip",
+     """  const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << kScaledDecCopiesLog2) + ((kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes) << kScaledEncCopiesLog2);
+  const dim3 block(kBlockThreads, kScaledStrips);""",
+     """#if defined(BT709_LAB_SCALED_ONCE_LDS)
+  const size_t lds_tables = (static_cast<size_t>(p.table_linear_bytes) << kScaledDecCopiesLog2) + ((kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes) << kScaledEncCopiesLog2);
+  p.lab_tile_off = static_cast<uint32_t>(lds_tables);  // the kernel's dynamic LDS starts at address 0 (no static LDS)
+  const size_t lds = lds_tables + 16u * kBlockThreads * kScaledStrips;
+#else
+  const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << kScaledDecCopiesLog2) + ((kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes) << kScaledEncCopiesLog2);
+#endif
+  const dim3 block(kBlockThreads, kScaledStrips);"""),
+    ("bt709_kernels.h",
+     """  uint32_t scaled_rows;  // output rows of a strip (filled by launch_decode_scaled)""",
+     """  uint32_t lab_tile_off;  // BT709_LAB_SCALED_ONCE_LDS
+  uint32_t scaled_rows;"""),
     ("bt709_encode.hip",
      """    uint32_t ytop, ybot, cbcr;
     quantize_quad(va, vb, ytop, ybot, cbcr);
@@ -446,7 +524,8 @@ constexpr bool kRepUniformEncode = true;
 MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT709_LAB_NO_TABLE", "BT709_NO_FMA_CENTRE",
           "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
           "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE", "BT709_LAB_F16_NO_ARITH", "BT709_LAB_F16_NO_TABLE",
-          "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_F16_DMA_STAGING", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32"]
+          "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_F16_DMA_STAGING", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32",
+          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS"]
 
 
 def make_lab_sources(dst=LAB_SRC):
