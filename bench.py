@@ -30,6 +30,10 @@ can be cut down to the timed launches (tools/pmc_summary.py).  cpu_baseline (ran
 per-pixel function (oracle/_ref, kind "reference") or, when that library is absent, the CPU oracle (kind "port") on WHOLE
 seeded frames: a 1080p and a 4K frame on one thread, then the workload's frame row-partitioned over the host cores.
 
+--y4m FILE: the ring holds the frames of a YUV4MPEG2 clip (repeated to the ring length) instead of PRNG bytes: `data` = "y4m",
+config.workload names the file's sha256 and geometry; the spot check compares the sampled ring frames with the oracle's decode of
+the clip's own planes.
+
 --dry-run replaces the GPU work by a sleep so the multi-process control flow (self-launch or rendezvous, barriers, max over
 ranks, single JSON line) can be tested on CPU.
 """
@@ -70,6 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--y4m", default=None, metavar="FILE",
+                    help="fill the ring from this YUV4MPEG2 C420jpeg clip (the reference's on-disk format, Renderer/y4m_writer.h:61-241; "
+                         "tools/make_y4m_clip.py writes one) instead of synthetic frames: geometry from the header, planar chroma interleaved on "
+                         "the device (bt709hip_interleave_cbcr), the clip's frames repeated to the ring length; everything else as --workload 4k")
     ap.add_argument("--ring", type=int, default=0, help="distinct frames resident per GPU (0 = workload default)")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = workload default (the whole ring)")
     ap.add_argument("--gamma", default="apple", choices=sorted(GAMMAS))
@@ -292,7 +300,11 @@ class GpuRunner:
         return placement_dict(self._capi, self.lib, self.h, self.rings[self.ring_name], sorted(self.rings))
 
     def fill_ring(self, content):
-        """Uploads (outside every timed region) the ring's frames: seeded PRNG bytes or smooth planes."""
+        """Uploads (outside every timed region) the ring's frames: seeded PRNG bytes or smooth planes -- or a clip's (--y4m)."""
+        if getattr(self.args, "clip", None):
+            self.host_frames.update(upload_clip(self.np, self._capi, self.lib, self.h, self.d_in.value, self.in_stride, self.g, self.args.clip,
+                                                self.sample_frames))
+            return
         self.host_frames.update(upload_frames(self.np, self._capi, self.lib, self.h, self.d_in.value, self.in_stride, self.g, content,
                                               1000 * self.rank, self.sample_frames))
 
@@ -431,6 +443,59 @@ def upload_frames(np, _capi, lib, ctx, d_in, in_stride, g, content, seed_offset,
         _capi.check(lib.bt709hip_stream_synchronize(ctx, None))
         if i in keep:
             kept[i] = buf.reshape(-1)
+    return kept
+
+
+def load_clip(path, max_frames):
+    """A YUV4MPEG2 4:2:0 clip -> {"W", "H", "frames": [(y, u, v)], "sha256", "fps"} (host memory; at most max_frames of it)."""
+    import hashlib
+    from metalbt709decoder_amd.y4m import Y4MReader
+    sha = hashlib.sha256()
+    with open(path, "rb") as f:
+        for block in iter(lambda: f.read(1 << 22), b""):
+            sha.update(block)
+    with Y4MReader(path) as r:
+        frames = []
+        for yuv in r:
+            frames.append(yuv)
+            if len(frames) >= max_frames:
+                break
+        if not frames:
+            sys.exit("--y4m %s: no frames" % path)
+        return {"W": r.width, "H": r.height, "frames": frames, "sha256": sha.hexdigest(), "fps": r.fps, "path": path}
+
+
+def clip_ring_frames(W, H):
+    """Ring length of a clip workload: the headline ring's pixel count (256 x 4K) in frames of this size, a multiple of 8."""
+    return max(8, (256 * 3840 * 2160 // (W * H)) // 8 * 8)
+
+
+def upload_clip(np, _capi, lib, ctx, d_in, in_stride, g, clip, keep):
+    """The clip's frames into ring slots 0 .. n-1 -- Y uploaded in place, the planar U and V uploaded to a staging buffer and
+    interleaved into the slot's CbCr plane ON THE DEVICE (bt709hip_interleave_cbcr: the reference's file layout -> NV12) -- then
+    slots n .. ring-1 as device-to-device copies of slot i mod n.  Untimed.  Returns {i: host NV12 bytes} for the slots in `keep`."""
+    W, H = g["W"], g["H"]
+    cw, ch = W // 2, H // 2
+    n = min(len(clip["frames"]), g["ring"])
+    stage = C.c_void_p()
+    _capi.check(lib.bt709hip_malloc(ctx, 2 * cw * ch + 256, C.byref(stage)), "staging")
+    for i in range(n):
+        y, u, v = (np.ascontiguousarray(p) for p in clip["frames"][i])
+        slot = d_in + i * in_stride
+        _capi.check(lib.bt709hip_upload(ctx, slot, W, y.ctypes.data, W, W, H, None), "upload Y")
+        _capi.check(lib.bt709hip_upload(ctx, stage.value, cw, u.ctypes.data, cw, cw, ch, None), "upload U")
+        _capi.check(lib.bt709hip_upload(ctx, stage.value + cw * ch, cw, v.ctypes.data, cw, cw, ch, None), "upload V")
+        _capi.check(lib.bt709hip_interleave_cbcr(ctx, stage.value, cw, stage.value + cw * ch, cw, slot + g["y_bytes"], W, cw, ch, None, 1), "interleave")
+    for i in range(n, g["ring"]):
+        _capi.check(lib.bt709hip_copy_probe(ctx, d_in + i * in_stride, d_in + (i % n) * in_stride, in_stride, None), "ring copy")
+    _capi.check(lib.bt709hip_stream_synchronize(ctx, None))
+    _capi.check(lib.bt709hip_free(ctx, stage))
+    kept = {}
+    for i in keep:
+        y, u, v = clip["frames"][i % n]
+        c = np.empty((ch, W), np.uint8)
+        c[:, 0::2], c[:, 1::2] = u, v
+        kept[i] = np.concatenate([np.ascontiguousarray(y).reshape(-1), c.reshape(-1)])
     return kept
 
 
@@ -790,6 +855,17 @@ def main(argv=None):
                              timeout_s=float(os.environ.get("BT709_BENCH_LAUNCH_TIMEOUT_S", "3600"))))
     if world != args.gpus and lanes == 1:
         args.gpus = world  # under torch.distributed.run the launcher's world size is authoritative
+    args.clip = None
+    if args.y4m:  # the workload IS the clip: geometry from its header, ring = the headline ring's pixel count in frames of that size
+        if lanes > 1:
+            sys.exit("--y4m runs with --launcher processes")
+        from metalbt709decoder_amd.y4m import Y4MReader
+        with Y4MReader(args.y4m) as hdr:
+            cw_, ch_ = hdr.width, hdr.height
+        ring_ = args.ring or clip_ring_frames(cw_, ch_)
+        args.clip = load_clip(args.y4m, ring_)
+        WORKLOADS["y4m"] = (cw_, ch_, False, ring_, ring_)
+        args.workload = "y4m"
     units = world * lanes  # GPUs the whole job asks for
 
     dist = None
@@ -943,17 +1019,18 @@ def main(argv=None):
         "scaling": "strong" if g["batch8"] and not args.share else "weak",
         "vs_baseline": None,
         "dtype": "f32",  # fp32 arithmetic on u8 samples, exact-table transfer, u8 out
-        "data": "synthetic",
+        "data": "y4m" if args.clip else "synthetic",
         "repeats": len(samples),  # value / ms_per_step = the MEDIAN of this many regions of `region_steps` steps
         "region_steps": region_steps,  # = steps x the smallest integer that makes a timed region >= 100 ms
         "k_step_region_ms": round(first[0] * 1e3, 4),  # the region of EXACTLY `steps` steps, timed first
         "value_min": round(to_value(slowest), 3),
         "value_max": round(to_value(fastest), 3),
         "config": {
-            "workload": "%dx%d NV12 BT.709 -> %dx%d BGRA8 sRGB, gamma=%s%s; per GPU a ring of %d distinct frames "
-                        "(%s, seed 0x709+i) resident in HBM; %s"
-                        % (g["W"], g["H"], g["OW"], g["OH"], args.gamma, ", fused 2:1 rescale" if g["half"] else "",
-                           g["ring"], {"random": "uniform random bytes", "smooth": "smooth video-like planes", "flat": "flat grey"}[args.content],
+            "workload": "%dx%d NV12 BT.709 -> %dx%d BGRA8 sRGB, gamma=%s%s; per GPU a ring of %d %s resident in HBM; %s"
+                        % (g["W"], g["H"], g["OW"], g["OH"], args.gamma, ", fused 2:1 rescale" if g["half"] else "", g["ring"],
+                           ("frames = the %d frames of the YUV4MPEG2 C420jpeg clip %s (sha256 %s) repeated, planar chroma interleaved on the device"
+                            % (len(args.clip["frames"]), os.path.basename(args.clip["path"]), args.clip["sha256"])) if args.clip else
+                           "distinct frames (%s, seed 0x709+i)" % {"random": "uniform random bytes", "smooth": "smooth video-like planes", "flat": "flat grey"}[args.content],
                            step_text),
             "frames_per_step_per_gpu": g["frames_per_step"],
             "streams": getattr(runner, "nstreams", 1),
@@ -999,7 +1076,8 @@ def main(argv=None):
         result["roofline"]["same_run_copy_GBps"] = round(copy_gbps, 1)
         result["roofline"]["frac_of_same_run_copy"] = round(achieved / copy_gbps, 4)
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(runner.host_frames[0], g, GAMMAS[args.gamma], args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(runner.host_frames[0], g, GAMMAS[args.gamma], args.cpu_seconds,
+                                                  own="frame 0 of the --y4m clip" if args.clip else None)
     if failed:
         result["value"] = None  # a wrong-output kernel on ANY rank yields no benchmark record
     if rank == 0:
@@ -1077,7 +1155,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(frame0, g, gamma, target_seconds):
+def cpu_baseline(frame0, g, gamma, target_seconds, own=None):
     """The CPU path beside the GPU, as SURVEY 8(d) defines it: WHOLE seeded frames through the reference's own per-pixel function
     (oracle/_ref, kind "reference"; the CPU oracle, kind "port", when that library is absent or for the fused 2:1 path) -- one
     1920x1080 frame and one 3840x2160 frame on ONE thread (the reference is single-threaded scalar, BGRAToBT709Converter.m:146-198),
@@ -1132,13 +1210,13 @@ def cpu_baseline(frame0, g, gamma, target_seconds):
         times.sort()
         frames.append({"size": "%dx%d%s" % (W, H, " (fused 2:1)" if via_half else ""), "threads": 1, "samples": len(times),
                        "Mpx_per_s": round(W * H / times[len(times) // 2] / 1e6, 3), "seconds": round(times[len(times) // 2], 4)})
-    # all cores, the workload's own frame: as many whole-frame passes as the remaining budget holds (at least 3)
+    # all cores, the workload's own frame: as many whole-frame passes as the remaining budget holds (at least 5)
     W, H = g["W"], g["H"]
     passes = []
     with ThreadPoolExecutor(cores) as pool:
         one_pass(W, H, cores, half, pool)  # threads started, pages touched
         deadline = t_start + target_seconds
-        while len(passes) < 3 or time.perf_counter() < deadline:
+        while len(passes) < 5 or time.perf_counter() < deadline:
             passes.append(one_pass(W, H, cores, half, pool))
             if len(passes) >= 200:
                 break
@@ -1153,7 +1231,7 @@ def cpu_baseline(frame0, g, gamma, target_seconds):
         "unit": "Gpixel/s",
         "cores": cores,
         "kind": kind,
-        "sample": "whole seeded frames (PRNG bytes, seed 0x709): %s on 1 thread (median of `samples` passes, see frames[]); then the %dx%d "
+        "sample": "whole seeded frames (PRNG bytes, seed 0x709" + ("; %dx%d: %s" % (W, H, own) if own else "") + "): %s on 1 thread (median of `samples` passes, see frames[]); then the %dx%d "
                   "frame row-partitioned over %d threads, median of %d whole-frame passes (%.1f s of CPU work in all)"
                   % (" and ".join(f["size"] for f in frames if f["threads"] == 1), W, H, cores, len(passes), time.perf_counter() - t_start),
         "frames": frames,

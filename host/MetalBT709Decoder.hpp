@@ -1,5 +1,5 @@
 // C++ host-side mirror of the reference's decode operator over the C ABI
-// (include/bt709hip.h).  Header-only; link with -lbt709hip.
+// (include/bt709hip.h, include/bt709hip_ext.h).  Header-only; link with -lbt709hip.
 //
 // The reference's host side is Objective-C:
 //     Renderer/MetalRenderContext.h:17-105    @interface MetalRenderContext
@@ -15,7 +15,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../include/bt709hip.h"
+#include "../include/bt709hip_ext.h"
 
 namespace bt709 {
 
@@ -383,7 +383,7 @@ class MetalBT709Decoder {
     return rc == BT709HIP_OK ? ok() : fail(rc);
   }
 
-  // The coalescing submit (include/bt709hip.h BT709HIP_OPT_COALESCE): keep the reference's one-decodeBT709-call-per-frame cadence
+  // The coalescing submit (include/bt709hip_ext.h BT709HIP_OPT_COALESCE): keep the reference's one-decodeBT709-call-per-frame cadence
   // on device-resident frames and let `frames` (2..32; 0 = off) queued calls go out as one launch; maxAgeMicroseconds > 0: a queue
   // older than that is issued by the context's next call on ANY stream (BT709HIP_OPT_COALESCE_MAX_AGE_US), so an idle caller's
   // frames do not wait for ever.
@@ -495,7 +495,7 @@ class InFlightFramePool {
 };
 
 // Frames resident in DEVICE memory: a ring of same-sized NV12 inputs and BGRA outputs carved from two slabs and placed by
-// bt709hip_ring_create's hunt (include/bt709hip.h "frame ring"; round 4).  The reference's twin is its per-in-flight-frame
+// bt709hip_ring_create's hunt (include/bt709hip_ext.h "frame ring"; round 4).  The reference's twin is its per-in-flight-frame
 // CVPixelBuffers + render texture (Renderer/AAPLRenderer.m:34, 530-862).
 class FrameRing {
  public:

@@ -1,7 +1,7 @@
 """MI355X-native BT.709 NV12 -> sRGB BGRA decode path (gfx950 HIP kernel behind the
 reference's MetalBT709Decoder operator API).
 
-The product is metalbt709decoder_amd/libbt709hip.so (C ABI: include/bt709hip.h); this
+The product is metalbt709decoder_amd/libbt709hip.so (C ABI: include/bt709hip.h + include/bt709hip_ext.h); this
 package is the host-side mirror of the reference's classes over it.  Nothing here
 imports, links or runs oracle/: that directory is test infrastructure.
 """

@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI declared in include/bt709hip.h.
+"""ctypes binding of the C ABI declared in include/bt709hip.h (the reference-twinned calls) and include/bt709hip_ext.h.
 
 Loading never falls back to anything: if libbt709hip.so is missing and cannot be
 built, importing the product raises.
@@ -24,7 +24,7 @@ class Surface(C.Structure):  # bt709hip_surface
                 ("format", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 502  # BT709HIP_VERSION of include/bt709hip.h these bindings were written against
+ABI_VERSION = 502  # BT709HIP_VERSION of the two headers these bindings were written against
 
 # bt709hip_format
 FORMAT_BGRA8_SRGB = 0
@@ -88,7 +88,7 @@ ERR_UNSUPPORTED = -11
 
 MAX_BATCH = 32
 
-# every symbol include/bt709hip.h declares: name -> (restype, argtypes)
+# every symbol the two headers declare: name -> (restype, argtypes)
 _P, _I, _Z = C.c_void_p, C.c_int, C.c_size_t
 _FP, _SP = C.POINTER(Frame), C.POINTER(Surface)
 SYMBOLS = {

@@ -17,10 +17,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbt709hip.so")
 ASM = os.path.join(HERE, "build", "bt709_kernels.s")  # decode + rescale + encode kernels, concatenated
-SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_rgba16f.hip", "bt709_encode.hip", "bt709_planes.hip", "bt709hip.cpp",
+SOURCES = ["bt709_kernels.hip", "bt709_rescale_half.hip", "bt709_rescale_scaled.hip", "bt709_rgba16f.hip", "bt709_encode.hip", "bt709_planes.hip",
+           "shim_core.cpp", "shim_decode.cpp", "shim_convert.cpp", "shim_coalesce.cpp", "shim_pool_shard.cpp", "shim_introspect.cpp",
            "bt709_ring.cpp", "transfer_tables.cpp"]
-KERNEL_SOURCES = ["bt709_kernels.hip", "bt709_rescale.hip", "bt709_rgba16f.hip", "bt709_encode.hip"]
-HEADERS = ["bt709_kernels.h", "bt709_device.h", "bt709_constants.h", "bt709_quantise.h", "bt709_stage.h", "transfer_tables.h"]
+KERNEL_SOURCES = ["bt709_kernels.hip", "bt709_rescale_half.hip", "bt709_rescale_scaled.hip", "bt709_rgba16f.hip", "bt709_encode.hip"]
+HEADERS = ["bt709_kernels.h", "bt709_device.h", "bt709_constants.h", "bt709_quantise.h", "bt709_stage.h", "transfer_tables.h", "shim_internal.h", "bt709_rescale.h"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: hipcc otherwise pairs scalar f32 multiplies/adds into v_pk_* ops, which run
 # at half rate on gfx950 and need v_mov shuffles to build their operand pairs (measured: 458 VALU
@@ -38,6 +39,7 @@ def _hipcc():
 def _deps():
     files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     files.append(os.path.join(os.path.dirname(HERE), "include", "bt709hip.h"))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "bt709hip_ext.h"))
     files.append(os.path.abspath(__file__))
     return files
 

@@ -1,5 +1,5 @@
 // Device-side building blocks shared by the decode (bt709_kernels.hip) and the fused
-// decode + rescale kernels (bt709_rescale.hip).  gfx950 only.
+// decode + rescale kernels (bt709_rescale_half.hip, bt709_rescale_scaled.hip).  gfx950 only.
 //
 // Arithmetic follows the reference's CPU path (Renderer/BT709.h:466-513, 348-460, 821-908),
 // which is what the 8-bit output is checked against:

@@ -113,7 +113,7 @@ const char *launch_decode_rgba16f(const DecodeParams &p, const HalfParams &hp, i
                                   uint32_t in_align, uint32_t out_align, uint32_t compute_units, bool xcd_bands, hipStream_t stream);
 hipError_t prepare_rgba16f_kernels();  // bt709_rgba16f.hip
 
-// Pass 2 alone (bt709_rescale.hip render_scaled): an intermediate surface -> a BGRA8 sRGB surface of any size.
+// Pass 2 alone (bt709_rescale_scaled.hip render_scaled): an intermediate surface -> a BGRA8 sRGB surface of any size.
 struct RenderParams {
   const uint8_t *in;   // BGRA8 sRGB words or RGBA16Float texels
   uint8_t *out;        // BGRA8 sRGB
@@ -261,6 +261,6 @@ inline uint32_t quads_rows_per_block(uint32_t block_threads, uint32_t tiles) {
 
 // Raise the dynamic-LDS cap of the kernels (tables can exceed the 64 KiB default).
 hipError_t prepare_kernels();          // bt709_kernels.hip
-hipError_t prepare_rescale_kernels();  // bt709_rescale.hip
+hipError_t prepare_rescale_kernels();  // bt709_rescale_half.hip (+ bt709_rescale_scaled.hip's)
 
 }  // namespace bt709

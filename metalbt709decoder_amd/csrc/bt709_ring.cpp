@@ -1,4 +1,4 @@
-// Frame ring with placement-aware allocation (include/bt709hip.h, "frame ring").
+// Frame ring with placement-aware allocation (include/bt709hip_ext.h, "frame ring").
 //
 // A streaming application -- and bench.py -- keeps a ring of same-sized frames resident in HBM: N NV12 inputs carved from
 // one slab, N BGRA outputs from another, decoded in long launches (bt709hip_decode_batch over evenly spaced frames).  On
@@ -7,7 +7,7 @@
 // slab carries most of it, the pairing with the input slab a further 1-2 %).  Rounds 2-3 hunted for a good pairing inside
 // bench.py; this file is that hunt as product behaviour: bt709hip_ring_create allocates `tries` candidates per slab, times
 // the decoder's OWN launch over the pairings and keeps the fastest.  Written on top of the public C ABI only.
-#include "../../include/bt709hip.h"
+#include "../../include/bt709hip_ext.h"
 
 #include <algorithm>
 #include <chrono>
@@ -33,6 +33,16 @@ namespace {
 constexpr size_t kHuntMinBytes = 256u << 20;  // a ring that fits the 256 MB memory-side cache has no placement to hunt for
 constexpr size_t kReserveBytes = 4ull << 30;  // device memory the hunt always leaves free
 constexpr int kMaxTries = 6;
+// The hunt's own cost (round 6: the default hunt must fit ~1.5 s for a 12 GB ring; tools/ab_hunt.sh times variant builds of these)
+#ifndef BT709_HUNT_WARM_S
+#define BT709_HUNT_WARM_S 0.03  // synchronous launches over a candidate before its probe (page tables, clocks)
+#endif
+#ifndef BT709_HUNT_CONFIRM_X
+#define BT709_HUNT_CONFIRM_X 6  // the finalists' probes are this many times as long as a prescan probe
+#endif
+#ifndef BT709_HUNT_FRUGAL_INPUTS
+#define BT709_HUNT_FRUGAL_INPUTS 1  // input candidates of the frugal hunt (the input slab moves the rate by ~1 %, the output slab by ~10 %)
+#endif
 constexpr int kMaxOutCandidates = 3 * kMaxTries;  // == the arrays of bt709hip_ring_placement
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -234,7 +244,7 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
   // rate by ~1 % -- but never more than a quarter of the budget, and always leaving room for two outputs.
   std::vector<Slab> ins, outs;
   {
-    int n_in = frugal ? std::min(tries, 2) : tries;
+    int n_in = frugal ? std::min(tries, BT709_HUNT_FRUGAL_INPUTS) : tries;
     while (n_in > 1 && ((!frugal && static_cast<size_t>(n_in) * in_bytes > led.budget / 4) || static_cast<size_t>(n_in) * in_bytes + 2 * out_bytes > led.budget)) --n_in;
     for (int i = 0; i < n_in; ++i) {
       if (i > 0 && !led.fits(in_bytes + out_bytes)) break;
@@ -303,7 +313,7 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
           break;
         }
         outs.push_back(Slab{p, 0.0f, true});
-        outs.back().rate = pr.measure(ins[0].p, p, reps, 0.03);
+        outs.back().rate = pr.measure(ins[0].p, p, reps, BT709_HUNT_WARM_S);
       }
       if (stuck || pr.rc != BT709HIP_OK) break;
       float hi = 0.0f, lo = 1e30f;
@@ -331,7 +341,7 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
           pl.stopped_by = 2;
           break;
         }
-        probed[{static_cast<int>(i), o}] = i == 0 ? outs[static_cast<size_t>(o)].rate : pr.measure(ins[i].p, outs[static_cast<size_t>(o)].p, reps, 0.03);
+        probed[{static_cast<int>(i), o}] = i == 0 ? outs[static_cast<size_t>(o)].rate : pr.measure(ins[i].p, outs[static_cast<size_t>(o)].p, reps, BT709_HUNT_WARM_S);
       }
     pl.probes = static_cast<int>(probed.size());
     if (pr.rc == BT709HIP_OK && !probed.empty()) {
@@ -359,7 +369,7 @@ int bt709hip_ring_create_ex(bt709hip_decoder *dec, int width, int height, int fr
             pl.stopped_by = 2;
             break;
           }
-          const float v = pr.measure(ins[static_cast<size_t>(io.first)].p, outs[static_cast<size_t>(io.second)].p, 6 * reps, 0.03);
+          const float v = pr.measure(ins[static_cast<size_t>(io.first)].p, outs[static_cast<size_t>(io.second)].p, BT709_HUNT_CONFIRM_X * reps, BT709_HUNT_WARM_S);
           if (v > best) best = v, bi = io.first, bo = io.second;
         }
       if (best > 0.0f) pl.chosen_GBps = best;
@@ -420,7 +430,7 @@ int bt709hip_ring_decode(bt709hip_ring *r, int first, int count, void *stream, i
 }
 
 // ----------------------------------------------------------------- ring set
-// One process, several GPUs, device-resident frames (include/bt709hip.h "ring set"): a context + decoder + ring per lane, one
+// One process, several GPUs, device-resident frames (include/bt709hip_ext.h "ring set"): a context + decoder + ring per lane, one
 // launch per lane per step issued from the calling thread.  Every C-ABI call binds its context's device, so the lanes need no
 // thread of their own: a launch call returns as soon as the kernel is enqueued.
 

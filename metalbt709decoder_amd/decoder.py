@@ -167,7 +167,7 @@ class InFlightFramePool:
 
 class FrameRing:
     """`frames` same-sized frames resident in device memory, inputs carved from one slab and outputs from another, placed by
-    bt709hip_ring_create's hunt (include/bt709hip.h "frame ring"): what a streaming application keeps in HBM.  The
+    bt709hip_ring_create's hunt (include/bt709hip_ext.h "frame ring"): what a streaming application keeps in HBM.  The
     reference's twin is its per-in-flight-frame CVPixelBuffers + render texture (AAPLRenderer.m:34, 530-862); unified
     memory has no placement to choose."""
 

@@ -11,7 +11,7 @@
 // (3, AAPLRenderer.m:34) frames stay in flight on their own HIP streams; the caller invokes -finishHIPFrames before
 // [commandBuffer commit].
 @property (nonatomic, assign) BOOL hipDeferredCompletion;
-// The coalescing submit of the HIP decoder (include/bt709hip.h BT709HIP_OPT_COALESCE / _COALESCE_MAX_AGE_US), for a caller that
+// The coalescing submit of the HIP decoder (include/bt709hip_ext.h BT709HIP_OPT_COALESCE / _COALESCE_MAX_AGE_US), for a caller that
 // hands this decoder DEVICE-resident frames through its bt709hip handle (hipDecoderHandle) at the reference's one-call-per-frame
 // cadence: n = 2..32 frames gathered per launch (0 = off, the default), and the age in microseconds after which a queue is issued
 // by the context's next call on any stream (0 = no limit).  Host-memory frames -- this class's own selector -- gain nothing: each

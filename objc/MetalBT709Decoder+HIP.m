@@ -1,5 +1,5 @@
 // Source-only: the Objective-C binding a maintainer of mdejong/MetalBT709Decoder would add to route
-// the decode to libbt709hip.so (include/bt709hip.h).  There is no Objective-C runtime, Foundation,
+// the decode to libbt709hip.so (include/bt709hip.h + bt709hip_ext.h).  There is no Objective-C runtime, Foundation,
 // CoreVideo or Metal on the ROCm image, so this file is NOT built or run here; the flow it implements
 // -- host planes -> in-flight pool -> host pixels, behind the unchanged 8-argument selector, the nil-texture /
 // render-pass-descriptor route included -- is built and tested as host/MetalBT709Decoder.hpp's HostPixelBuffer
@@ -13,7 +13,7 @@
 #import "MetalBT709Decoder+HIP.h"   // hipDeferredCompletion, -finishHIPFrames, hipCoalesceFrames (class extension)
 #import "MetalRenderContext.h"
 #import <CoreVideo/CoreVideo.h>
-#include "bt709hip.h"
+#include "bt709hip_ext.h"
 
 enum { BT709HIPMaxInFlight = 3 };  // MaxBuffersInFlight, AAPLRenderer.m:34
 

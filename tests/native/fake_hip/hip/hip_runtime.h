@@ -1,7 +1,7 @@
 // TESTS ONLY -- a fake HIP runtime for the CPU build of the host shim (tests/native/fake_hip/fake_hip.cpp implements it).
 //
 // GPU sanitizers do not exist on this pool, so the 2 000+ lines of host code that hold mutexes, thread-locals and per-stream
-// queues (metalbt709decoder_amd/csrc/bt709hip.cpp, bt709_ring.cpp) are compiled with g++ against THIS header instead of ROCm's and
+// queues (metalbt709decoder_amd/csrc/shim_*.cpp, bt709_ring.cpp) are compiled with g++ against THIS header instead of ROCm's and
 // run under ASan / UBSan / TSan (tools/sanitize.sh, tests/test_fake_hip.py).  Device memory is host memory (large slabs are
 // address reservations that are never touched), a stream is a FIFO run by a worker thread, a kernel launch is a log entry plus
 // a tick of a fake device clock, events are stamps of that clock.  Only the API subset the shim uses exists.  Nothing under

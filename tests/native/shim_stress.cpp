@@ -1,4 +1,4 @@
-// TESTS ONLY -- the host shim (csrc/bt709hip.cpp, bt709_ring.cpp) driven hard on the fake HIP runtime (tests/native/fake_hip/),
+// TESTS ONLY -- the host shim (csrc/shim_*.cpp, bt709_ring.cpp) driven hard on the fake HIP runtime (tests/native/fake_hip/),
 // built with -fsanitize=address,undefined or -fsanitize=thread (tools/sanitize.sh, tests/test_fake_hip.py).  No kernel runs and no
 // pixel is checked here -- parity is the GPU tests' job -- this is about the shim's own state: mutexes, per-stream queues,
 // thread-locals, lifetimes, error paths.
@@ -23,7 +23,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/bt709hip.h"
+#include "../../include/bt709hip_ext.h"
 #include "fake_hip/fake_hip.h"
 
 static int failures = 0;
@@ -268,14 +268,36 @@ static void test_ring_hunts() {
   CHECK(fake_hip_allocated(0) == base_bytes);
 
   // frugal: the fast slab is found although only two outputs ever live together
-  fake_hip_set_rate_by_allocation_order(rates + 1, static_cast<int>(sizeof rates / sizeof rates[0]) - 1);  // 2 inputs, then outputs
+  fake_hip_set_rate_by_allocation_order(rates + 2, static_cast<int>(sizeof rates / sizeof rates[0]) - 2);  // 1 input, then outputs
   bt709hip_ring_options frugal = {0, 0, 1};
   OK(bt709hip_ring_create_ex(dec, w, h, n, 0, 3, &frugal, &ring));
   OK(bt709hip_ring_placement_info(ring, &p));
-  CHECK(p.in_candidates == 2 && p.evicted == p.out_candidates - 2 && p.stopped_by == 1);
+  CHECK(p.in_candidates == 1 && p.evicted == p.out_candidates - 2 && p.stopped_by == 1);
   CHECK(p.out_prescan_GBps[p.chosen_out] > 6500.0f && p.peak_bytes <= p.budget_bytes);
+  const uint64_t frugal_budget = p.budget_bytes;
   OK(bt709hip_ring_destroy(ring));
   CHECK(fake_hip_allocated(0) == base_bytes);
+  // round 6: that IS the default -- options NULL (bt709hip_ring_create) or a zeroed struct hunt within twice the ring
+  fake_hip_set_rate_by_allocation_order(rates + 2, static_cast<int>(sizeof rates / sizeof rates[0]) - 2);
+  OK(bt709hip_ring_create(dec, w, h, n, 0, 3, &ring));
+  OK(bt709hip_ring_placement_info(ring, &p));
+  CHECK(p.budget_bytes == frugal_budget && p.in_candidates == 1 && p.stopped_by == 1 && p.out_prescan_GBps[p.chosen_out] > 6500.0f);
+  OK(bt709hip_ring_destroy(ring));
+  CHECK(fake_hip_allocated(0) == base_bytes);
+  // a probe that fails AFTER the budget has evicted (freed) the first output: the error comes back and nothing is freed twice
+  // (round 5's advisor: the error path used to free outs[0] again; AddressSanitizer is the judge here)
+  int failed_hunts = 0;
+  for (int k : {20, 45, 90, 150}) {
+    fake_hip_set_rate_by_allocation_order(rates + 2, static_cast<int>(sizeof rates / sizeof rates[0]) - 2);
+    fake_hip_fail_launch_at(k);
+    ring = nullptr;
+    const int rc = bt709hip_ring_create(dec, w, h, n, 0, 3, &ring);
+    fake_hip_fail_launch_at(0);
+    CHECK((rc == BT709HIP_ERR_HIP && ring == nullptr) || (rc == BT709HIP_OK && ring != nullptr));
+    failed_hunts += rc == BT709HIP_ERR_HIP;
+    if (ring) OK(bt709hip_ring_destroy(ring));
+    CHECK(fake_hip_allocated(0) == base_bytes);
+  }
 
   // allocation refused at candidate k (k = 1: the ring's own input; 2: its first output; later: a candidate): clean error or a
   // smaller hunt, never a leak

@@ -1,12 +1,12 @@
 """CPU tests of the host shim on a FAKE HIP runtime (tests/native/fake_hip/): GPU sanitizers do not exist on this pool, so
-the code that holds mutexes, thread-locals and per-stream queues -- csrc/bt709hip.cpp, csrc/bt709_ring.cpp -- is compiled with
+the code that holds mutexes, thread-locals and per-stream queues -- csrc/shim_*.cpp, csrc/bt709_ring.cpp -- is compiled with
 g++ against a stand-in <hip/hip_runtime.h> (streams = FIFOs with worker threads, launches = log entries, device memory = host
 memory / address reservations) and
 
   * run under ASan + UBSan + LeakSanitizer and under TSan (tests/native/shim_stress.cpp: coalescing from two threads on two streams
     with a third flipping options, pool / sharder churn, ring hunts with refused allocations and failing launches, ring sets,
     graphs, decoder destruction with frames queued);
-  * checked STRUCTURALLY: every export of include/bt709hip.h that takes a `void *stream` must issue the frames a coalescing
+  * checked STRUCTURALLY: every export of include/bt709hip.h / bt709hip_ext.h that takes a `void *stream` must issue the frames a coalescing
     decoder has queued on that stream before its own work -- the header is parsed, so an export added later without that
     property (or without an entry below) fails here.
 
@@ -24,7 +24,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "metalbt709decoder_amd", "csrc")
 FAKE = os.path.join(HERE, "native", "fake_hip")
-SHIM_SOURCES = [os.path.join(CSRC, f) for f in ("bt709hip.cpp", "bt709_ring.cpp", "transfer_tables.cpp")] + [os.path.join(FAKE, "fake_hip.cpp")]
+SHIM_SOURCES = [os.path.join(CSRC, f) for f in ("shim_core.cpp", "shim_decode.cpp", "shim_convert.cpp", "shim_coalesce.cpp", "shim_pool_shard.cpp",
+                                                 "shim_introspect.cpp", "bt709_ring.cpp", "transfer_tables.cpp")] + [os.path.join(FAKE, "fake_hip.cpp")]
 CXX = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-Wall", "-Wno-format-truncation", "-I" + FAKE, "-I" + os.path.join(HERE, "native")]
 
 sys.path.insert(0, ROOT)
@@ -80,7 +81,8 @@ def log(lib, start=0):
 
 def stream_exports():
     """Names of the C-ABI exports with a `void *stream` parameter, parsed from the public header."""
-    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    import abi_headers
+    hdr = abi_headers.text()
     hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
     names = []
     for m in re.finditer(r"\b(?:int|const char \*|bt709hip_\w+ \*)\s*(bt709hip_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
@@ -170,7 +172,7 @@ def test_every_stream_taking_export_issues_the_queued_frames_first(fake):
     }
     exports = stream_exports()
     assert len(exports) >= 27, exports
-    assert sorted(recipes) == exports, "include/bt709hip.h and this test disagree about the stream-taking exports: %s" % sorted(set(recipes) ^ set(exports))
+    assert sorted(recipes) == exports, "the headers and this test disagree about the stream-taking exports: %s" % sorted(set(recipes) ^ set(exports))
 
     for name in exports:
         S = new_stream()
@@ -209,7 +211,7 @@ def test_every_stream_taking_export_issues_the_queued_frames_first(fake):
 
 def test_fake_runtime_is_not_part_of_the_product():
     """The fake runtime lives under tests/ only: the package, the public header and the build script never mention it."""
-    for path in [os.path.join(ROOT, "include", "bt709hip.h"), os.path.join(ROOT, "metalbt709decoder_amd", "build.py"),
+    for path in [os.path.join(ROOT, "include", "bt709hip.h"), os.path.join(ROOT, "include", "bt709hip_ext.h"), os.path.join(ROOT, "metalbt709decoder_amd", "build.py"),
                  os.path.join(ROOT, "metalbt709decoder_amd", "_capi.py"), os.path.join(ROOT, "metalbt709decoder_amd", "decoder.py")]:
         assert "fake_hip" not in open(path).read(), path
     for f in os.listdir(CSRC):

@@ -1,5 +1,5 @@
 """CPU-side tests of the product (no GPU, no compute calls): the C-ABI library loads
-and exports everything include/bt709hip.h declares, the host-built tables and constants
+and exports everything include/bt709hip.h and include/bt709hip_ext.h declare, the host-built tables and constants
 equal the reference-pinned goldens, the kernel ISA honours the no-FMA contract, the
 failure behaviour without a device is loud, and the N>1 control flow works over gloo.
 """
@@ -17,6 +17,7 @@ import pytest
 import metalbt709decoder_amd as mb
 from metalbt709decoder_amd import _capi, build
 from oracle_lib import GAMMA_NAMES
+import abi_headers
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -32,10 +33,9 @@ def test_library_is_not_older_than_its_sources(lib):
 
 
 def test_library_exports_every_declared_symbol(lib):
-    header = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
-    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    header = re.sub(r"/\*.*?\*/", "", abi_headers.text(), flags=re.S)
     declared = set(re.findall(r"\b(bt709hip_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 30
+    assert len(declared) == 102  # ABI 502: frozen in round 6 (the split into two headers moved declarations, it added none)
     for name in declared:
         assert hasattr(lib, name), "library does not export " + name
     # and the ctypes table binds exactly that set
@@ -44,10 +44,45 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_header_compiles_as_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "bt709hip.h"\nint main(void){bt709hip_frame f; (void)f; return BT709HIP_MAX_BATCH==32?0:1;}\n')
-    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
-                        "-o", str(tmp_path / "t")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    for header in ("bt709hip.h", "bt709hip_ext.h"):  # each on its own (the second includes the first)
+        src.write_text('#include "%s"\nint main(void){bt709hip_frame f; (void)f; return BT709HIP_MAX_BATCH==32?0:1;}\n' % header)
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                            "-o", str(tmp_path / "t")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+# the calls SURVEY 8(b) / the reference's headers name (Renderer/MetalRenderContext.h:17-105, MetalBT709Decoder.h:15-72,
+# MetalScaleRenderContext.h:34-40, BGRAToBT709Converter.h:34-76, y4m_writer.h:194-241): what include/bt709hip.h declares
+REFERENCE_TWINNED = {
+    "bt709hip_context_create", "bt709hip_context_destroy", "bt709hip_device_count", "bt709hip_abi_version",
+    "bt709hip_stream_create", "bt709hip_stream_destroy", "bt709hip_stream_synchronize",
+    "bt709hip_malloc", "bt709hip_free", "bt709hip_memset", "bt709hip_upload", "bt709hip_download",
+    "bt709hip_decoder_create", "bt709hip_decoder_destroy", "bt709hip_decoder_set_context", "bt709hip_decoder_set_alpha_fill",
+    "bt709hip_decoder_get_gamma", "bt709hip_decoder_has_alpha", "bt709hip_decoder_context", "bt709hip_decoder_setup",
+    "bt709hip_decode", "bt709hip_decode_batch", "bt709hip_decode_half", "bt709hip_decode_scaled", "bt709hip_render_scaled",
+    "bt709hip_unconvert", "bt709hip_encode", "bt709hip_interleave_cbcr", "bt709hip_deinterleave_cbcr",
+    "bt709hip_strerror", "bt709hip_last_hip_error", "bt709hip_last_hip_error_string",
+}
+
+
+def test_boundary_is_split_into_reference_twins_and_extensions():
+    """Round 6: include/bt709hip.h is the thin boundary SURVEY 8(b) describes -- at most 250 lines, exactly the calls that replace
+    a reference interface -- and everything without a twin (rings, ring sets, shards, pools, coalescing, graphs, events,
+    options, batched side paths, introspection) sits in include/bt709hip_ext.h, which includes it.  The shim is split along the
+    same line and no file of csrc/ exceeds 900 lines."""
+    strip = lambda t: re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+    core = set(re.findall(r"\b(bt709hip_[a-z0-9_]+)\s*\(", strip(abi_headers.core_text())))
+    ext = set(re.findall(r"\b(bt709hip_[a-z0-9_]+)\s*\(", strip(abi_headers.ext_text())))
+    assert core == REFERENCE_TWINNED
+    assert not core & ext and len(core | ext) == 102
+    assert abi_headers.core_text().count("\n") <= 250
+    assert '#include "bt709hip.h"' in abi_headers.ext_text() and "bt709hip_ext.h" not in strip(abi_headers.core_text())
+    csrc = os.path.join(os.path.dirname(mb.__file__), "csrc")
+    for f in sorted(os.listdir(csrc)):
+        assert open(os.path.join(csrc, f), encoding="utf-8").read().count("\n") <= 900, f
+    # the pool / ring / shard handles are extension types: the core header does not even name them
+    for word in ("bt709hip_pool", "bt709hip_ring", "bt709hip_shard", "coalesc", "graph", "event"):
+        assert word not in strip(abi_headers.core_text()), word
 
 
 def test_matrix_constants_bit_patterns(lib, oracle):
@@ -200,7 +235,7 @@ def test_decoder_and_context_options(lib):
     assert lib.bt709hip_last_launch_info(None) == _capi.ERR_INVALID_ARG
     assert lib.bt709hip_context_set_option(None, _capi.CTX_OPT_GRID_MULT, 2) == _capi.ERR_INVALID_ARG
     assert lib.bt709hip_abi_version() == _capi.ABI_VERSION
-    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    hdr = abi_headers.core_text()
     assert "#define BT709HIP_VERSION %d" % _capi.ABI_VERSION in hdr
     src = "".join(open(os.path.join(os.path.dirname(mb.__file__), "csrc", f)).read()
                   for f in os.listdir(os.path.join(os.path.dirname(mb.__file__), "csrc")))
@@ -521,7 +556,7 @@ def test_no_experiment_gates_in_the_product_sources():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import lab_variants
     for name, product, _ in lab_variants.GATES:
-        assert open(os.path.join(csrc, name)).read().count(product) == 1, (name, product[:60])
+        assert lab_variants.resolve(csrc, name, product) is not None, (name, product[:60])
 
 
 def test_product_never_touches_the_oracle():
@@ -531,8 +566,7 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert "oracle_lib" not in text and "liboracle" not in text and "bt709_oracle" not in text, f
-    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
-    assert "oracle" not in hdr
+    assert "oracle" not in abi_headers.text()
 
 
 # ------------------------------------------------------------------ N > 1 control flow
@@ -819,7 +853,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     added to the header alone (or to the bindings alone) fails here, before it mis-calls the library."""
     pairs = {"bt709hip_frame": _capi.Frame, "bt709hip_surface": _capi.Surface, "bt709hip_ring_placement": _capi.RingPlacement,
              "bt709hip_ring_options": _capi.RingOptions, "bt709hip_launch_info": _capi.LaunchInfo, "bt709hip_device_info": _capi.DeviceInfo}
-    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "bt709hip.h"', 'int main(void) {']
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "bt709hip_ext.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
         for field, _ in cls._fields_:
@@ -836,7 +870,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
         for field, _ in cls._fields_:
             assert int(got["%s.%s" % (cname, field)]) == getattr(cls, field).offset, (cname, field)
     # and the header has no struct the bindings do not know (opaque handles aside)
-    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    hdr = abi_headers.text()
     named = set(re.findall(r"^\} (bt709hip_\w+);", hdr, flags=re.M)) - {"bt709hip_status", "bt709hip_gamma", "bt709hip_matrix_tag",
                                                                         "bt709hip_transfer_tag", "bt709hip_format",
                                                                         "bt709hip_context_option", "bt709hip_decoder_option"}
@@ -846,7 +880,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
 def test_ctypes_constants_match_the_header():
     """Status codes, render-target formats and option ids of _capi.py against the enumerators of include/bt709hip.h, by name:
     BT709HIP_<NAME> = value  <->  _capi.<NAME> (BT709HIP_OK -> OK); every enumerator of those enums has a twin."""
-    hdr = open(os.path.join(ROOT, "include", "bt709hip.h")).read()
+    hdr = abi_headers.text()
     seen = 0
     for enum in ("bt709hip_status", "bt709hip_format", "bt709hip_context_option", "bt709hip_decoder_option"):
         body = re.search(r"typedef enum \{([^}]*)\} %s;" % enum, hdr, flags=re.S).group(1)

@@ -118,3 +118,34 @@ def test_y4m_file_through_the_decoder(gh, oracle, tmp_path):
     with y4m.Y4MWriter(str(q), w, h) as wr:
         wr.write_pixel_buffer(buf)
     assert q.read_bytes() == p.read_bytes()
+
+
+@pytest.mark.gpu
+def test_bench_path_decodes_a_generated_clip(gh, tmp_path):
+    """bench.py --y4m (round 6): a 64-frame 1080p clip written by tools/make_y4m_clip.py -- the bundled QuickTime pattern panned,
+    through the GPU ENCODER, in the reference's file layout (Renderer/y4m_writer.h:61-241) -- fills the bench's ring (planar
+    chroma interleaved on the device, frames repeated to the ring length) and is decoded by the same launch the headline times;
+    bench.py byte-compares 48 rows of one ring frame per XCD band with the oracle's decode of the CLIP'S OWN planes and
+    reports it in the line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from make_y4m_clip import make_clip
+    clip = tmp_path / "qt_pattern_1080p.y4m"
+    assert make_clip(str(clip), frames=64, fps=60, ctx=gh.context()) == (1920, 1080)
+    with y4m.Y4MReader(str(clip)) as r:
+        assert (r.width, r.height, r.fps) == (1920, 1080, (60, 1))
+        frames = list(r)
+    assert len(frames) == 64 and not np.array_equal(frames[0][0], frames[1][0])  # the pan moves the picture
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--y4m", str(clip), "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--placement-tries", "1"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout)
+    assert d["data"] == "y4m" and d["value"] and d["parity_spot_check"] == "ok" and len(d["parity_spot_frames"]) == 8
+    assert "1920x1080" in d["config"]["workload"] and "a ring of 1024 frames = the 64 frames of the YUV4MPEG2" in d["config"]["workload"]
+    import hashlib
+    assert hashlib.sha256(clip.read_bytes()).hexdigest() in d["config"]["workload"]
+    assert d["roofline"]["kernel"].startswith("decode_nv12") and d["roofline"]["frac"] > 0.3

@@ -528,6 +528,17 @@ MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT
           "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS"]
 
 
+RESCALE_FILES = ("bt709_rescale.h", "bt709_rescale_half.hip", "bt709_rescale_scaled.hip")  # round 6 split bt709_rescale.hip
+
+
+def resolve(csrc, name, product):
+    """The file of `csrc` a gate anchors on: `name`, or -- for gates written against the former bt709_rescale.hip -- whichever of
+    its three successors holds the product text exactly once.  None when no file does."""
+    names = [name] if os.path.exists(os.path.join(csrc, name)) else (RESCALE_FILES if name == "bt709_rescale.hip" else ())
+    hits = [n for n in names if open(os.path.join(csrc, n)).read().count(product) == 1]
+    return hits[0] if len(hits) == 1 else None
+
+
 def make_lab_sources(dst=LAB_SRC):
     """csrc/ copied to `dst` with every gate re-inserted; returns dst."""
     from metalbt709decoder_amd import build as b
@@ -535,19 +546,20 @@ def make_lab_sources(dst=LAB_SRC):
         shutil.rmtree(dst)
     shutil.copytree(b.CSRC, dst)
     for name, product, lab in GATES:
-        path = os.path.join(dst, name)
+        found = resolve(dst, name, product)
+        if found is None:
+            raise SystemExit("tools/lab_variants.py: the product text this gate anchors on does not occur exactly once in csrc/%s "
+                             "(or its successors): re-state the experiment against the current kernel\n---\n%s" % (name, product))
+        path = os.path.join(dst, found)
         text = open(path).read()
-        if text.count(product) != 1:
-            raise SystemExit("tools/lab_variants.py: the product text this gate anchors on occurs %d times in csrc/%s "
-                             "(expected once): re-state the experiment against the current kernel\n---\n%s"
-                             % (text.count(product), name, product))
         open(path, "w").write(text.replace(product, lab))
-    # the copy sits two levels deeper than csrc/: point its include of the public header at the real one
+    # the copy sits two levels deeper than csrc/: point its includes of the public headers at the real ones
     for name in os.listdir(dst):
         path = os.path.join(dst, name)
         text = open(path).read()
-        if '"../../include/bt709hip.h"' in text:
-            open(path, "w").write(text.replace('"../../include/bt709hip.h"', '"%s"' % os.path.join(ROOT, "include", "bt709hip.h")))
+        for header in ("bt709hip.h", "bt709hip_ext.h"):
+            text = text.replace('"../../include/%s"' % header, '"%s"' % os.path.join(ROOT, "include", header))
+        open(path, "w").write(text)
     return dst
 
 

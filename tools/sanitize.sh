@@ -1,7 +1,7 @@
 #!/bin/bash
 # CPU sanitizer pass (GPU sanitizers are not available on this pool).  Runs in the build container; no GPU needed.
 #   1. the oracle and the product's HOST-side table builders under -fsanitize=address,undefined
-#   2. (round 5) the host shim itself -- csrc/bt709hip.cpp + bt709_ring.cpp: coalescing queues, pools, sharder, ring hunts, ring
+#   2. (round 5) the host shim itself -- csrc/shim_*.cpp + bt709_ring.cpp: coalescing queues, pools, sharder, ring hunts, ring
 #      sets -- compiled against the tests-only fake HIP runtime (tests/native/fake_hip/) and driven by tests/native/shim_stress.cpp
 #      under ASan + UBSan + LeakSanitizer and under TSan (the same two builds tests/test_fake_hip.py runs)
 set -e
@@ -52,7 +52,7 @@ for w, h in ((2, 2), (6, 4), (66, 12), (256, 16)):
         if w % 4 == 0 and h % 4 == 0: o.decode_nv12_half(g, y, c, alpha=a)
 print("oracle ok under asan+ubsan")
 PY
-SHIM="metalbt709decoder_amd/csrc/bt709hip.cpp metalbt709decoder_amd/csrc/bt709_ring.cpp metalbt709decoder_amd/csrc/transfer_tables.cpp tests/native/fake_hip/fake_hip.cpp tests/native/shim_stress.cpp"
+SHIM="metalbt709decoder_amd/csrc/shim_core.cpp metalbt709decoder_amd/csrc/shim_decode.cpp metalbt709decoder_amd/csrc/shim_convert.cpp metalbt709decoder_amd/csrc/shim_coalesce.cpp metalbt709decoder_amd/csrc/shim_pool_shard.cpp metalbt709decoder_amd/csrc/shim_introspect.cpp metalbt709decoder_amd/csrc/bt709_ring.cpp metalbt709decoder_amd/csrc/transfer_tables.cpp tests/native/fake_hip/fake_hip.cpp tests/native/shim_stress.cpp"
 CXXF="-std=c++17 -O1 -g -fno-omit-frame-pointer -Wall -Wno-format-truncation -Itests/native/fake_hip -Itests/native"
 g++ $CXXF -fsanitize=address,undefined $SHIM -o $T/shim_stress_asan -lpthread
 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 $T/shim_stress_asan
