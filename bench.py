@@ -548,6 +548,32 @@ def placement_dict(_capi, lib, ctx, ring, rings_resident):
             "device_memory_total_GB": round(total_b.value / 1e9, 1)}
 
 
+def memory_plan(g, args, world=1, lanes=1):
+    """What ONE rank (GPU) of this job will hold, worked out from the geometry alone (no GPU needed: --dry-run reports it too, and a
+    CPU test checks the 8-rank plan against a 288 GB MI355X and a 16 GB host budget).  Device: the ring allocated first (tries = 1,
+    kept for roofline.first_allocation_frac) + the placement hunt's budget for the hunted ring (bt709hip_ring_options: --hunt-max-gb,
+    or the library's default of twice the ring) -- of which the ring it keeps is a part.  Host: the frames are generated ONE AT A
+    TIME and uploaded (upload_frames), so a rank holds one frame being generated, its staging copy, and the `sample_frames` kept for
+    the oracle spot check -- not the ring."""
+    up = lambda v: (v + 255) // 256 * 256
+    frame_in, frame_out = g["y_bytes"] + g["c_bytes"], g["o_bytes"]
+    ring_bytes = g["ring"] * (up(frame_in) + up(frame_out))
+    hunted = max(1, args.placement_tries) > 1 and ring_bytes >= (256 << 20)
+    budget = int(args.hunt_max_gb * 1e9) if args.hunt_max_gb and not args.hunt_frugal else 2 * ring_bytes
+    device_peak = ring_bytes + (max(budget, ring_bytes) if hunted else 0)
+    kept = len(sample_frames(g["ring"]))
+    host = (kept + 2) * frame_in + 3 * 16 * g["OW"] * 4
+    clip = getattr(args, "clip", None)
+    if clip:
+        host += len(clip["frames"]) * frame_in
+    ranks = world * lanes
+    return {"ring_bytes": ring_bytes, "ring_in_bytes": g["ring"] * up(frame_in), "ring_out_bytes": g["ring"] * up(frame_out),
+            "rings_resident_after_setup": 2 if hunted else 1, "hunt_budget_bytes": budget if hunted else 0,
+            "device_peak_bytes_per_gpu": device_peak, "device_steady_bytes_per_gpu": ring_bytes * (2 if hunted else 1),
+            "host_bytes_per_rank": host, "ranks": ranks, "host_bytes_all_ranks": host * ranks,
+            "fits_288GB_per_gpu": device_peak <= 288 * 10**9 - (4 << 30)}
+
+
 def sample_frames(ring):
     """One frame of each eighth of the ring (= each XCD band of a whole-ring launch), first and last frame included."""
     if ring < 8:
@@ -1040,6 +1066,7 @@ def main(argv=None):
                          else "torch.distributed.run" if world > 1
                          else "threads (ONE process drives %d GPUs through bt709hip_ringset_*: one launch per device per step from one thread)" % lanes
                          if lanes > 1 else "single process"),
+            "memory_plan": memory_plan(g, args, world, lanes),
             "placement": getattr(runner, "placement", None),  # rank 0's ring: allocated `tries` times, the fastest-streaming pairing kept (untimed set-up)
             "device": runner.device,
             "arch": runner.arch,

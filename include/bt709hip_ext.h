@@ -122,7 +122,9 @@ int bt709hip_decoder_get_option(const bt709hip_decoder *dec, int option, int *va
  * the raw hipStream_t behind this API's back (its own kernels, hipStreamSynchronize) is not ordered after queued frames --
  * call bt709hip_decoder_flush first.  Frame and surface descriptors are copied at the call; the buffers they point to must
  * stay alive until the stream has passed the launch, as always.  A launch failure at issue time is returned by the call that
- * issued the queue.  Thread safety: as without the option (several threads may share a decoder; each queue is per stream). */
+ * issued the queue.  Thread safety: as without the option (several threads may share a decoder; each queue is per stream); while any decoder of a
+ * context coalesces, that context's stream-taking calls serialise on one mutex for the length of the launch calls they issue, and a
+ * call made while its stream records a graph issues that stream's queue only (aged queues of other streams wait for the next call). */
 int bt709hip_decoder_flush(bt709hip_decoder *dec, void *stream /* NULL = the context's default stream */);
 /* every stream's queue of this decoder */
 int bt709hip_decoder_flush_all(bt709hip_decoder *dec);
@@ -298,8 +300,8 @@ int bt709hip_shard_wait(bt709hip_shard *shard, uint64_t ticket, const void **bgr
  * benchmarks that want to report a kernel against the same box's copy rate (no reference twin). */
 int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_t bytes, void *stream);
 /* Placement-aware allocation of ONE streaming slab.  Takes up to `tries` candidates of `bytes` ONE AT A TIME against the incumbent
- * (at most two slabs are alive at any moment; freeing and allocating again hands out other physical pages, so holding them all
- * buys nothing), times a streaming copy (lower half onto upper half) plus a fill of the whole slab over each and keeps the fastest;
+ * (two slabs are alive while one is probed, three for the moment of an allocation: the slab that lost stays until the next
+ * candidate has its memory, so the allocator cannot hand the same block straight back; holding them all buys nothing), times a streaming copy (lower half onto upper half) plus a fill of the whole slab over each and keeps the fastest;
  * the slab kept has been overwritten by the probe (zero-filled) whenever a probe ran, and is NOT cleared otherwise (tries = 1, a slab
  * under 2 MiB).  rates_GBps (optional, `tries` floats; always fully written: 0 where no probe ran) receives the probe rates,
  * *chosen (optional) the index kept.  tries = 1 is bt709hip_malloc.

@@ -44,11 +44,18 @@ int flush_decoder(bt709hip_decoder *dec, hipStream_t s, bool all, bool aged_only
 // destroyed leaves the list under the same mutex (set_coalescing), so none of the pointers can dangle.
 int flush_stream(bt709hip_context *ctx, hipStream_t s, const bt709hip_decoder *skip) {
   if (ctx == nullptr || ctx->n_coalescing.load(std::memory_order_acquire) == 0) return BT709HIP_OK;
+  // While the CALLING stream records a graph only its own queue goes out: an aged queue of another stream may need a first-use
+  // table (an allocation + blocking copies: illegal on a thread that is capturing) and has nothing to do with this recording;
+  // it waits for the context's next call outside a capture.
+  const bool aged_too = !capturing(s);
+  // SERIALISATION: coalescing_mutex is held across the launches the loop issues, so while at least one decoder of the context
+  // coalesces, the context's stream-taking entry points run one at a time for the length of those (asynchronous, ~10 us) launch
+  // calls.  Contexts without a coalescing decoder never take the mutex (the counter above).
   std::lock_guard<std::mutex> lock(ctx->coalescing_mutex);
   int rc = BT709HIP_OK;
   for (bt709hip_decoder *d : ctx->coalescing)
     if (d != skip)
-      if (int e = flush_decoder(d, s, false, true)) rc = rc ? rc : e;
+      if (int e = flush_decoder(d, s, false, aged_too)) rc = rc ? rc : e;
   return rc;
 }
 
@@ -99,7 +106,7 @@ int coalescing_submit(bt709hip_decoder *dec, int count, const bt709hip_frame *fr
   if (int rc = flush_stream(dec->ctx, s, dec)) return rc;
   std::lock_guard<std::mutex> lock(dec->queue_mutex);
   PendingQueue *q = nullptr;
-  if (dec->coalesce_max_age_us > 0) {  // this decoder's queues of OTHER streams that have waited too long
+  if (dec->coalesce_max_age_us > 0 && !capturing(s)) {  // this decoder's queues of OTHER streams that have waited too long (never from inside a capture)
     const int64_t limit = now_us() - dec->coalesce_max_age_us;
     for (PendingQueue &c : dec->queues)
       if (c.stream != s && !c.frames.empty() && c.oldest_us <= limit)
@@ -138,7 +145,7 @@ int coalescing_submit(bt709hip_decoder *dec, int count, const bt709hip_frame *fr
   q->frames.insert(q->frames.end(), frames, frames + count);
   if (alphas != nullptr) q->alphas.insert(q->alphas.end(), alphas, alphas + count);
   q->outs.insert(q->outs.end(), outs, outs + count);
-  tl_kernel_name = "(queued: coalescing submit)";
+  set_kernel_name("(queued: coalescing submit)");
   if (q->frames.size() >= static_cast<size_t>(n)) return issue_queue(dec, *q);
   return BT709HIP_OK;
 }

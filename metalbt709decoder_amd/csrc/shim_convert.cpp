@@ -84,8 +84,8 @@ int bt709hip_unconvert_batch(bt709hip_decoder *dec, int count, const void *const
   batch.in_step = uniform ? byte_step(ycbcr_words[0], ycbcr_words[1]) : 0;
   batch.out_step = uniform ? byte_step(outs[0].bgra, outs[1].bgra) : 0;
   hipStream_t s = pick(dec->ctx, stream);
-  tl_kernel_name = launch_unconvert(t, batch, in_stride, outs[0].stride, static_cast<uint32_t>(width), static_cast<uint32_t>(height), vec,
-                                    dec->gamma == kGammaSRGB, s);
+  set_kernel_name(launch_unconvert(t, batch, in_stride, outs[0].stride, static_cast<uint32_t>(width), static_cast<uint32_t>(height), vec,
+                                    dec->gamma == kGammaSRGB, s));
   return finish_launch(s, wait_until_completed);
 }
 
@@ -203,7 +203,7 @@ static int render_scaled_launch(bt709hip_context *ctx, int count, const bt709hip
   const char *name = launch_render_scaled(p, count, in->format == BT709HIP_FORMAT_RGBA16F,
                                           static_cast<uint32_t>(ctx->props.multiProcessorCount), s);
   if (name == nullptr) return BT709HIP_ERR_UNSUPPORTED;  // a surface of 2 GiB or more
-  tl_kernel_name = name;
+  set_kernel_name(name);
   return finish_launch(s, wait_until_completed);
 }
 
@@ -277,7 +277,7 @@ int bt709hip_encode_batch(bt709hip_context *ctx, int count, const bt709hip_surfa
   p.bgra_stride = static_cast<uint32_t>(in0.stride);
   p.y_stride = static_cast<uint32_t>(out0.y_stride);
   p.cbcr_stride = static_cast<uint32_t>(out0.cbcr_stride);
-  tl_kernel_name = launch_encode(p, count, fast, ctx->xcd_bands != 0, s);
+  set_kernel_name(launch_encode(p, count, fast, ctx->xcd_bands != 0, s));
   HIP_TRY(hipGetLastError());
   if (wait_until_completed) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;
@@ -322,7 +322,7 @@ static int planes_call(bt709hip_context *ctx, const void *u, size_t u_stride, co
   p.wide = (cw % 8) == 0 && (u_stride % 8) == 0 && (v_stride % 8) == 0 && (cbcr_stride % 16) == 0 && aligned(u, 8) &&
            aligned(v, 8) && aligned(cbcr, 16);
   hipStream_t s = pick(ctx, stream);
-  tl_kernel_name = launch_planes(p, interleave, s);
+  set_kernel_name(launch_planes(p, interleave, s));
   HIP_TRY(hipGetLastError());
   if (wait) HIP_TRY(hipStreamSynchronize(s));
   return BT709HIP_OK;

@@ -8,8 +8,18 @@
 
 namespace bt709shim __attribute__((visibility("hidden"))) {
 
+// This thread's last failing HIP call and last launched kernel.  Touched through the functions below ONLY: an `extern
+// thread_local` read from another translation unit goes through a TLS wrapper that tests a weak, hidden init symbol, and in
+// this -fPIC library clang resolves that symbol to the load address instead of null -- the first kernel launch of round 6's
+// split shim jumped there (CPU tests cannot see it: nothing launches without a GPU).
+namespace {
 thread_local hipError_t tl_hip_error = hipSuccess;
 thread_local const char *tl_kernel_name = "";
+}  // namespace
+
+void set_kernel_name(const char *name) { tl_kernel_name = name; }
+const char *kernel_name() { return tl_kernel_name; }
+hipError_t last_hip_error() { return tl_hip_error; }
 
 int hip_fail(hipError_t e) {
   tl_hip_error = e;
@@ -361,6 +371,17 @@ bool pageable(const void *host) {
   }
   return attr.type == hipMemoryTypeUnregistered;
 }
+
+// Waits for what `s` holds up to HERE -- the copy just enqueued -- through an event of its own, not hipStreamSynchronize: work
+// another thread enqueues on the stream behind the copy is not waited for (round 5's advisor).
+int wait_for_copy(hipStream_t s) {
+  hipEvent_t e = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipError_t rc = hipEventRecord(e, s);
+  if (rc == hipSuccess) rc = hipEventSynchronize(e);
+  (void)hipEventDestroy(e);
+  return rc == hipSuccess ? BT709HIP_OK : hip_fail(rc);
+}
 }  // namespace
 }  // extern "C++"
 
@@ -375,7 +396,7 @@ int bt709hip_upload(bt709hip_context *ctx, void *dst_dev, size_t dst_pitch, cons
   HIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_host, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, s));
   // pageable source: the copy is complete when the call returns (the reference's fill* methods are synchronous,
   // MetalRenderContext.m:122-160); pinned memory (bt709hip_host_alloc) stays asynchronous
-  if (!capturing(s) && pageable(src_host)) HIP_TRY(hipStreamSynchronize(s));
+  if (!capturing(s) && pageable(src_host)) return wait_for_copy(s);
   return BT709HIP_OK;
 }
 
@@ -388,7 +409,7 @@ int bt709hip_download(bt709hip_context *ctx, void *dst_host, size_t dst_pitch, c
   FLUSH_STREAM(ctx, stream);
   hipStream_t s = pick(ctx, stream);
   HIP_TRY(hipMemcpy2DAsync(dst_host, dst_pitch, src_dev, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost, s));
-  if (!capturing(s) && pageable(dst_host)) HIP_TRY(hipStreamSynchronize(s));  // as above: a pageable target is filled on return
+  if (!capturing(s) && pageable(dst_host)) return wait_for_copy(s);  // as above: a pageable target is filled on return
   return BT709HIP_OK;
 }
 

@@ -379,8 +379,8 @@ int decode_batch_now(bt709hip_decoder *dec, int count, const bt709hip_frame *fra
   if (info.format == BT709HIP_FORMAT_RGBA16F) {  // the reference's pre-10.14 intermediate: linear-light halves
     if (int rc = ensure_half_table(dec, stream)) return rc;
     last_launch_shape() = LaunchShape{};
-    tl_kernel_name = launch_decode_rgba16f(p, dec->half, count, dec->has_alpha != 0, info.in_align, info.out_align,
-                                           static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), dec->xcd_bands != 0, s);
+    set_kernel_name(launch_decode_rgba16f(p, dec->half, count, dec->has_alpha != 0, info.in_align, info.out_align,
+                                           static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), dec->xcd_bands != 0, s));
     return finish_launch(s, wait_until_completed);
   }
   // Fast path: one short-lived workgroup per tile of a row pair, dispatched in address order
@@ -389,8 +389,8 @@ int decode_batch_now(bt709hip_decoder *dec, int count, const bt709hip_frame *fra
   const uint32_t gx = fast ? quads_tiles(p.width) : grid_x_for(dec->ctx, p.height / 2, count);
   const uint32_t threads = quads_block_threads(p.width);
   last_launch_shape() = LaunchShape{};
-  tl_kernel_name = launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
-                                 dec->gamma == kGammaSRGB, dec->nontemporal, dec->xcd_bands, gx, threads, s);
+  set_kernel_name(launch_decode(p, count, fast ? kVariantQuads : kVariantBlocks, dec->has_alpha != 0,
+                                 dec->gamma == kGammaSRGB, dec->nontemporal, dec->xcd_bands, gx, threads, s));
   return finish_launch(s, wait_until_completed);
 }
 
@@ -445,7 +445,7 @@ int bt709hip_decode_half_batch(bt709hip_decoder *dec, int count, const bt709hip_
   const uint32_t rep_groups = dec->half_workgroups > 0 ? static_cast<uint32_t>(dec->half_workgroups) : cus;
   const uint32_t rep_lds = (dec->half_lds_kb > 0 ? static_cast<uint32_t>(dec->half_lds_kb) : 160u) * 1024u;
   const char *name = rep ? launch_decode_half_rep(p, count, dec->has_alpha != 0, dec->nontemporal, rep_groups, rep_lds, s) : nullptr;
-  tl_kernel_name = name ? name : launch_decode_half(p, count, wide, dec->has_alpha != 0, dec->nontemporal, gx, threads, s);
+  set_kernel_name(name ? name : launch_decode_half(p, count, wide, dec->has_alpha != 0, dec->nontemporal, gx, threads, s));
   return finish_launch(s, wait_until_completed);
 }
 
@@ -471,7 +471,7 @@ int bt709hip_decode_scaled_batch(bt709hip_decoder *dec, int count, const bt709hi
   const char *name = launch_decode_scaled(p, count, dec->has_alpha != 0, info.in_align,
                                           static_cast<uint32_t>(dec->ctx->props.multiProcessorCount), s);
   if (name == nullptr) return BT709HIP_ERR_UNSUPPORTED;  // a plane of 2 GiB or more
-  tl_kernel_name = name;
+  set_kernel_name(name);
   return finish_launch(s, wait_until_completed);
 }
 

@@ -117,8 +117,10 @@ struct bt709hip_pool {
 
 namespace bt709shim __attribute__((visibility("hidden"))) {
 
-extern thread_local hipError_t tl_hip_error;      // bt709hip_last_hip_error
-extern thread_local const char *tl_kernel_name;   // bt709hip_last_kernel_name
+// this thread's last launched kernel / last failing HIP call (shim_core.cpp owns the thread-locals)
+void set_kernel_name(const char *name);  // bt709hip_last_kernel_name
+const char *kernel_name();
+hipError_t last_hip_error();             // bt709hip_last_hip_error
 
 int hip_fail(hipError_t e);  // records e for bt709hip_last_hip_error, clears the runtime's sticky copy -> BT709HIP_ERR_HIP
 

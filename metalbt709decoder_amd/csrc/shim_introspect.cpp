@@ -12,7 +12,7 @@ int bt709hip_copy_probe(bt709hip_context *ctx, void *dst, const void *src, size_
   if (dst == nullptr || src == nullptr || (bytes & 15) || !aligned(dst, 16) || !aligned(src, 16))
     return BT709HIP_ERR_INVALID_ARG;
   FLUSH_STREAM(ctx, stream);
-  tl_kernel_name = launch_copy_probe(dst, src, bytes, pick(ctx, stream));
+  set_kernel_name(launch_copy_probe(dst, src, bytes, pick(ctx, stream)));
   HIP_TRY(hipGetLastError());
   return BT709HIP_OK;
 }
@@ -25,9 +25,9 @@ int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, vo
   if (rates_GBps)
     for (int i = 0; i < tries; ++i) rates_GBps[i] = 0.0f;  // fully written whatever path is taken below
   if (int rc = bind(ctx)) return rc;
-  // Candidates are taken ONE AT A TIME against the incumbent (round 5): at most two slabs are alive at any moment -- round 4 held
-  // all `tries` of them, 34 GB for a 4K ring's output slab -- and the diversity does not suffer: hipFree + hipMalloc of a slab this
-  // size hands out other physical pages (profiles/r05_hunt_budget.txt).
+  // Candidates are taken ONE AT A TIME against the incumbent (round 5): two slabs are alive while one is probed (three for the
+  // moment of an allocation, see the loop) -- round 4 held all `tries` of them, 34 GB for a 4K ring's output slab -- and the
+  // diversity does not suffer: hipFree + hipMalloc of a slab this size hands out other physical pages (profiles/r05_hunt_budget.txt).
   const size_t half = (bytes / 2) & ~static_cast<size_t>(4095);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t s = ctx->default_stream;
@@ -51,24 +51,36 @@ int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, vo
     if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.0f) ms = 1e9f;
     return static_cast<float>(4.0 * (2.0 * static_cast<double>(half) + static_cast<double>(bytes)) / (ms * 1e-3) / 1e9);
   };
-  void *best_p = nullptr;
+  void *best_p = nullptr, *loser = nullptr;
   int best = -1;
   float best_rate = -1.0f;
   for (int i = 0; i < (probing ? tries : 1); ++i) {
+    // The slab that lost the previous comparison stays allocated until this candidate HAS its memory: freed first, the allocator
+    // could hand the very same block back and the "candidates" would be one placement probed `tries` times (round 5's advisor).
+    // Three slabs are alive for the moment of the allocation, two while probing.
     void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess && loser != nullptr) {  // no room for three: give the loser back and try once more
+      (void)hipGetLastError();
+      (void)hipFree(loser);
+      loser = nullptr;
+      e = hipMalloc(&p, bytes);
+    }
+    if (loser != nullptr) (void)hipFree(loser), loser = nullptr;
+    if (e != hipSuccess) {
       (void)hipGetLastError();
       break;  // out of memory: the incumbent (if any) stays
     }
     const float rate = probing ? probe(p) : 0.0f;
     if (rates_GBps) rates_GBps[i] = rate;
     if (best_p == nullptr || rate > best_rate) {
-      if (best_p != nullptr) (void)hipFree(best_p);
+      loser = best_p;
       best_p = p, best = i, best_rate = rate;
     } else {
-      (void)hipFree(p);
+      loser = p;
     }
   }
+  if (loser != nullptr) (void)hipFree(loser);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   (void)hipGetLastError();
@@ -78,7 +90,7 @@ int bt709hip_malloc_streaming(bt709hip_context *ctx, size_t bytes, int tries, vo
   return BT709HIP_OK;
 }
 
-const char *bt709hip_last_kernel_name(void) { return tl_kernel_name; }
+const char *bt709hip_last_kernel_name(void) { return kernel_name(); }
 
 int bt709hip_last_launch_info(bt709hip_launch_info *info) {
   if (info == nullptr) return BT709HIP_ERR_INVALID_ARG;

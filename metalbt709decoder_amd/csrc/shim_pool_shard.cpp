@@ -34,7 +34,7 @@ hipError_t alloc_pool_buffer(bt709hip_context *ctx, size_t bytes, uint8_t **out)
     void *p = nullptr;
     const int rc = bt709hip_malloc_streaming(ctx, bytes, ctx->streaming_tries, &p, nullptr, nullptr);
     *out = static_cast<uint8_t *>(p);
-    return rc == BT709HIP_OK ? hipSuccess : (tl_hip_error != hipSuccess ? tl_hip_error : hipErrorOutOfMemory);
+    return rc == BT709HIP_OK ? hipSuccess : (last_hip_error() != hipSuccess ? last_hip_error() : hipErrorOutOfMemory);
   }
   return hipMalloc(reinterpret_cast<void **>(out), bytes);
 }

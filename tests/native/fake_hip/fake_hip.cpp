@@ -439,6 +439,8 @@ hipError_t hipEventCreate(hipEvent_t *event) {
   rt().events.fetch_add(1);
   return hipSuccess;
 }
+hipError_t hipEventCreateWithFlags(hipEvent_t *event, unsigned) { return hipEventCreate(event); }
+
 hipError_t hipEventDestroy(hipEvent_t e) {
   if (e == nullptr) return fail(hipErrorInvalidResourceHandle);
   delete e;

@@ -89,6 +89,8 @@ hipError_t hipStreamBeginCapture(hipStream_t stream, hipStreamCaptureMode mode);
 hipError_t hipStreamEndCapture(hipStream_t stream, hipGraph_t *graph);
 
 hipError_t hipEventCreate(hipEvent_t *event);
+constexpr unsigned hipEventDisableTiming = 2;
+hipError_t hipEventCreateWithFlags(hipEvent_t *event, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t event);
 hipError_t hipEventRecord(hipEvent_t event, hipStream_t stream);
 hipError_t hipEventSynchronize(hipEvent_t event);

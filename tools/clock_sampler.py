@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Lab: samples the GPU's shader clock, memory clock and power from sysfs (hwmon of the amdgpu device; no privileges needed)
 every `period` seconds into a CSV until it is terminated, for "does a VALU-bound kernel lose clock when it is sustained?"
-(tools/rounds/r04_half_clock.sh).  usage: python tools/clock_sampler.py out.csv [period=0.05]
+(round 4: profiles/r04_half_clock.txt).  usage: python tools/clock_sampler.py out.csv [period=0.05]
    summary: python tools/clock_sampler.py --summary out.csv   (samples in the busiest half by power)"""
 import glob
 import os

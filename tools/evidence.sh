@@ -1,13 +1,16 @@
 #!/bin/bash
 # One-call evidence run on the GPU box: tests, every bench line, rocprof + PMC summaries.
-# usage (through gpurun, from the repo root): tools/evidence.sh r05
-R=${1:-r05}
+# usage (through gpurun, from the repo root): tools/evidence.sh r06
+R=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/$R; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log
 python bench.py --steps 20 --warmup 5 > $O/bench_4k_driver_args.json 2> $O/bench_4k.err
 python bench.py --no-cpu-baseline > $O/bench_4k.json 2>/dev/null
-python bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>/dev/null
+python bench.py --workload 1080p > $O/bench_1080p.json 2>/dev/null
+# round 6: the reference's own on-disk format as the bench's input -- a 64-frame 1080p clip written through the GPU encoder, then bench.py --y4m
+python tools/make_y4m_clip.py /tmp/qt_pattern_1080p.y4m --frames 64 > $O/make_y4m_clip.txt 2>&1
+python bench.py --y4m /tmp/qt_pattern_1080p.y4m > $O/bench_y4m.json 2> $O/bench_y4m.err
 python bench.py --workload 8k-half > $O/bench_8k-half.json 2>/dev/null
 for sh in 8 4 2 1; do python bench.py --workload 4k-batch8 --share $sh --no-cpu-baseline --steps 400 > $O/bench_batch8_share$sh.json 2>/dev/null; done
 python bench.py --workload 4k-batch8 --share 1 --streams 1 --no-cpu-baseline --steps 400 > $O/bench_batch8_share1_1stream.json 2>/dev/null

@@ -34,6 +34,7 @@ Gates (macro -> what it does; profiles/ file it produced):
   BT709_LAB_SCALED_HALF_FEWER_TAPS     any-ratio kernel, WRONG OUTPUT: the right tap a copy of the left one (half the decodes)  r06_ab_scaled_share.txt
   BT709_LAB_SCALED_PAIR_DPP            the same with the copy taken from the next lane by a DPP move (lane-pair exchange)      r06_ab_scaled_share.txt
   BT709_LAB_SCALED_ONCE_LDS            wave-decodes-once form exchanging through a wave-private LDS tile (same bytes out)      r06_ab_scaled_share.txt
+  BT709_LAB_HUNT_TRACE                 bt709hip_ring_create prints where its hunt's wall-clock time went (stderr; same ring)   r06_hunt_default.txt
 """
 import os
 import shutil
@@ -414,6 +415,101 @@ constexpr bool kRepUniformEncode = true;
     linearise6(r, x, rl.v);
 #endif
 """),
+    # round 6: where the placement hunt's wall-clock time goes (stderr, one line per ring): allocation, free, hipMemGetInfo, warm-up launches, probes
+    ("bt709_ring.cpp",
+     """  void *take(size_t bytes) {
+    void *p = nullptr;
+    if (bt709hip_malloc(ctx, bytes, &p) != BT709HIP_OK || p == nullptr) return nullptr;
+""",
+     """  void *take(size_t bytes) {
+    void *p = nullptr;
+#if defined(BT709_LAB_HUNT_TRACE)
+    const double t0 = now_s();
+    const int rc_ = bt709hip_malloc(ctx, bytes, &p);
+    lab_trace()[0] += now_s() - t0;
+    if (rc_ != BT709HIP_OK || p == nullptr) return nullptr;
+#else
+    if (bt709hip_malloc(ctx, bytes, &p) != BT709HIP_OK || p == nullptr) return nullptr;
+#endif
+"""),
+    ("bt709_ring.cpp",
+     """    if (p == nullptr) return;
+    (void)bt709hip_free(ctx, p);
+    held -= bytes;
+""",
+     """    if (p == nullptr) return;
+#if defined(BT709_LAB_HUNT_TRACE)
+    const double t0 = now_s();
+    (void)bt709hip_free(ctx, p);
+    lab_trace()[1] += now_s() - t0;
+#else
+    (void)bt709hip_free(ctx, p);
+#endif
+    held -= bytes;
+"""),
+    ("bt709_ring.cpp",
+     """    size_t free_b = 0;
+    return bt709hip_mem_info(ctx, &free_b, nullptr) == BT709HIP_OK && free_b >= bytes + kReserveBytes;
+""",
+     """    size_t free_b = 0;
+#if defined(BT709_LAB_HUNT_TRACE)
+    const double t0 = now_s();
+    const bool ok_ = bt709hip_mem_info(ctx, &free_b, nullptr) == BT709HIP_OK && free_b >= bytes + kReserveBytes;
+    lab_trace()[2] += now_s() - t0;
+    return ok_;
+#else
+    return bt709hip_mem_info(ctx, &free_b, nullptr) == BT709HIP_OK && free_b >= bytes + kReserveBytes;
+#endif
+"""),
+    ("bt709_ring.cpp",
+     """double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+""",
+     """double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#if defined(BT709_LAB_HUNT_TRACE)
+double *lab_trace() {  // seconds: malloc, free, mem_info, warm-up, probe
+  static double t[5] = {0, 0, 0, 0, 0};
+  return t;
+}
+#endif
+"""),
+    ("bt709_ring.cpp",
+     """    bind_slabs(r, in, out);
+    const double t_end = now_s() + warm_s;
+    do {
+      if ((rc = launch(r, 0, r->frames, nullptr, 1)) != BT709HIP_OK) return 0.0f;
+    } while (now_s() < t_end);
+""",
+     """    bind_slabs(r, in, out);
+#if defined(BT709_LAB_HUNT_TRACE)
+    const double lab_t0 = now_s();
+    struct LabProbe { double t0; ~LabProbe() { lab_trace()[4] += now_s() - t0; } };
+#endif
+    const double t_end = now_s() + warm_s;
+    do {
+      if ((rc = launch(r, 0, r->frames, nullptr, 1)) != BT709HIP_OK) return 0.0f;
+    } while (now_s() < t_end);
+#if defined(BT709_LAB_HUNT_TRACE)
+    lab_trace()[3] += now_s() - lab_t0;
+    LabProbe lab_probe{now_s()};
+#endif
+"""),
+    ("bt709_ring.cpp",
+     """  if (pl.tries > 1) pl.hunt_ms = static_cast<float>((now_s() - t_start) * 1e3);
+""",
+     """  if (pl.tries > 1) pl.hunt_ms = static_cast<float>((now_s() - t_start) * 1e3);
+#if defined(BT709_LAB_HUNT_TRACE)
+  if (pl.tries > 1) {
+    double *t = lab_trace();
+    std::fprintf(stderr, "hunt trace: total %.0f ms = malloc %.0f + free %.0f + mem_info %.0f + warm-up %.0f + probes %.0f + rest %.0f (candidates %d + %d)\\n", pl.hunt_ms,
+                 t[0] * 1e3, t[1] * 1e3, t[2] * 1e3, t[3] * 1e3, t[4] * 1e3, pl.hunt_ms - (t[0] + t[1] + t[2] + t[3] + t[4]) * 1e3, pl.in_candidates, pl.out_candidates);
+    for (int k = 0; k < 5; ++k) t[k] = 0.0;
+  }
+#endif
+"""),
     # round 6: the wave-decodes-once form's exchange through a wave-private LDS tile instead of ds_bpermute (same bytes out)
     ("bt709_rescale.hip",
      """      RowLin rl;
@@ -525,7 +621,7 @@ MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT
           "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
           "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE", "BT709_LAB_F16_NO_ARITH", "BT709_LAB_F16_NO_TABLE",
           "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_F16_DMA_STAGING", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32",
-          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS"]
+          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE"]
 
 
 RESCALE_FILES = ("bt709_rescale.h", "bt709_rescale_half.hip", "bt709_rescale_scaled.hip")  # round 6 split bt709_rescale.hip
