@@ -41,6 +41,29 @@ namespace bt709 {
 // ---------------------------------------------------------------------------
 enum : int { TAPS_BYTES = 0, TAPS_PAIRS = 1, TAPS_WIDE = 2, TAPS_SHARED = 3, TAPS_ONCE = 4 };
 
+// output rows whose source rows are fetched ahead of the row being produced (scaled_strip, "HOW FAR AHEAD"): per-lane tap
+// fetches (8 VGPRs per row in flight) and the two by-wave forms (4 per row)
+#ifndef BT709_SCALED_AHEAD
+#define BT709_SCALED_AHEAD 1
+#endif
+#ifndef BT709_SCALED_AHEAD_WAVE
+#define BT709_SCALED_AHEAD_WAVE 3
+#endif
+constexpr int kScaledAhead = BT709_SCALED_AHEAD, kScaledAheadWave = BT709_SCALED_AHEAD_WAVE;
+#ifndef BT709_SCALED_STORE_AUX
+#define BT709_SCALED_STORE_AUX 2  // cache-policy bits of the output store (buffer instruction aux operand): 2 = slc, a streaming store (the
+                                  // output is written once and not read again: 1080p -> 4K +6 %, one frame per launch +13 %, profiles/r06_ab_scaled_ahead.txt)
+#endif
+constexpr int kScaledStoreAux = BT709_SCALED_STORE_AUX;
+// pass 2 alone (render_scaled): rows fetched ahead from a BGRA8 (4 VGPRs per row in flight) / RGBA16Float (8) intermediate
+#ifndef BT709_RENDER_AHEAD8
+#define BT709_RENDER_AHEAD8 1
+#endif
+#ifndef BT709_RENDER_AHEAD16
+#define BT709_RENDER_AHEAD16 1
+#endif
+constexpr int kRenderAhead8 = BT709_RENDER_AHEAD8, kRenderAhead16 = BT709_RENDER_AHEAD16;
+
 // Vertical taps of a strip of at most 64 output rows starting at oy0: lane i holds row oy0 + i (sy = (oy + 0.5f) *
 // scale_y - 0.5f, y0 = floor(sy), fy = sy - y0).  gfx950 has no scalar float unit, so one evaluation costs 8 VALU
 // instructions per row whichever way it is written; done once per strip by the lanes in parallel, a row takes its
@@ -311,7 +334,7 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
       aw = alpha_word_of(av);
     }
     if (!BY_WAVE || live)
-      __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, oy * p.out_stride, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, oy * p.out_stride, kScaledStoreAux);
   };
 
   // The FETCH is unconditional and one output row ahead (a load the row does not need after all is an L2
@@ -323,25 +346,65 @@ __device__ __forceinline__ void scaled_strip(const DecodeParams &p, const Rescal
   // accounting takes the path with the fewest loads in flight, so one conditional fetch turns every
   // wait of the loop into a full drain.)
   const uint32_t last = oy1 - 1;
-  RowTaps rta = row_taps(oy0), rtb;
-  Fetched1 a0 = fetch_row(rta.ys[0]), a1 = fetch_row(rta.ys[1]), b0, b1;
-  for (uint32_t oy = oy0; oy < oy1; oy += 2) {
-    rtb = row_taps(min(oy + 1, last));
-    b0 = fetch_row(rtb.ys[0]);
-    b1 = fetch_row(rtb.ys[1]);
-    output_row(oy, rta, a0, a1);
-    if (oy + 1 >= oy1) {  // uniform.  Nothing stays in flight past the strip: a dangling load is a pending
-      landed(b0);         // write to registers the next strip reuses, i.e. a drain in every trip of ITS loop
-      landed(b1);
-      break;
+  // HOW FAR AHEAD (round 6).  gfx950 counts loads and stores in ONE in-order counter (vmcnt): waiting for the loads of row j
+  // also waits for every store issued before them.  One row ahead, the store of row j - 2 must have been acknowledged when row
+  // j starts -- and a wave's row takes ~1.2 us here, about what a store takes to come back from HBM under this write load: with
+  // the stores deleted, or the loads, the enlarging launch runs 27 % faster, with every lookup and all arithmetic deleted 9 %
+  // (profiles/r06_ab_scaled_parts.txt).  Fetching D rows ahead gives a store D row-times.  D + 1 register sets, D + 1 rows per trip.
+  constexpr int D = BY_WAVE ? kScaledAheadWave : kScaledAhead;
+  if constexpr (D == 1) {
+    RowTaps rta = row_taps(oy0), rtb;
+    Fetched1 a0 = fetch_row(rta.ys[0]), a1 = fetch_row(rta.ys[1]), b0, b1;
+    for (uint32_t oy = oy0; oy < oy1; oy += 2) {
+      rtb = row_taps(min(oy + 1, last));
+      b0 = fetch_row(rtb.ys[0]);
+      b1 = fetch_row(rtb.ys[1]);
+      output_row(oy, rta, a0, a1);
+      if (oy + 1 >= oy1) {  // uniform.  Nothing stays in flight past the strip: a dangling load is a pending
+        landed(b0);         // write to registers the next strip reuses, i.e. a drain in every trip of ITS loop
+        landed(b1);
+        break;
+      }
+      rta = row_taps(min(oy + 2, last));
+      a0 = fetch_row(rta.ys[0]);
+      a1 = fetch_row(rta.ys[1]);
+      output_row(oy + 1, rtb, b0, b1);
     }
-    rta = row_taps(min(oy + 2, last));
-    a0 = fetch_row(rta.ys[0]);
-    a1 = fetch_row(rta.ys[1]);
-    output_row(oy + 1, rtb, b0, b1);
+    landed(a0);
+    landed(a1);
+  } else {
+    struct RowFetch {
+      RowTaps rt;
+      Fetched1 f0, f1;
+    };
+    auto fetch_for = [&](uint32_t oy) {  // past the strip's end the last row again (see above)
+      RowFetch q;
+      q.rt = row_taps(min(oy, last));
+      q.f0 = fetch_row(q.rt.ys[0]);
+      q.f1 = fetch_row(q.rt.ys[1]);
+      return q;
+    };
+    RowFetch s[D + 1];
+#pragma unroll
+    for (int k = 0; k < D; ++k) s[k] = fetch_for(oy0 + static_cast<uint32_t>(k));
+    for (uint32_t oy = oy0; oy < oy1; oy += D + 1) {
+#pragma unroll
+      for (int u = 0; u <= D; ++u) {
+        s[(u + D) % (D + 1)] = fetch_for(oy + static_cast<uint32_t>(u + D));
+        if (oy + static_cast<uint32_t>(u) < oy1) {  // uniform
+          output_row(oy + static_cast<uint32_t>(u), s[u].rt, s[u].f0, s[u].f1);
+        } else {
+          landed(s[u].f0);
+          landed(s[u].f1);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {  // nothing stays in flight past the strip
+      landed(s[k].f0);
+      landed(s[k].f1);
+    }
   }
-  landed(a0);
-  landed(a1);
 }
 
 // A workgroup = 256 output columns x kScaledStrips strips of `scaled_rows` output rows of one frame; its
@@ -548,28 +611,42 @@ render_scaled(const RenderParams p) {
     const uint32_t G = encode_byte(r, add_sat(acc[1], 0.0f));
     const uint32_t B = encode_byte(r, add_sat(acc[2], 0.0f));
     const uint32_t A = alpha_word_of(acc[3]);
-    __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, A), rout, ox * 4u, oy * p.out_stride, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, A), rout, ox * 4u, oy * p.out_stride, kScaledStoreAux);
   };
   const uint32_t last = oy1 - 1;
-  RowTaps rta = row_taps(oy0), rtb;
-  Fetched a0 = fetch_row(rta.ys[0]), a1 = fetch_row(rta.ys[1]), b0, b1;
-  for (uint32_t oy = oy0; oy < oy1; oy += 2) {
-    rtb = row_taps(min(oy + 1, last));
-    b0 = fetch_row(rtb.ys[0]);
-    b1 = fetch_row(rtb.ys[1]);
-    output_row(oy, rta, a0, a1);
-    if (oy + 1 >= oy1) {
-      landed(b0);
-      landed(b1);
-      break;
+  // rows fetched ahead: as in scaled_strip ("HOW FAR AHEAD"): D + 1 register sets, D + 1 rows per trip
+  constexpr int D = IN_RGBA16F ? kRenderAhead16 : kRenderAhead8;
+  struct RowFetch {
+    RowTaps rt;
+    Fetched f0, f1;
+  };
+  auto fetch_for = [&](uint32_t oy) {  // past the strip's end the last row again
+    RowFetch q;
+    q.rt = row_taps(min(oy, last));
+    q.f0 = fetch_row(q.rt.ys[0]);
+    q.f1 = fetch_row(q.rt.ys[1]);
+    return q;
+  };
+  RowFetch s[D + 1];
+#pragma unroll
+  for (int k = 0; k < D; ++k) s[k] = fetch_for(oy0 + static_cast<uint32_t>(k));
+  for (uint32_t oy = oy0; oy < oy1; oy += D + 1) {
+#pragma unroll
+    for (int u = 0; u <= D; ++u) {
+      s[(u + D) % (D + 1)] = fetch_for(oy + static_cast<uint32_t>(u + D));
+      if (oy + static_cast<uint32_t>(u) < oy1) {  // uniform
+        output_row(oy + static_cast<uint32_t>(u), s[u].rt, s[u].f0, s[u].f1);
+      } else {
+        landed(s[u].f0);
+        landed(s[u].f1);
+      }
     }
-    rta = row_taps(min(oy + 2, last));
-    a0 = fetch_row(rta.ys[0]);
-    a1 = fetch_row(rta.ys[1]);
-    output_row(oy + 1, rtb, b0, b1);
   }
-  landed(a0);
-  landed(a1);
+#pragma unroll
+  for (int k = 0; k < D; ++k) {  // nothing stays in flight past the strip
+    landed(s[k].f0);
+    landed(s[k].f1);
+  }
 }
 
 const char *launch_render_scaled(const RenderParams &p_in, int frames, bool in_rgba16f, uint32_t compute_units, hipStream_t stream) {
@@ -631,7 +708,14 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
   const uint32_t cols = (p.out_width + kBlockThreads - 1) / kBlockThreads;
   const uint64_t want = static_cast<uint64_t>(BT709_SCALED_WG_PER_CU) * cus * kScaledStrips;
   uint32_t rows = static_cast<uint32_t>(static_cast<uint64_t>(cols) * p.out_height * static_cast<uint32_t>(frames) / want);
-  rows = rows < 1 ? 1 : (rows > BT709_SCALED_MAX_ROWS ? BT709_SCALED_MAX_ROWS : rows);
+#ifndef BT709_SCALED_MAX_ROWS_WAVE
+#define BT709_SCALED_MAX_ROWS_WAVE 32  // the by-wave forms fetch 3 rows ahead: a longer strip pays its prologue and drain less often
+#endif
+  static_assert(BT709_SCALED_MAX_ROWS_WAVE <= 64, "one lane per row of a strip works out its vertical taps");
+  const uint32_t max_rows = (taps == TAPS_ONCE || taps == TAPS_SHARED) ? BT709_SCALED_MAX_ROWS_WAVE : BT709_SCALED_MAX_ROWS;
+  rows = rows < 1 ? 1 : (rows > max_rows ? max_rows : rows);
+  // the by-wave forms produce kScaledAheadWave + 1 rows per trip of their loop: whole trips only (a partial trip still fetches for all its rows)
+  if ((taps == TAPS_ONCE || taps == TAPS_SHARED) && rows > static_cast<uint32_t>(kScaledAheadWave + 1)) rows -= rows % static_cast<uint32_t>(kScaledAheadWave + 1);
   p.scaled_rows = rows;
   const uint32_t strips = (p.out_height + rows - 1) / rows;
   const uint32_t strip_groups = (strips + kScaledStrips - 1) / kScaledStrips;

@@ -571,6 +571,25 @@ def test_no_experiment_gates_in_the_product_sources():
         assert lab_variants.resolve(csrc, name, product) is not None, (name, product[:60])
 
 
+def test_documents_cite_evidence_that_exists():
+    """Round 6: DESIGN.md is a contract a reader can use -- at most 30 KB, one evidence file per number -- and every
+    `profiles/...` path DESIGN.md or README.md cites is a file in the repository (a pattern with * must match at least one)."""
+    import glob
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 30 * 1024
+    for doc in ("DESIGN.md", "README.md"):
+        text = open(os.path.join(ROOT, doc), encoding="utf-8").read()
+        cited = set(re.findall(r"`(profiles/[A-Za-z0-9_\-./*+]+)`", text))
+        assert doc != "DESIGN.md" or len(cited) >= 15, cited
+        for path in sorted(cited):
+            path = path.rstrip(".")
+            hits = glob.glob(os.path.join(ROOT, path)) if "*" in path else [path] * os.path.exists(os.path.join(ROOT, path))
+            assert hits, "%s cites %s, which does not exist" % (doc, path)
+        for line in text.split("\n"):  # table cells a reader can take in: 300 characters in DESIGN.md's kernel table
+            if doc == "DESIGN.md" and line.startswith("| `") and "evidence" not in line[:40]:
+                for cell in line.strip("|").split("|"):
+                    assert len(cell.strip()) <= 330, (len(cell), cell[:80])
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.dirname(mb.__file__)
     for dirpath, _, files in os.walk(pkg):

@@ -34,6 +34,7 @@ Gates (macro -> what it does; profiles/ file it produced):
   BT709_LAB_SCALED_HALF_FEWER_TAPS     any-ratio kernel, WRONG OUTPUT: the right tap a copy of the left one (half the decodes)  r06_ab_scaled_share.txt
   BT709_LAB_SCALED_PAIR_DPP            the same with the copy taken from the next lane by a DPP move (lane-pair exchange)      r06_ab_scaled_share.txt
   BT709_LAB_SCALED_ONCE_LDS            wave-decodes-once form exchanging through a wave-private LDS tile (same bytes out)      r06_ab_scaled_share.txt
+  BT709_LAB_SCALED_NO_FETCH / _NO_DECODE / _NO_ENCODE / _NO_STORE  any-ratio kernel, WRONG OUTPUT: one part deleted each      r06_ab_scaled_parts.txt
   BT709_LAB_HUNT_TRACE                 bt709hip_ring_create prints where its hunt's wall-clock time went (stderr; same ring)   r06_hunt_default.txt
 """
 import os
@@ -510,6 +511,64 @@ double *lab_trace() {  // seconds: malloc, free, mem_info, warm-up, probe
   }
 #endif
 """),
+    # round 6: what bounds the any-ratio kernel at ratio >= 1 -- stubs that delete ONE part each (WRONG OUTPUT)
+    ("bt709_rescale.hip",
+     """  auto fetch_row = [&](int srow) {
+    Fetched1 v = {};
+""",
+     """  auto fetch_row = [&](int srow) {
+    Fetched1 v = {};
+#if defined(BT709_LAB_SCALED_NO_FETCH)  // no vector memory loads: the source bytes are made up from registers
+    v.y[0] = (ybase + static_cast<uint32_t>(srow)) * 0x9e3779b9u, v.y[1] = v.y[0] >> 3, v.c[0] = v.y[0] ^ 0x55aa55aau, v.c[1] = ~v.y[0];
+    v.c[2] = v.y[1], v.c[3] = v.c[0], v.a[0] = v.y[0], v.a[1] = v.y[1];
+    asm volatile("" : "+v"(v.y[0]), "+v"(v.y[1]), "+v"(v.c[0]), "+v"(v.c[1]));
+    if (true) return v;
+#endif
+"""),
+    ("bt709_rescale.hip",
+     """  auto decode_row = [&](const Fetched1 &raw, int srow) {
+    if (TAPS == TAPS_ONCE) {""",
+     """  auto decode_row = [&](const Fetched1 &raw, int srow) {
+#if defined(BT709_LAB_SCALED_NO_DECODE)  // no matrix, no decode-side lookups: six floats straight from the fetched bytes
+    {
+      RowLin rl;
+      const float tiny = __uint_as_float(0x2b800000u);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rl.v[k] = __fmul_rn(byte_of(k < 4 ? raw.y[0] : raw.c[0], k & 3), tiny);
+      rl.a[0] = rl.a[1] = 0.0f;
+      (void)srow;
+      if (true) return rl;
+    }
+#endif
+    if (TAPS == TAPS_ONCE) {"""),
+    ("bt709_rescale.hip",
+     """    const uint32_t R = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[0]) : encode_byte(r, acc[0]);
+    const uint32_t G = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[1]) : encode_byte(r, acc[1]);
+    const uint32_t B = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[2]) : encode_byte(r, acc[2]);
+""",
+     """#if defined(BT709_LAB_SCALED_NO_ENCODE)  // no encode-side lookups: a byte cut out of each float
+    const uint32_t R = (__float_as_uint(acc[0]) >> 15) & 0xffu, G = (__float_as_uint(acc[1]) >> 15) & 0xffu, B = (__float_as_uint(acc[2]) >> 15) & 0xffu;
+#else
+    const uint32_t R = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[0]) : encode_byte(r, acc[0]);
+    const uint32_t G = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[1]) : encode_byte(r, acc[1]);
+    const uint32_t B = UNIFORM_ENCODE ? encode_byte_uniform(r, acc[2]) : encode_byte(r, acc[2]);
+#endif
+"""),
+    ("bt709_rescale.hip",
+     """    if (!BY_WAVE || live)
+      __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, oy * p.out_stride, kScaledStoreAux);
+""",
+     """#if defined(BT709_LAB_SCALED_NO_STORE)  // (almost) no stores: about one pixel in 2^32
+    if ((!BY_WAVE || live) && pack_bgra(R, G, B, aw) + oy == 0x9e3779b9u)
+#else
+    if (!BY_WAVE || live)
+#endif
+#if defined(BT709_LAB_SCALED_STORE_ONE_LINE)  // every store instruction is issued, but all of a wave's rows go to ONE row of the frame: the lines stay in L2
+      __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, (oy & 1u) * p.out_stride, kScaledStoreAux);
+#else
+      __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, oy * p.out_stride, kScaledStoreAux);
+#endif
+"""),
     # round 6: the wave-decodes-once form's exchange through a wave-private LDS tile instead of ds_bpermute (same bytes out)
     ("bt709_rescale.hip",
      """      RowLin rl;
@@ -621,7 +680,7 @@ MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT
           "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
           "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE", "BT709_LAB_F16_NO_ARITH", "BT709_LAB_F16_NO_TABLE",
           "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_F16_DMA_STAGING", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32",
-          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE"]
+          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE", "BT709_LAB_SCALED_NO_FETCH", "BT709_LAB_SCALED_NO_DECODE", "BT709_LAB_SCALED_NO_ENCODE", "BT709_LAB_SCALED_NO_STORE", "BT709_LAB_SCALED_STORE_ONE_LINE"]
 
 
 RESCALE_FILES = ("bt709_rescale.h", "bt709_rescale_half.hip", "bt709_rescale_scaled.hip")  # round 6 split bt709_rescale.hip
