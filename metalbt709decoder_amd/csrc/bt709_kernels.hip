@@ -7,8 +7,9 @@
 //       byte = bucket[q].base + (x >= bucket[q].edge),  q = floor(x N)
 // (transfer_tables.h), x the saturated R, G or B.
 //
-// Memory plan (HBM-bound: 1.5 B read + 4 B written per pixel, no reuse between workgroups, so
-// no XCD-aware remap is needed):
+// Memory plan (HBM-bound: 1.5 B read + 4 B written per pixel, no reuse between workgroups -- nothing to keep in an L2 --
+// but the ORDER in which the eight XCDs walk a long launch decides how the DRAM streams interleave: batched launches of 64
+// frames or more give each XCD a contiguous band of the frames, see decode_nv12_quads below):
 //   * a lane owns 4-wide x 2-high pixel "quads": one dword of each luma row, one dword of CbCr
 //     (two Cb,Cr pairs, each shared by a 2x2 block -- chroma is REPLICATED, not interpolated:
 //     AAPLShaders.metal:350, BGRAToBT709Converter.m:267-277) and two 16-byte non-temporal
