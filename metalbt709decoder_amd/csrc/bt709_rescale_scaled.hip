@@ -716,13 +716,9 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
   rows = rows < 1 ? 1 : (rows > max_rows ? max_rows : rows);
   // the by-wave forms produce kScaledAheadWave + 1 rows per trip of their loop: whole trips only (a partial trip still fetches for all its rows)
   if ((taps == TAPS_ONCE || taps == TAPS_SHARED) && rows > static_cast<uint32_t>(kScaledAheadWave + 1)) rows -= rows % static_cast<uint32_t>(kScaledAheadWave + 1);
-  p.scaled_rows = rows;
-  const uint32_t strips = (p.out_height + rows - 1) / rows;
-  const uint32_t strip_groups = (strips + kScaledStrips - 1) / kScaledStrips;
   const size_t lds = (static_cast<size_t>(p.table_linear_bytes) << kScaledDecCopiesLog2) + ((kScaledUniform ? p.table_encode_u_bytes : p.table_encode_bytes) << kScaledEncCopiesLog2);
   const dim3 block(kBlockThreads, kScaledStrips);
   const bool persistent = taps == TAPS_ONCE ? BT709_SCALED_ONCE_PERSISTENT != 0 : taps != TAPS_SHARED;
-  dim3 grid(cols, strip_groups, static_cast<uint32_t>(frames));
   const void *fn = nullptr;
 #define BT709_PICK_SCALED(T, P)                                                                                        \
   fn = has_alpha ? reinterpret_cast<const void *>(&decode_nv12_scaled<T, true, P>) : reinterpret_cast<const void *>(&decode_nv12_scaled<T, false, P>)
@@ -732,11 +728,8 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
   else if (taps == TAPS_PAIRS) BT709_PICK_SCALED(TAPS_PAIRS, true);
   else BT709_PICK_SCALED(TAPS_BYTES, true);
 #undef BT709_PICK_SCALED
+  uint64_t resident = 0;
   if (persistent) {
-    const uint64_t items = static_cast<uint64_t>(cols) * strip_groups * static_cast<uint32_t>(frames);
-    if (items > 0x7fffffffull) return nullptr;
-    p.tiles_x = cols;
-    p.tile_rows = static_cast<uint32_t>(items);
     // as many workgroups as the chip holds at once (what the registers and the tables' LDS allow per CU).  The answer
     // depends on the kernel variant, on the dynamic LDS (the decode-side table's size follows the gamma's bucket count)
     // and on the device: a small cache keyed on all three (a miss just asks
@@ -762,7 +755,32 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
       slot.per_cu.store(per_cu, std::memory_order_relaxed);
       slot.fn.store(fn, std::memory_order_release);
     }
-    const uint64_t resident = static_cast<uint64_t>(per_cu) * cus;
+    resident = static_cast<uint64_t>(per_cu) * cus;
+#ifndef BT709_SCALED_BALANCE
+#define BT709_SCALED_BALANCE 1
+#endif
+    // ONE GENERATION (round 6): the resident workgroups take the items w, w + G, ...  A launch small enough for every workgroup
+    // to get ONE item should be cut that way: one 4K -> 1440p frame in strips of 7 rows (the 8-per-CU rule) is 2 057 items for
+    // 1 280 workgroups -- two for most, one for the rest -- in strips of 12 rows 1 200 items, one each: 19.6 -> 18.8 us.  Longer
+    // launches keep the rule (balancing them by the same count of items per workgroup measured 4-7 % SLOWER: the workgroups do not
+    // march in generations; profiles/r06_ab_scaled_ahead.txt).
+    if (BT709_SCALED_BALANCE && kScaledStrips == 1 && static_cast<uint64_t>(cols) * p.out_height * static_cast<uint32_t>(frames) <= resident * max_rows) {
+      for (uint32_t r = 4; r <= max_rows; ++r)
+        if (static_cast<uint64_t>(cols) * ((p.out_height + r - 1) / r) * static_cast<uint32_t>(frames) <= resident) {
+          rows = r;
+          break;
+        }
+    }
+  }
+  p.scaled_rows = rows;
+  const uint32_t strips = (p.out_height + rows - 1) / rows;
+  const uint32_t strip_groups = (strips + kScaledStrips - 1) / kScaledStrips;
+  dim3 grid(cols, strip_groups, static_cast<uint32_t>(frames));
+  if (persistent) {
+    const uint64_t items = static_cast<uint64_t>(cols) * strip_groups * static_cast<uint32_t>(frames);
+    if (items > 0x7fffffffull) return nullptr;
+    p.tiles_x = cols;
+    p.tile_rows = static_cast<uint32_t>(items);
     grid = dim3(static_cast<uint32_t>(items < resident ? items : resident), 1, 1);
   }
   void *args[] = {&p};
