@@ -569,6 +569,28 @@ double *lab_trace() {  // seconds: malloc, free, mem_info, warm-up, probe
       __builtin_amdgcn_raw_buffer_store_b32(pack_bgra(R, G, B, aw), ro, ox * 4u, oy * p.out_stride, kScaledStoreAux);
 #endif
 """),
+    # round 6: consecutive one-frame launches on ONE stream without the in-order barrier between them (hipExtAnyOrderLaunch; the header says "not supported on GFX9xx")
+    ("bt709_kernels.hip",
+     """      hipLaunchKernelGGL((decode_nv12_quads<false, true, false>), grid, block, lds, stream, p);
+""",
+     """#if defined(BT709_LAB_ANY_ORDER)
+      hipExtLaunchKernelGGL((decode_nv12_quads<false, true, false>), grid, block, lds, stream, nullptr, nullptr, hipExtAnyOrderLaunch, p);
+#else
+      hipLaunchKernelGGL((decode_nv12_quads<false, true, false>), grid, block, lds, stream, p);
+#endif
+"""),
+    ("bt709_kernels.hip",
+     """#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+""",
+     """#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <cstdint>
+#include <cstring>
+"""),
     # round 6: the wave-decodes-once form's exchange through a wave-private LDS tile instead of ds_bpermute (same bytes out)
     ("bt709_rescale.hip",
      """      RowLin rl;
@@ -680,7 +702,7 @@ MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT
           "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
           "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE", "BT709_LAB_F16_NO_ARITH", "BT709_LAB_F16_NO_TABLE",
           "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_F16_DMA_STAGING", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32",
-          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE", "BT709_LAB_SCALED_NO_FETCH", "BT709_LAB_SCALED_NO_DECODE", "BT709_LAB_SCALED_NO_ENCODE", "BT709_LAB_SCALED_NO_STORE", "BT709_LAB_SCALED_STORE_ONE_LINE"]
+          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE", "BT709_LAB_SCALED_NO_FETCH", "BT709_LAB_SCALED_NO_DECODE", "BT709_LAB_SCALED_NO_ENCODE", "BT709_LAB_SCALED_NO_STORE", "BT709_LAB_SCALED_STORE_ONE_LINE", "BT709_LAB_ANY_ORDER"]
 
 
 RESCALE_FILES = ("bt709_rescale.h", "bt709_rescale_half.hip", "bt709_rescale_scaled.hip")  # round 6 split bt709_rescale.hip
