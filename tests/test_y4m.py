@@ -73,6 +73,38 @@ def test_write_nv12_host_planes(tmp_path):
     assert np.array_equal(y2, y) and np.array_equal(u2, u) and np.array_equal(v2, v)
 
 
+def test_bench_takes_a_clip_on_the_dry_run_path(tmp_path):
+    """bench.py --y4m FILE without a GPU (--dry-run): the workload is the clip -- geometry from its header, the ring sized like
+    the headline's (256 x 4K worth of pixels, a multiple of 8 frames), `data` says "y4m", config.workload names the file's sha256,
+    and the memory plan counts the clip's frames held in host memory."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clip = tmp_path / "tiny.y4m"
+    with y4m.Y4MWriter(str(clip), 640, 360, fps=30) as w:
+        for i in range(5):
+            w.write_frame(*_frame(640, 360, 70 + i))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--y4m", str(clip), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.splitlines()[0])
+    ring = 256 * 3840 * 2160 // (640 * 360) // 8 * 8
+    assert d["data"] == "y4m" and d["metric"].startswith("Gpixel/s, y4m")
+    assert "640x360" in d["config"]["workload"] and "a ring of %d frames = the 5 frames of the YUV4MPEG2" % ring in d["config"]["workload"]
+    assert hashlib.sha256(clip.read_bytes()).hexdigest() in d["config"]["workload"]
+    plan = d["config"]["memory_plan"]
+    assert plan["ring_bytes"] == ring * ((640 * 360 * 3 // 2 + 255) // 256 * 256 + 640 * 360 * 4) and plan["host_bytes_per_rank"] > 5 * 640 * 360 * 3 // 2
+    # not a YUV4MPEG2 file: refused before anything is allocated
+    bad = tmp_path / "bad.y4m"
+    bad.write_bytes(b"RIFF....")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--y4m", str(bad)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "YUV4MPEG2" in r.stderr
+
+
 # ------------------------------------------------------------------ GPU
 
 @pytest.fixture(scope="module")
