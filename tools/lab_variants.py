@@ -591,6 +591,34 @@ double *lab_trace() {  // seconds: malloc, free, mem_info, warm-up, probe
 #include <cstdint>
 #include <cstring>
 """),
+    # round 6: the persistent 2:1 kernel (BASELINE config 4) with its loads or its stores deleted (WRONG OUTPUT): is its memory side anywhere near mattering?
+    ("bt709_rescale.hip",
+     """  in.ya = load32<NT>(y0 + 4 * q);
+  in.yb = load32<NT>(y0 + p.y_stride + 4 * q);
+  in.cw = load32<NT>(cc + 4 * q);
+  in.aa = in.ab = 0;
+""",
+     """#if defined(BT709_LAB_HALF_NO_FETCH)
+  in.ya = q * 0x9e3779b9u + c.rp, in.yb = in.ya >> 3, in.cw = ~in.ya;
+  asm volatile("" : "+v"(in.ya), "+v"(in.yb), "+v"(in.cw));
+  (void)y0, (void)cc;
+#else
+  in.ya = load32<NT>(y0 + 4 * q);
+  in.yb = load32<NT>(y0 + p.y_stride + 4 * q);
+  in.cw = load32<NT>(cc + 4 * q);
+#endif
+  in.aa = in.ab = 0;
+"""),
+    ("bt709_rescale.hip",
+     """      const uint32_t q = min(c.tx * blockDim.x + threadIdx.x, quads - 1);
+      store8<NT>(o + 8 * q, v);
+""",
+     """      const uint32_t q = min(c.tx * blockDim.x + threadIdx.x, quads - 1);
+#if defined(BT709_LAB_HALF_NO_STORE)
+      if (v.x + v.y == 0x9e3779b9u)
+#endif
+      store8<NT>(o + 8 * q, v);
+"""),
     # round 6: the wave-decodes-once form's exchange through a wave-private LDS tile instead of ds_bpermute (same bytes out)
     ("bt709_rescale.hip",
      """      RowLin rl;
@@ -702,7 +730,7 @@ MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT
           "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
           "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE", "BT709_LAB_F16_NO_ARITH", "BT709_LAB_F16_NO_TABLE",
           "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_F16_DMA_STAGING", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32",
-          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE", "BT709_LAB_SCALED_NO_FETCH", "BT709_LAB_SCALED_NO_DECODE", "BT709_LAB_SCALED_NO_ENCODE", "BT709_LAB_SCALED_NO_STORE", "BT709_LAB_SCALED_STORE_ONE_LINE", "BT709_LAB_ANY_ORDER"]
+          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE", "BT709_LAB_SCALED_NO_FETCH", "BT709_LAB_SCALED_NO_DECODE", "BT709_LAB_SCALED_NO_ENCODE", "BT709_LAB_SCALED_NO_STORE", "BT709_LAB_SCALED_STORE_ONE_LINE", "BT709_LAB_ANY_ORDER", "BT709_LAB_HALF_NO_FETCH", "BT709_LAB_HALF_NO_STORE"]
 
 
 RESCALE_FILES = ("bt709_rescale.h", "bt709_rescale_half.hip", "bt709_rescale_scaled.hip")  # round 6 split bt709_rescale.hip
