@@ -35,7 +35,9 @@ constexpr size_t kReserveBytes = 4ull << 30;  // device memory the hunt always l
 constexpr int kMaxTries = 6;
 // The hunt's own cost (round 6: the default hunt must fit ~1.5 s for a 12 GB ring; tools/ab_hunt.sh times variant builds of these)
 #ifndef BT709_HUNT_WARM_S
-#define BT709_HUNT_WARM_S 0.03  // synchronous launches over a candidate before its probe (page tables, clocks)
+#define BT709_HUNT_WARM_S 0.01  // synchronous launches over a candidate before its probe (page tables, clocks; the first candidate gets 150 ms).
+                                // 30 ms until round 6: 10 ms separates the placement levels as well (profiles/r06_hunt_default.txt box 2,
+                                // profiles/r06_partial_probe.txt) and takes a quarter of a second off a twelve-candidate hunt
 #endif
 #ifndef BT709_HUNT_CONFIRM_X
 #define BT709_HUNT_CONFIRM_X 6  // the finalists' probes are this many times as long as a prescan probe
