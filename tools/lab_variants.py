@@ -619,6 +619,16 @@ double *lab_trace() {  // seconds: malloc, free, mem_info, warm-up, probe
 #endif
       store8<NT>(o + 8 * q, v);
 """),
+    # round 6: which XCD takes which band of the launch's frames (rotation / reversal of the band index): does a placement's level follow it?
+    ("bt709_kernels.hip",
+     """  const uint32_t frame = p.xcd_bands == 1 ? (blockIdx.x & 7u) * p.frames_per_band + blockIdx.z
+""",
+     """#if defined(BT709_LAB_BAND_ROT)
+  const uint32_t frame = p.xcd_bands == 1 ? ((((blockIdx.x & 7u) + BT709_LAB_BAND_ROT) & 7u) ^ BT709_LAB_BAND_XOR) * p.frames_per_band + blockIdx.z
+#else
+  const uint32_t frame = p.xcd_bands == 1 ? (blockIdx.x & 7u) * p.frames_per_band + blockIdx.z
+#endif
+"""),
     # round 6: the wave-decodes-once form's exchange through a wave-private LDS tile instead of ds_bpermute (same bytes out)
     ("bt709_rescale.hip",
      """      RowLin rl;
@@ -730,7 +740,7 @@ MACROS = ["BT709_LAB_NO_ARITH", "BT709_LAB_NO_LOADS", "BT709_LAB_NO_STORES", "BT
           "BT709_INDEX_RTZ", "BT709_UNIFORM_INDEX_TWO_STEP", "BT709_REP_SPLIT_ENCODE", "BT709_LAB_BOUND_SHARED_INDEX",
           "BT709_LAB_BOUND_ONE_ENCODE", "BT709_LAB_HALF_TABLE", "BT709_LAB_F16_NO_ARITH", "BT709_LAB_F16_NO_TABLE",
           "BT709_LAB_F16_CVT_ONLY", "BT709_LAB_F16_NO_CAND_GATHER", "BT709_LAB_F16_NO_T_GATHER", "BT709_LAB_F16_NO_INDEX_SCALE", "BT709_LAB_F16_DMA_STAGING", "BT709_LAB_ENC_NO_ARITH", "BT709_LAB_UNC_NO_ARITH", "BT709_LAB_SCALED_QUARTER_FEWER_TAPS", "BT709_LAB_HALF_ENCODE_B32",
-          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE", "BT709_LAB_SCALED_NO_FETCH", "BT709_LAB_SCALED_NO_DECODE", "BT709_LAB_SCALED_NO_ENCODE", "BT709_LAB_SCALED_NO_STORE", "BT709_LAB_SCALED_STORE_ONE_LINE", "BT709_LAB_ANY_ORDER", "BT709_LAB_HALF_NO_FETCH", "BT709_LAB_HALF_NO_STORE"]
+          "BT709_LAB_SCALED_HALF_FEWER_TAPS", "BT709_LAB_SCALED_PAIR_DPP", "BT709_LAB_SCALED_ONCE_LDS", "BT709_LAB_HUNT_TRACE", "BT709_LAB_SCALED_NO_FETCH", "BT709_LAB_SCALED_NO_DECODE", "BT709_LAB_SCALED_NO_ENCODE", "BT709_LAB_SCALED_NO_STORE", "BT709_LAB_SCALED_STORE_ONE_LINE", "BT709_LAB_ANY_ORDER", "BT709_LAB_HALF_NO_FETCH", "BT709_LAB_HALF_NO_STORE", "BT709_LAB_BAND_ROT", "BT709_LAB_BAND_XOR"]
 
 
 RESCALE_FILES = ("bt709_rescale.h", "bt709_rescale_half.hip", "bt709_rescale_scaled.hip")  # round 6 split bt709_rescale.hip
