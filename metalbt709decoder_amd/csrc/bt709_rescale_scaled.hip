@@ -729,7 +729,7 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
   else BT709_PICK_SCALED(TAPS_BYTES, true);
 #undef BT709_PICK_SCALED
   uint64_t resident = 0;
-  if (persistent) {
+  {
     // as many workgroups as the chip holds at once (what the registers and the tables' LDS allow per CU).  The answer
     // depends on the kernel variant, on the dynamic LDS (the decode-side table's size follows the gamma's bucket count)
     // and on the device: a small cache keyed on all three (a miss just asks
@@ -764,8 +764,11 @@ const char *launch_decode_scaled(const DecodeParams &p_in, int frames, bool has_
     // 1 280 workgroups -- two for most, one for the rest -- in strips of 12 rows 1 200 items, one each: 19.6 -> 18.8 us.  Longer
     // launches keep the rule (balancing them by the same count of items per workgroup measured 4-7 % SLOWER: the workgroups do not
     // march in generations; profiles/r06_ab_scaled_ahead.txt).
+    // The forms that are not persistent (one workgroup per item, dispatched by the hardware) have the same tail: 2 700 workgroups
+    // for 2 048 places are 1.3 generations.  Their strips stay whole trips of the fetch loop (kScaledAheadWave + 1 rows).
+    const uint32_t step = persistent ? 1u : static_cast<uint32_t>(kScaledAheadWave + 1);
     if (BT709_SCALED_BALANCE && kScaledStrips == 1 && static_cast<uint64_t>(cols) * p.out_height * static_cast<uint32_t>(frames) <= resident * max_rows) {
-      for (uint32_t r = 4; r <= max_rows; ++r)
+      for (uint32_t r = 4; r <= max_rows; r += step)
         if (static_cast<uint64_t>(cols) * ((p.out_height + r - 1) / r) * static_cast<uint32_t>(frames) <= resident) {
           rows = r;
           break;
